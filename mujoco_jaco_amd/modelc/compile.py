@@ -1,0 +1,233 @@
+"""Model compiler: reference MJCF + STL  ->  committed model-constant blobs.
+
+  python -m mujoco_jaco_amd.modelc.compile            # needs /root/reference (not on the GPU box)
+
+Writes mujoco_jaco_amd/assets/<model>.jacomdl holding two views of the same model:
+
+* raw view (MuJoCo-style arrays, all 56 bodies) -- consumed by the fp64 oracle;
+* fused view (prefix ``f_``): welded bodies merged into 11 moving bodies + static
+  world, per-pair contact parameters pre-mixed, collision-pair whitelist -- consumed
+  by the HIP library.
+
+Collision filter and parameter mixing follow SURVEY.md App. C / D.1 step 3 [EXT].
+"""
+import os
+import sys
+
+import numpy as np
+
+from . import blob, kin, mjcf, rot
+
+REF_ASSETS = "/root/reference/env_script/assets/jaco2"
+OUT_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "assets")
+
+
+def collision_pairs(M):
+    ng = int(M["ngeom"][0])
+    weld, parent = M["body_weldid"], M["body_parentid"]
+    gb, ct, ca = M["geom_bodyid"], M["geom_contype"], M["geom_conaffinity"]
+    pairs = []
+    for g1 in range(ng):
+        for g2 in range(g1 + 1, ng):
+            w1, w2 = weld[gb[g1]], weld[gb[g2]]
+            if w1 == w2:
+                continue
+            if w1 != 0 and w2 != 0:
+                if weld[parent[w1]] == w2 or weld[parent[w2]] == w1:
+                    continue
+            if not ((ct[g1] & ca[g2]) or (ct[g2] & ca[g1])):
+                continue
+            pairs.append((g1, g2))
+    return np.array(pairs, dtype=np.int32).reshape(-1, 2)
+
+
+def mix_pair(M, g1, g2, timestep):
+    """condim / friction / solref / solimp of a geom pair (equal priority, equal solmix)."""
+    condim = max(M["geom_condim"][g1], M["geom_condim"][g2])
+    f = np.maximum(M["geom_friction"].reshape(-1, 3)[g1], M["geom_friction"].reshape(-1, 3)[g2])
+    solref = 0.5 * (M["geom_solref"].reshape(-1, 2)[g1] + M["geom_solref"].reshape(-1, 2)[g2])
+    solimp = 0.5 * (M["geom_solimp"].reshape(-1, 5)[g1] + M["geom_solimp"].reshape(-1, 5)[g2])
+    solref = solref.copy()
+    solref[0] = max(solref[0], 2 * timestep)  # refsafe
+    mu = np.array([f[0], f[0], f[1], f[2], f[2]])
+    margin = max(M["geom_margin"][g1], M["geom_margin"][g2])
+    return condim, mu, solref, solimp, margin
+
+
+def fuse(M, names, pairs):
+    """Merge weld groups; return dict of f_* arrays."""
+    nbody = int(M["nbody"][0])
+    weld = M["body_weldid"]
+    xpos, xquat, _, _ = kin.fk(M, M["qpos0"])
+    roots = [b for b in range(1, nbody) if weld[b] == b]
+    fid = {0: -1}
+    for i, r in enumerate(roots):
+        fid[r] = i
+    nmov = len(roots)
+    ipos = M["body_ipos"].reshape(-1, 3)
+    inertia = M["body_inertia"].reshape(-1, 3, 3)
+
+    def rel(b, w):
+        """pose of body b in the frame of its weld root w (constant: no joints in between)."""
+        qw = rot.quat_conj(xquat[w])
+        return rot.rot_vec(qw, xpos[b] - xpos[w]), rot.quat_normalize(rot.quat_mul(qw, xquat[b]))
+
+    F = {}
+    fparent, fpos, fquat, faxis, fjpos, fq0, fmass, fcom, finert = [], [], [], [], [], [], [], [], []
+    flim, frange, fdamp, ftype, fqadr, fdadr = [], [], [], [], [], []
+    for r in roots:
+        members = [b for b in range(1, nbody) if weld[b] == r]
+        mass = sum(M["body_mass"][b] for b in members)
+        com = np.zeros(3)
+        for b in members:
+            p, q = rel(b, r)
+            com += M["body_mass"][b] * (p + rot.rot_vec(q, ipos[b]))
+        com /= mass
+        I = np.zeros((3, 3))
+        for b in members:
+            if M["body_mass"][b] <= 0:
+                continue
+            p, q = rel(b, r)
+            R = rot.quat_to_mat(q)
+            d = p + R @ ipos[b] - com
+            I += R @ inertia[b] @ R.T + M["body_mass"][b] * (np.dot(d, d) * np.eye(3) - np.outer(d, d))
+        pw = weld[M["body_parentid"][r]]
+        fparent.append(fid[pw])
+        # frame of r relative to its fused parent at qpos0 (hinge angle 0) == composition of static frames
+        if pw == 0:
+            p, q = xpos[r] - 0, xquat[r]
+            # static ancestors of r may be offset from the world origin; xpos at qpos0 already includes them
+        else:
+            qw = rot.quat_conj(xquat[pw])
+            p, q = rot.rot_vec(qw, xpos[r] - xpos[pw]), rot.quat_normalize(rot.quat_mul(qw, xquat[r]))
+        fpos.append(p)
+        fquat.append(q)
+        j = M["body_jntadr"][r]
+        assert M["body_jntnum"][r] == 1
+        ftype.append(M["jnt_type"][j])
+        faxis.append(M["jnt_axis"].reshape(-1, 3)[j])
+        fjpos.append(M["jnt_pos"].reshape(-1, 3)[j])
+        fq0.append(M["qpos0"][M["jnt_qposadr"][j]] if M["jnt_type"][j] == mjcf.JNT_HINGE else 0.0)
+        fqadr.append(M["jnt_qposadr"][j])
+        fdadr.append(M["jnt_dofadr"][j])
+        flim.append(M["jnt_limited"][j])
+        frange.append(M["jnt_range"].reshape(-1, 2)[j])
+        fdamp.append(M["dof_damping"][M["jnt_dofadr"][j]])
+        fmass.append(mass)
+        fcom.append(com)
+        finert.append([I[0, 0], I[1, 1], I[2, 2], I[0, 1], I[0, 2], I[1, 2]])
+    f64 = lambda x: np.ascontiguousarray(np.array(x, dtype=np.float64).reshape(-1))
+    i32 = lambda x: np.ascontiguousarray(np.array(x, dtype=np.int32).reshape(-1))
+    F["f_nbody"] = i32([nmov])
+    F["f_parent"], F["f_jtype"] = i32(fparent), i32(ftype)
+    F["f_qposadr"], F["f_dofadr"] = i32(fqadr), i32(fdadr)
+    F["f_pos"], F["f_quat"], F["f_axis"], F["f_jpos"] = f64(fpos), f64(fquat), f64(faxis), f64(fjpos)
+    F["f_qpos0"], F["f_mass"], F["f_com"], F["f_inertia"] = f64(fq0), f64(fmass), f64(fcom), f64(finert)
+    F["f_limited"], F["f_range"], F["f_damping"] = i32(flim), f64(frange), f64(fdamp)
+
+    # ---- geoms that can collide with anything (appear in the pair list), re-indexed
+    used = sorted(set(pairs.reshape(-1).tolist()))
+    gmap = {g: i for i, g in enumerate(used)}
+    biw = M["body_invweight0"].reshape(-1, 2)
+    gbody, gpos, gquat, gmocap = [], [], [], []
+    for g in used:
+        b = M["geom_bodyid"][g]
+        w = weld[b]
+        gq = M["geom_quat"].reshape(-1, 4)[g]
+        gp = M["geom_pos"].reshape(-1, 3)[g]
+        mid = M["body_mocapid"][b]
+        gmocap.append(mid)
+        if mid >= 0:  # pose relative to the mocap body, composed at run time
+            gbody.append(-1)
+            gpos.append(gp)
+            gquat.append(gq)
+            continue
+        if w == 0:
+            p, q = xpos[b], xquat[b]
+        else:
+            p, q = rel(b, w)
+        gbody.append(fid[w])
+        gpos.append(p + rot.rot_vec(q, gp))
+        gquat.append(rot.quat_normalize(rot.quat_mul(q, gq)))
+    F["f_ngeom"] = i32([len(used)])
+    F["f_geom_orig"] = i32(used)
+    F["f_geom_body"], F["f_geom_mocap"] = i32(gbody), i32(gmocap)
+    F["f_geom_origbody"] = i32([M["geom_bodyid"][g] for g in used])
+    F["f_geom_type"] = i32([M["geom_type"][g] for g in used])
+    F["f_geom_pos"], F["f_geom_quat"] = f64(gpos), f64(gquat)
+    F["f_geom_size"] = f64([M["geom_size"].reshape(-1, 3)[g] for g in used])
+    F["f_geom_rbound"] = f64([M["geom_rbound"][g] for g in used])
+    F["f_geom_vertadr"] = i32([M["mesh_vertadr"][M["geom_dataid"][g]] if M["geom_dataid"][g] >= 0 else 0 for g in used])
+    F["f_geom_vertnum"] = i32([M["mesh_vertnum"][M["geom_dataid"][g]] if M["geom_dataid"][g] >= 0 else 0 for g in used])
+    F["f_geom_invweight"] = f64([biw[M["geom_bodyid"][g]] for g in used])
+
+    # ---- pair table with pre-mixed parameters
+    dt = float(M["opt_timestep"][0])
+    pp, pdim, pmu, pref, pimp, pmargin = [], [], [], [], [], []
+    for g1, g2 in pairs:
+        condim, mu, solref, solimp, margin = mix_pair(M, g1, g2, dt)
+        pp.append((gmap[g1], gmap[g2]))
+        pdim.append(condim)
+        pmu.append(mu)
+        pref.append(solref)
+        pimp.append(solimp)
+        pmargin.append(margin)
+    F["f_npair"] = i32([len(pairs)])
+    F["f_pair_geom"], F["f_pair_condim"] = i32(pp), i32(pdim)
+    F["f_pair_mu"], F["f_pair_solref"], F["f_pair_solimp"] = f64(pmu), f64(pref), f64(pimp)
+    F["f_pair_margin"] = f64(pmargin)
+
+    # ---- touch sites
+    sb, sp, sq = [], [], []
+    for s in M["sensor_siteid"]:
+        b = M["site_bodyid"][s]
+        p, q = rel(b, weld[b])
+        sb.append(fid[weld[b]])
+        sp.append(p + rot.rot_vec(q, M["site_pos"].reshape(-1, 3)[s]))
+        sq.append(rot.quat_normalize(rot.quat_mul(q, M["site_quat"].reshape(-1, 4)[s])))
+    F["f_nsensor"] = i32([len(sb)])
+    F["f_site_body"], F["f_site_pos"], F["f_site_quat"] = i32(sb), f64(sp), f64(sq)
+    F["f_site_type"] = i32([M["site_type"][s] for s in M["sensor_siteid"]])
+    F["f_site_size"] = f64([M["site_size"].reshape(-1, 3)[s] for s in M["sensor_siteid"]])
+    F["f_site_origbody"] = i32([M["site_bodyid"][s] for s in M["sensor_siteid"]])
+
+    # ---- named frames the task logic reads (env_mujoco_util.py:35,107,310)
+    for nm in ("EE", "EE_obj", "link1", "object_body", "object_dest"):
+        if nm in names["body"]:
+            b = names["body"].index(nm)
+            w = weld[b]
+            p, q = (xpos[b], xquat[b]) if w == 0 else rel(b, w)
+            F["f_frame_" + nm] = f64(np.concatenate([[fid[w]], p, q]))
+    return F
+
+
+def compile_model(xml_name, timestep=0.001):
+    """timestep: the reference overrides model.opt.timestep with 0.001 (mujoco.py:39, env_mujoco_util.py:30)."""
+    M, names = mjcf.parse(os.path.join(REF_ASSETS, xml_name + ".xml"), timestep=timestep)
+    biw, diw, meaninertia = kin.invweights(M)
+    M["body_invweight0"] = np.ascontiguousarray(biw.reshape(-1))
+    M["dof_invweight0"] = diw
+    M["meaninertia"] = np.array([meaninertia])
+    pairs = collision_pairs(M)
+    M["pair_geom"] = np.ascontiguousarray(pairs.reshape(-1))
+    M["npair"] = np.array([len(pairs)], dtype=np.int32)
+    M.update(fuse(M, names, pairs))
+    return M, names
+
+
+def main():
+    os.makedirs(OUT_DIR, exist_ok=True)
+    for xml_name in ("jaco2_curtain_torque", "jaco2_reaching_torque"):
+        M, names = compile_model(xml_name)
+        path = os.path.join(OUT_DIR, xml_name + ".jacomdl")
+        blob.save(path, M)
+        with open(os.path.join(OUT_DIR, xml_name + ".names.txt"), "w") as f:
+            for k, v in names.items():
+                f.write(k + ": " + " ".join(n if n else "-" for n in v) + "\n")
+        print(xml_name, "nq", M["nq"][0], "nv", M["nv"][0], "nbody", M["nbody"][0], "ngeom", M["ngeom"][0],
+              "npair", M["npair"][0], "f_nbody", M["f_nbody"][0], "f_ngeom", M["f_ngeom"][0],
+              "hullverts", len(M["mesh_vert"]) // 3, "bytes", os.path.getsize(path))
+
+
+if __name__ == "__main__":
+    sys.exit(main())
