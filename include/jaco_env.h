@@ -1,0 +1,108 @@
+/* C ABI of the MI355X-native batched Jaco environment (libjaco_env.so).
+ *
+ * The reference has no FFI of its own: its only native boundary is mujoco-py's Cython layer
+ * (mujoco_py.cymj), crossed at the call sites listed per entry point below (all paths relative to
+ * /root/reference).  This library replaces what sits behind those calls, batched over num_envs
+ * independent environments, one 64-lane wavefront per environment.
+ *
+ * Conventions: every function returns 0 on success and a negative JACO_E* code on failure, never
+ * throws; jaco_last_error() gives the message.  All "*_dev" arguments are DEVICE pointers supplied and
+ * owned by the caller (e.g. torch tensor .data_ptr()); the library owns only its model constants,
+ * per-env state and scratch.  Calls are asynchronous on the given HIP stream (hipStream_t passed as
+ * void*; NULL = default stream) and perform no hidden synchronisation unless stated.  One handle per
+ * GPU; a handle is not thread-safe (the reference is single-threaded: main.py:27).
+ *
+ * Batched array layout: row-major [num_envs][n] fp32, i.e. the 64 lanes of the wavefront that owns
+ * environment e read consecutive addresses of row e.
+ */
+#ifndef JACO_ENV_H
+#define JACO_ENV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JACO_OK 0
+#define JACO_EINVAL (-1)   /* bad argument / model */
+#define JACO_EHIP (-2)     /* HIP runtime error */
+#define JACO_ENODEV (-3)   /* no usable gfx950 device */
+
+/* per-env sticky flag bits (jaco_get_flags) */
+#define JACO_FLAG_CON_OVERFLOW 1u   /* more contacts than the per-env contact buffer */
+#define JACO_FLAG_EFC_OVERFLOW 2u   /* more constraint rows than the per-env row buffer */
+#define JACO_FLAG_CAND_OVERFLOW 4u  /* more broadphase survivors than the candidate buffer */
+#define JACO_FLAG_NAN 8u            /* non-finite velocity: env should be reset */
+#define JACO_FLAG_SOLVER_MAXITER 16u
+
+/* task ids (env_script/env_mujoco.py:18-23; only picking/placing return the 4-tuple step() unpacks) */
+#define JACO_TASK_PICKING 0
+#define JACO_TASK_PLACING 1
+#define JACO_TASK_REACHING 2
+
+typedef struct JacoHandle JacoHandle;
+
+typedef struct JacoConfig {
+  const void* model_blob;      /* JACOMDL1 bytes (host memory), see mujoco_jaco_amd/modelc */
+  size_t model_blob_size;
+  int num_envs;
+  int device;                  /* HIP device ordinal */
+  int frame_skip;              /* physics substeps per env step; reference: 50 (env_mujoco.py:24) */
+  int task;                    /* JACO_TASK_* */
+  uint64_t seed;               /* counter-based RNG seed for reset / sub-goal noise */
+} JacoConfig;
+
+/* JacoMujocoEnvUtil.__init__ -> MujocoConfig(xml) + Mujoco.connect()  (env_mujoco_util.py:28-33,
+ * mujoco_config.py:74 mjp.load_model_from_path, mujoco.py:55-56 MjSim + forward). */
+int jaco_create(const JacoConfig* cfg, JacoHandle** out);
+int jaco_destroy(JacoHandle* h);
+/* Message of the last failure on this handle; pass NULL for a failure of jaco_create itself. */
+const char* jaco_last_error(const JacoHandle* h);
+
+/* model.nq / nv / nu, len(sensordata); observation and action widths (env_mujoco.py:51-63,79-89). */
+int jaco_dims(const JacoHandle* h, int* nq, int* nv, int* nu, int* nsensor, int* nobs, int* nact);
+int jaco_num_envs(const JacoHandle* h);
+
+/* sim.get_state()/set_state() + sim.data.qpos/qvel writes (mujoco.py:213-246,332-347).
+ * Any pointer may be NULL to skip that field.  qacc_warmstart is part of the state because the
+ * constraint solver is warm-started from it, as in MuJoCo. Device-to-device copies on `stream`. */
+int jaco_set_state(JacoHandle* h, const float* qpos_dev, const float* qvel_dev, const float* qacc_ws_dev, void* stream);
+int jaco_get_state(JacoHandle* h, float* qpos_dev, float* qvel_dev, float* qacc_ws_dev, void* stream);
+/* sim.reset() for every env: qpos0, zero velocities (env_mujoco_util.py:93). */
+int jaco_reset_state(JacoHandle* h, void* stream);
+
+/* Mujoco.send_forces(u): sim.data.ctrl[:] = u; sim.step()  (mujoco.py:258-278), `nsub` times with
+ * the same ctrl, for all envs.  ctrl_dev: [num_envs][nu] fp32.  This is the ctrl-level entry used
+ * for oracle parity and the physics benchmark. */
+int jaco_physics_step(JacoHandle* h, const float* ctrl_dev, int nsub, void* stream);
+
+/* sim.data.get_sensor(...) for the 20 touch sensors (env_mujoco_util.py:470-475): values computed
+ * by the last substep, sensordata order of the XML (EE_touch first). out_dev: [num_envs][nsensor]. */
+int jaco_get_sensordata(JacoHandle* h, float* out_dev, void* stream);
+
+/* Per-env sticky error bits / last-substep statistics [num_envs][4] = {ncon, nefc, solver iterations,
+ * narrowphase candidates}. */
+int jaco_get_flags(JacoHandle* h, uint32_t* out_dev, void* stream);
+int jaco_clear_flags(JacoHandle* h, void* stream);
+int jaco_get_stats(JacoHandle* h, int32_t* out_dev, void* stream);
+
+/* Solver / collision options, MuJoCo <option> names: "iterations", "tolerance", "ls_iterations",
+ * "disable_contact" (contact flag), "mpr_iterations", "mpr_tolerance". */
+int jaco_set_option(JacoHandle* h, const char* name, double value);
+
+/* Test hook: like jaco_physics_step but also copies the stage dump of environment `env` taken in
+ * the last substep (layout: JDBG_* in csrc/physics_kernel.h) to host memory; synchronises. */
+int jaco_physics_step_debug(JacoHandle* h, const float* ctrl_dev, int nsub, int env, float* dump_host, int dump_floats);
+int jaco_debug_dump_floats(void);
+
+/* Average device time of the physics kernel over the launches since the last call, measured with HIP
+ * events on the stream the kernel was launched on (bench.py roofline leg); synchronises. */
+int jaco_kernel_time_ms(JacoHandle* h, double* avg_ms, int* launches);
+int jaco_enable_timing(JacoHandle* h, int enable);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JACO_ENV_H */

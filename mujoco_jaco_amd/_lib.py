@@ -1,0 +1,62 @@
+"""ctypes binding of libjaco_env.so (C ABI: include/jaco_env.h).
+
+There is deliberately no fallback: if the HIP extension has not been built
+(``python -c "import __graft_entry__ as g; g.build()"``) importing this module raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libjaco_env.so")
+ASSETS = os.path.join(_HERE, "assets")
+
+
+class JacoConfig(ctypes.Structure):
+    _fields_ = [("model_blob", ctypes.c_void_p), ("model_blob_size", ctypes.c_size_t), ("num_envs", ctypes.c_int),
+                ("device", ctypes.c_int), ("frame_skip", ctypes.c_int), ("task", ctypes.c_int), ("seed", ctypes.c_uint64)]
+
+
+# every symbol include/jaco_env.h declares: name -> (restype, argtypes)
+_vp, _ci, _cd, _cp = ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_char_p
+_ip = ctypes.POINTER(ctypes.c_int)
+SYMBOLS = {
+    "jaco_create": (_ci, [ctypes.POINTER(JacoConfig), ctypes.POINTER(_vp)]),
+    "jaco_destroy": (_ci, [_vp]),
+    "jaco_last_error": (_cp, [_vp]),
+    "jaco_dims": (_ci, [_vp, _ip, _ip, _ip, _ip, _ip, _ip]),
+    "jaco_num_envs": (_ci, [_vp]),
+    "jaco_set_state": (_ci, [_vp, _vp, _vp, _vp, _vp]),
+    "jaco_get_state": (_ci, [_vp, _vp, _vp, _vp, _vp]),
+    "jaco_reset_state": (_ci, [_vp, _vp]),
+    "jaco_physics_step": (_ci, [_vp, _vp, _ci, _vp]),
+    "jaco_get_sensordata": (_ci, [_vp, _vp, _vp]),
+    "jaco_get_flags": (_ci, [_vp, _vp, _vp]),
+    "jaco_clear_flags": (_ci, [_vp, _vp]),
+    "jaco_get_stats": (_ci, [_vp, _vp, _vp]),
+    "jaco_set_option": (_ci, [_vp, _cp, _cd]),
+    "jaco_physics_step_debug": (_ci, [_vp, _vp, _ci, _ci, ctypes.POINTER(ctypes.c_float), _ci]),
+    "jaco_debug_dump_floats": (_ci, []),
+    "jaco_kernel_time_ms": (_ci, [_vp, ctypes.POINTER(_cd), _ip]),
+    "jaco_enable_timing": (_ci, [_vp, _ci]),
+}
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "mujoco_jaco_amd: %s is missing. Build the HIP extension first "
+                "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback." % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def model_path(name):
+    return os.path.join(ASSETS, name + ".jacomdl")

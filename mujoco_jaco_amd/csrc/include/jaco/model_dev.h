@@ -1,0 +1,70 @@
+// Device-side model constants (fp32), built on the host from the fused view of a JACOMDL1 blob
+// (mujoco_jaco_amd/modelc/compile.py) and uploaded once per handle.  Plain-old-data: shared by
+// the host loader (model_blob.cpp) and the kernels.  Index conventions follow the reference's
+// joint discovery (env_script/mujoco.py:60-88): dofs 0..5 arm, 6..8 fingers, then free bodies.
+#pragma once
+
+#define JNB 11        // moving (fused) bodies: 6 links, 3 fingers, object, destination pedestal
+#define JNV 21        // dofs
+#define JNQ 23        // generalized positions
+#define JNU 9         // actuators: 6 motors + 3 finger position servos (xml:341-349)
+#define JNSENS 20     // touch sensors (xml:352-374)
+#define JMAXGEOM 64   // collidable geoms
+#define JMAXPAIR 768  // geom pairs passing the static collision filter
+#define JMAXLEAF 8    // leaves of the kinematic tree (3 fingers + 2 free bodies)
+#define JMAXDEPTH 8   // longest root->leaf path (link1..link6, finger)
+#define JNMOCAP 16
+
+enum { JG_PLANE = 0, JG_SPHERE = 2, JG_CYLINDER = 5, JG_BOX = 6, JG_MESH = 7 };
+enum { JJ_FREE = 0, JJ_HINGE = 3 };
+
+struct JacoPairParam {
+  float mu[5];       // tangent1, tangent2, torsional, rolling1, rolling2 (element-wise max of the two geoms)
+  float solref[2];   // mean of the two geoms, timeconst clamped to 2*dt (refsafe)
+  float solimp[5];   // mean of the two geoms
+  float margin;
+  int condim;        // max of the two geoms
+  int g1, g2;        // fused geom ids, type(g1) <= type(g2)
+  int pad;
+};
+
+struct JacoModelDev {
+  int nbody, nv, nq, nu, ngeom, npair, nsensor, nleaf, nhullvert, nmocap;
+  float timestep, gravity[3], tolerance, meaninertia, mpr_tolerance;
+  int iterations, ls_iterations, mpr_iterations;
+  float ls_tolerance;
+
+  // bodies (parents precede children)
+  int b_parent[JNB], b_jtype[JNB], b_qadr[JNB], b_dadr[JNB], b_limited[JNB];
+  float b_pos[JNB][3], b_mat[JNB][9], b_axis[JNB][3], b_qpos0[JNB];
+  float b_mass[JNB], b_com[JNB][3], b_inertia[JNB][6];  // xx yy zz xy xz yz about the CoM, body frame
+  float b_range[JNB][2], b_solref[JNB][2], b_solimp[JNB][5];  // joint-limit solver parameters
+  unsigned b_chainmask[JNB];                       // bit d set: dof d moves body b
+  int leaf_body[JMAXLEAF], leaf_depth[JMAXLEAF];   // root->leaf paths walked by one lane each
+  int leaf_path[JMAXLEAF][JMAXDEPTH];
+  int b_writer[JNB];                               // leaf index whose lane publishes body b's frame
+
+  // dofs
+  int d_body[JNV], d_parent[JNV];
+  float d_damping[JNV], d_invweight[JNV];
+  int has_damping;
+
+  // actuators: force = position ? kp*(clamp(ctrl) - qpos) : ctrl, then clamped (xml:341-349)
+  int a_dof[JNU], a_qadr[JNU], a_position[JNU], a_ctrllimited[JNU], a_forcelimited[JNU];
+  float a_kp[JNU], a_ctrlrange[JNU][2], a_forcerange[JNU][2];
+
+  // collidable geoms; body -1 = static (g_pos/g_mat are then world poses)
+  int g_body[JMAXGEOM], g_type[JMAXGEOM], g_vertadr[JMAXGEOM], g_vertnum[JMAXGEOM], g_origbody[JMAXGEOM], g_mocap[JMAXGEOM];
+  float g_pos[JMAXGEOM][3], g_mat[JMAXGEOM][9], g_size[JMAXGEOM][3], g_rbound[JMAXGEOM], g_invweight[JMAXGEOM][2];
+
+  JacoPairParam pair[JMAXPAIR];
+
+  // touch sites, one per sensor, in sensordata order
+  int s_body[JNSENS], s_type[JNSENS], s_origbody[JNSENS];
+  float s_pos[JNSENS][3], s_mat[JNSENS][9], s_size[JNSENS][3];
+
+  // named frames the task layer reads: body id + local pos + local rotation
+  int ee_body, eeobj_body;
+  float ee_pos[3], ee_mat[9], eeobj_pos[3], eeobj_mat[9], base_pos[3];
+  int obj_body, dest_body;
+};

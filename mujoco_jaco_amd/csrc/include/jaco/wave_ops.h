@@ -1,0 +1,83 @@
+// Wavefront-level primitives for gfx950 (64 lanes). One env == one wavefront == one workgroup,
+// so every "sync" below is wave-scoped.  All cross-lane calls must be reached by all 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define JACO_WAVE 64
+#define JDEV __device__ __forceinline__
+
+JDEV int lane_id() { return (int)threadIdx.x; }
+JDEV int env_id() { return (int)blockIdx.x; }
+
+// LDS hand-off between lanes of the (single-wave) workgroup.
+JDEV void wave_sync() { __syncthreads(); }
+
+// Broadcast from a wave-uniform source lane (v_readlane_b32).
+JDEV float wave_bcast(float v, int src) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
+}
+JDEV int wave_bcast_i(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+// Arbitrary per-lane gather (ds_bpermute_b32).
+JDEV float wave_shfl(float v, int src) { return __shfl(v, src, 64); }
+JDEV int wave_shfl_i(int v, int src) { return __shfl(v, src, 64); }
+
+JDEV unsigned long long wave_ballot(bool p) { return __ballot(p); }
+// number of set bits of `mask` below this lane
+JDEV int wave_prefix_count(unsigned long long mask) {
+  return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+JDEV int popc64(unsigned long long m) { return __popcll(m); }
+JDEV int ffs64(unsigned long long m) { return __ffsll((long long)m) - 1; }  // index of lowest set bit, -1 if none
+
+template <int CTRL>
+JDEV float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+JDEV int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+
+// DPP butterflies inside each 16-lane row (quad swap, quad pair swap, half mirror, mirror), then 4 readlanes.
+JDEV float wave_sum(float v) {
+  v += dpp_f<0xB1>(v);
+  v += dpp_f<0x4E>(v);
+  v += dpp_f<0x141>(v);
+  v += dpp_f<0x140>(v);
+  return (wave_bcast(v, 0) + wave_bcast(v, 16)) + (wave_bcast(v, 32) + wave_bcast(v, 48));
+}
+JDEV float wave_max(float v) {
+  v = fmaxf(v, dpp_f<0xB1>(v));
+  v = fmaxf(v, dpp_f<0x4E>(v));
+  v = fmaxf(v, dpp_f<0x141>(v));
+  v = fmaxf(v, dpp_f<0x140>(v));
+  return fmaxf(fmaxf(wave_bcast(v, 0), wave_bcast(v, 16)), fmaxf(wave_bcast(v, 32), wave_bcast(v, 48)));
+}
+JDEV float wave_min(float v) { return -wave_max(-v); }
+
+// argmax with lowest-index tie-break; returns the winning index in all lanes, *best gets the value.
+JDEV int wave_argmax(float v, int idx, float* best) {
+#define JACO_ARGMAX_STEP(CTRL)                              \
+  {                                                         \
+    float v2 = dpp_f<CTRL>(v);                              \
+    int i2 = dpp_i<CTRL>(idx);                              \
+    bool take = (v2 > v) || (v2 == v && i2 < idx);          \
+    v = take ? v2 : v;                                      \
+    idx = take ? i2 : idx;                                  \
+  }
+  JACO_ARGMAX_STEP(0xB1)
+  JACO_ARGMAX_STEP(0x4E)
+  JACO_ARGMAX_STEP(0x141)
+  JACO_ARGMAX_STEP(0x140)
+#undef JACO_ARGMAX_STEP
+  float bv = wave_bcast(v, 0);
+  int bi = wave_bcast_i(idx, 0);
+#pragma unroll
+  for (int r = 16; r < 64; r += 16) {
+    float v2 = wave_bcast(v, r);
+    int i2 = wave_bcast_i(idx, r);
+    bool take = (v2 > bv) || (v2 == bv && i2 < bi);
+    bv = take ? v2 : bv;
+    bi = take ? i2 : bi;
+  }
+  *best = bv;
+  return bi;
+}

@@ -1,0 +1,274 @@
+// libjaco_env.so: C ABI (include/jaco_env.h) over the gfx950 physics kernel.
+// Host side owns model constants, per-env state rows and launch plumbing; all arithmetic is in
+// physics_kernel.h.  There is no CPU fallback: without a HIP device jaco_create fails.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/jaco_env.h"
+#include "model_blob.h"
+#include "physics_kernel.h"
+
+static_assert(JFLAG_CON_OVERFLOW == JACO_FLAG_CON_OVERFLOW && JFLAG_EFC_OVERFLOW == JACO_FLAG_EFC_OVERFLOW &&
+                  JFLAG_CAND_OVERFLOW == JACO_FLAG_CAND_OVERFLOW && JFLAG_NAN == JACO_FLAG_NAN &&
+                  JFLAG_SOLVER_MAXITER == JACO_FLAG_SOLVER_MAXITER,
+              "flag bits of the kernel and the public header must agree");
+
+struct JacoHandle {
+  JacoModelDev model_host;
+  JacoModelDev* model_dev = nullptr;
+  float* hull_dev = nullptr;
+  float *qpos = nullptr, *qvel = nullptr, *qacc_ws = nullptr, *sensordata = nullptr, *dbg = nullptr;
+  unsigned* flags = nullptr;
+  int* stats = nullptr;
+  std::vector<float> qpos0;
+  int num_envs = 0, device = 0, frame_skip = 50, task = 0, disable_contact = 0;
+  uint64_t seed = 0;
+  std::string err;
+  bool timing = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+  size_t events_used = 0;
+};
+
+static std::string g_create_error;
+
+#define HIPCHK(h, call)                                                                              \
+  do {                                                                                               \
+    hipError_t e_ = (call);                                                                          \
+    if (e_ != hipSuccess) {                                                                          \
+      (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                                  \
+      return JACO_EHIP;                                                                              \
+    }                                                                                                \
+  } while (0)
+
+extern "C" const char* jaco_last_error(const JacoHandle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+static int upload_model(JacoHandle* h) {
+  HIPCHK(h, hipMemcpy(h->model_dev, &h->model_host, sizeof(JacoModelDev), hipMemcpyHostToDevice));
+  return JACO_OK;
+}
+
+extern "C" int jaco_create(const JacoConfig* cfg, JacoHandle** out) {
+  if (!cfg || !out || !cfg->model_blob || cfg->num_envs <= 0) { g_create_error = "jaco_create: bad arguments"; return JACO_EINVAL; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) {
+    g_create_error = "jaco_create: no usable HIP device (this library has no CPU path)";
+    return JACO_ENODEV;
+  }
+  JacoHandle* h = new JacoHandle();
+  std::vector<float> hull;
+  std::string err;
+  if (jaco_model_from_blob(cfg->model_blob, cfg->model_blob_size, &h->model_host, &hull, &err)) {
+    g_create_error = "jaco_create: " + err;
+    delete h;
+    return JACO_EINVAL;
+  }
+  h->num_envs = cfg->num_envs; h->device = cfg->device; h->frame_skip = cfg->frame_skip > 0 ? cfg->frame_skip : 50;
+  h->task = cfg->task; h->seed = cfg->seed;
+#define CREATECHK(call)                                                                    \
+  do {                                                                                     \
+    hipError_t e_ = (call);                                                                \
+    if (e_ != hipSuccess) {                                                                \
+      g_create_error = std::string("jaco_create: " #call ": ") + hipGetErrorString(e_);    \
+      jaco_destroy(h);                                                                     \
+      return JACO_EHIP;                                                                    \
+    }                                                                                      \
+  } while (0)
+  CREATECHK(hipSetDevice(cfg->device));
+  const JacoModelDev& m = h->model_host;
+  size_t B = (size_t)cfg->num_envs;
+  CREATECHK(hipMalloc(&h->model_dev, sizeof(JacoModelDev)));
+  CREATECHK(hipMalloc(&h->hull_dev, hull.size() * sizeof(float) + 16));
+  CREATECHK(hipMalloc(&h->qpos, B * m.nq * sizeof(float)));
+  CREATECHK(hipMalloc(&h->qvel, B * m.nv * sizeof(float)));
+  CREATECHK(hipMalloc(&h->qacc_ws, B * m.nv * sizeof(float)));
+  CREATECHK(hipMalloc(&h->sensordata, B * (m.nsensor > 0 ? m.nsensor : 1) * sizeof(float)));
+  CREATECHK(hipMalloc(&h->flags, B * sizeof(unsigned)));
+  CREATECHK(hipMalloc(&h->stats, B * 4 * sizeof(int)));
+  CREATECHK(hipMalloc(&h->dbg, JDBG_SIZE * sizeof(float)));
+  CREATECHK(hipMemcpy(h->model_dev, &h->model_host, sizeof(JacoModelDev), hipMemcpyHostToDevice));
+  CREATECHK(hipMemcpy(h->hull_dev, hull.data(), hull.size() * sizeof(float), hipMemcpyHostToDevice));
+  CREATECHK(hipMemset(h->flags, 0, B * sizeof(unsigned)));
+  CREATECHK(hipMemset(h->stats, 0, B * 4 * sizeof(int)));
+  CREATECHK(hipMemset(h->sensordata, 0, B * (m.nsensor > 0 ? m.nsensor : 1) * sizeof(float)));
+  // qpos0 from the raw view of the blob (same joint order as the fused view)
+  {
+    const char* p = (const char*)cfg->model_blob;
+    int n = *(const int32_t*)(p + 8);
+    size_t off = 16;
+    for (int i = 0; i < n; i++) {
+      std::string name(p + off, strnlen(p + off, 32));
+      int code = *(const int32_t*)(p + off + 32), count = *(const int32_t*)(p + off + 36);
+      off += 40;
+      size_t nb = (size_t)count * (code == 0 ? 8 : 4);
+      if (name == "qpos0" && code == 0) {
+        h->qpos0.resize(count);
+        for (int k = 0; k < count; k++) h->qpos0[k] = (float)((const double*)(p + off))[k];
+      }
+      off += nb + ((8 - nb % 8) % 8);
+    }
+    if ((int)h->qpos0.size() != m.nq) { g_create_error = "jaco_create: qpos0 missing"; jaco_destroy(h); return JACO_EINVAL; }
+  }
+  *out = h;
+  int rc = jaco_reset_state(h, nullptr);
+  if (rc) { g_create_error = h->err; jaco_destroy(h); *out = nullptr; return rc; }
+  hipDeviceSynchronize();
+  return JACO_OK;
+}
+
+extern "C" int jaco_destroy(JacoHandle* h) {
+  if (!h) return JACO_EINVAL;
+  hipSetDevice(h->device);
+  for (auto& e : h->events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+  void* ptrs[] = {h->model_dev, h->hull_dev, h->qpos, h->qvel, h->qacc_ws, h->sensordata, h->flags, h->stats, h->dbg};
+  for (void* p : ptrs) if (p) hipFree(p);
+  delete h;
+  return JACO_OK;
+}
+
+extern "C" int jaco_dims(const JacoHandle* h, int* nq, int* nv, int* nu, int* nsensor, int* nobs, int* nact) {
+  if (!h) return JACO_EINVAL;
+  if (nq) *nq = h->model_host.nq;
+  if (nv) *nv = h->model_host.nv;
+  if (nu) *nu = h->model_host.nu;
+  if (nsensor) *nsensor = h->model_host.nsensor;
+  if (nobs) *nobs = 26;
+  if (nact) *nact = h->task == JACO_TASK_REACHING ? 6 : 7;
+  return JACO_OK;
+}
+extern "C" int jaco_num_envs(const JacoHandle* h) { return h ? h->num_envs : JACO_EINVAL; }
+
+extern "C" int jaco_set_state(JacoHandle* h, const float* qpos, const float* qvel, const float* qacc_ws, void* stream) {
+  if (!h) return JACO_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  size_t B = h->num_envs;
+  if (qpos) HIPCHK(h, hipMemcpyAsync(h->qpos, qpos, B * h->model_host.nq * sizeof(float), hipMemcpyDeviceToDevice, st));
+  if (qvel) HIPCHK(h, hipMemcpyAsync(h->qvel, qvel, B * h->model_host.nv * sizeof(float), hipMemcpyDeviceToDevice, st));
+  if (qacc_ws) HIPCHK(h, hipMemcpyAsync(h->qacc_ws, qacc_ws, B * h->model_host.nv * sizeof(float), hipMemcpyDeviceToDevice, st));
+  return JACO_OK;
+}
+extern "C" int jaco_get_state(JacoHandle* h, float* qpos, float* qvel, float* qacc_ws, void* stream) {
+  if (!h) return JACO_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  size_t B = h->num_envs;
+  if (qpos) HIPCHK(h, hipMemcpyAsync(qpos, h->qpos, B * h->model_host.nq * sizeof(float), hipMemcpyDeviceToDevice, st));
+  if (qvel) HIPCHK(h, hipMemcpyAsync(qvel, h->qvel, B * h->model_host.nv * sizeof(float), hipMemcpyDeviceToDevice, st));
+  if (qacc_ws) HIPCHK(h, hipMemcpyAsync(qacc_ws, h->qacc_ws, B * h->model_host.nv * sizeof(float), hipMemcpyDeviceToDevice, st));
+  return JACO_OK;
+}
+
+__global__ void jaco_fill_rows_kernel(float* dst, const float* row, int n, int nenv) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (size_t)n * nenv) dst[i] = row[i % n];
+}
+extern "C" int jaco_reset_state(JacoHandle* h, void* stream) {
+  if (!h) return JACO_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const JacoModelDev& m = h->model_host;
+  size_t B = h->num_envs;
+  // stage qpos0 in the debug buffer (device), then replicate it over all rows
+  HIPCHK(h, hipMemcpyAsync(h->dbg, h->qpos0.data(), m.nq * sizeof(float), hipMemcpyHostToDevice, st));
+  size_t total = B * m.nq;
+  hipLaunchKernelGGL(jaco_fill_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, h->qpos, h->dbg, m.nq, (int)B);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipMemsetAsync(h->qvel, 0, B * m.nv * sizeof(float), st));
+  HIPCHK(h, hipMemsetAsync(h->qacc_ws, 0, B * m.nv * sizeof(float), st));
+  return JACO_OK;
+}
+
+static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t st, float* dbg, int dbg_env) {
+  if (!ctrl || nsub <= 0) { h->err = "jaco_physics_step: bad arguments"; return JACO_EINVAL; }
+  JacoStepArgs A{};
+  A.model = h->model_dev; A.hull = h->hull_dev; A.qpos = h->qpos; A.qvel = h->qvel; A.qacc_ws = h->qacc_ws; A.ctrl = ctrl;
+  A.sensordata = h->sensordata; A.flags = h->flags; A.stats = h->stats; A.nenv = h->num_envs; A.nsub = nsub;
+  A.disable_contact = h->disable_contact; A.dbg = dbg; A.dbg_env = dbg_env;
+  std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
+  if (h->timing) {
+    if (h->events_used == h->events.size()) {
+      hipEvent_t a, b;
+      HIPCHK(h, hipEventCreate(&a));
+      HIPCHK(h, hipEventCreate(&b));
+      h->events.emplace_back(a, b);
+    }
+    ev = &h->events[h->events_used++];
+    HIPCHK(h, hipEventRecord(ev->first, st));
+  }
+  hipLaunchKernelGGL(jaco_physics_kernel, dim3((unsigned)h->num_envs), dim3(64), 0, st, A);
+  HIPCHK(h, hipGetLastError());
+  if (ev) HIPCHK(h, hipEventRecord(ev->second, st));
+  return JACO_OK;
+}
+
+extern "C" int jaco_physics_step(JacoHandle* h, const float* ctrl_dev, int nsub, void* stream) {
+  if (!h) return JACO_EINVAL;
+  return launch_step(h, ctrl_dev, nsub, (hipStream_t)stream, nullptr, -1);
+}
+extern "C" int jaco_debug_dump_floats(void) { return JDBG_SIZE; }
+extern "C" int jaco_physics_step_debug(JacoHandle* h, const float* ctrl_dev, int nsub, int env, float* dump_host, int dump_floats) {
+  if (!h || !dump_host || dump_floats < JDBG_SIZE || env < 0 || env >= h->num_envs) return JACO_EINVAL;
+  HIPCHK(h, hipMemset(h->dbg, 0, JDBG_SIZE * sizeof(float)));
+  int rc = launch_step(h, ctrl_dev, nsub, nullptr, h->dbg, env);
+  if (rc) return rc;
+  HIPCHK(h, hipDeviceSynchronize());
+  HIPCHK(h, hipMemcpy(dump_host, h->dbg, JDBG_SIZE * sizeof(float), hipMemcpyDeviceToHost));
+  return JACO_OK;
+}
+
+extern "C" int jaco_get_sensordata(JacoHandle* h, float* out, void* stream) {
+  if (!h || !out) return JACO_EINVAL;
+  HIPCHK(h, hipMemcpyAsync(out, h->sensordata, (size_t)h->num_envs * h->model_host.nsensor * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return JACO_OK;
+}
+extern "C" int jaco_get_flags(JacoHandle* h, uint32_t* out, void* stream) {
+  if (!h || !out) return JACO_EINVAL;
+  HIPCHK(h, hipMemcpyAsync(out, h->flags, (size_t)h->num_envs * sizeof(unsigned), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return JACO_OK;
+}
+extern "C" int jaco_clear_flags(JacoHandle* h, void* stream) {
+  if (!h) return JACO_EINVAL;
+  HIPCHK(h, hipMemsetAsync(h->flags, 0, (size_t)h->num_envs * sizeof(unsigned), (hipStream_t)stream));
+  return JACO_OK;
+}
+extern "C" int jaco_get_stats(JacoHandle* h, int32_t* out, void* stream) {
+  if (!h || !out) return JACO_EINVAL;
+  HIPCHK(h, hipMemcpyAsync(out, h->stats, (size_t)h->num_envs * 4 * sizeof(int), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return JACO_OK;
+}
+
+extern "C" int jaco_set_option(JacoHandle* h, const char* name, double v) {
+  if (!h || !name) return JACO_EINVAL;
+  JacoModelDev& m = h->model_host;
+  if (!strcmp(name, "disable_contact")) { h->disable_contact = v != 0; return JACO_OK; }
+  else if (!strcmp(name, "iterations")) m.iterations = (int)v;
+  else if (!strcmp(name, "tolerance")) m.tolerance = (float)v;
+  else if (!strcmp(name, "ls_iterations")) m.ls_iterations = (int)v;
+  else if (!strcmp(name, "mpr_iterations")) m.mpr_iterations = (int)v;
+  else if (!strcmp(name, "mpr_tolerance")) m.mpr_tolerance = (float)v;
+  else { h->err = std::string("jaco_set_option: unknown option ") + name; return JACO_EINVAL; }
+  HIPCHK(h, hipDeviceSynchronize());
+  return upload_model(h);
+}
+
+extern "C" int jaco_enable_timing(JacoHandle* h, int enable) {
+  if (!h) return JACO_EINVAL;
+  h->timing = enable != 0;
+  h->events_used = 0;
+  return JACO_OK;
+}
+extern "C" int jaco_kernel_time_ms(JacoHandle* h, double* avg_ms, int* launches) {
+  if (!h || !avg_ms) return JACO_EINVAL;
+  HIPCHK(h, hipDeviceSynchronize());
+  double tot = 0;
+  for (size_t i = 0; i < h->events_used; i++) {
+    float ms = 0;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->events[i].first, h->events[i].second));
+    tot += ms;
+  }
+  *avg_ms = h->events_used ? tot / h->events_used : 0.0;
+  if (launches) *launches = (int)h->events_used;
+  h->events_used = 0;
+  return JACO_OK;
+}

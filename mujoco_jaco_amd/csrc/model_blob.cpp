@@ -1,0 +1,223 @@
+// Host-side: JACOMDL1 blob (fused view, f_* arrays) -> JacoModelDev + hull vertex table.
+// No HIP dependency so the same loader serves the product library and the CPU-side kernel checks.
+#include "model_blob.h"
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <string>
+
+namespace {
+struct Arr { int code; int count; const char* data; };
+
+struct Blob {
+  std::map<std::string, Arr> a;
+  std::string err;
+  bool parse(const void* buf, size_t size) {
+    const char* p = (const char*)buf;
+    if (size < 16 || memcmp(p, "JACOMDL1", 8)) { err = "bad magic"; return false; }
+    int n = *(const int32_t*)(p + 8);
+    size_t off = 16;
+    for (int i = 0; i < n; i++) {
+      if (off + 40 > size) { err = "truncated header"; return false; }
+      std::string name(p + off, strnlen(p + off, 32));
+      int code = *(const int32_t*)(p + off + 32), count = *(const int32_t*)(p + off + 36);
+      off += 40;
+      size_t nb = (size_t)count * (code == 0 ? 8 : 4);
+      if (off + nb > size) { err = "truncated payload: " + name; return false; }
+      a[name] = Arr{code, count, p + off};
+      off += nb + ((8 - nb % 8) % 8);
+    }
+    return true;
+  }
+  const double* f64(const char* n, int count = -1) {
+    auto it = a.find(n);
+    if (it == a.end() || it->second.code != 0 || (count >= 0 && it->second.count != count)) {
+      if (err.empty()) err = std::string("missing/mis-sized f64 array ") + n;
+      return nullptr;
+    }
+    return (const double*)it->second.data;
+  }
+  const int32_t* i32(const char* n, int count = -1) {
+    auto it = a.find(n);
+    if (it == a.end() || it->second.code != 1 || (count >= 0 && it->second.count != count)) {
+      if (err.empty()) err = std::string("missing/mis-sized i32 array ") + n;
+      return nullptr;
+    }
+    return (const int32_t*)it->second.data;
+  }
+  int count(const char* n) { auto it = a.find(n); return it == a.end() ? -1 : it->second.count; }
+  bool has(const char* n) { return a.count(n) != 0; }
+};
+
+void quat2mat(const double* q, float* M) {
+  double w = q[0], x = q[1], y = q[2], z = q[3];
+  M[0] = (float)(w * w + x * x - y * y - z * z); M[1] = (float)(2 * (x * y - w * z)); M[2] = (float)(2 * (x * z + w * y));
+  M[3] = (float)(2 * (x * y + w * z)); M[4] = (float)(w * w - x * x + y * y - z * z); M[5] = (float)(2 * (y * z - w * x));
+  M[6] = (float)(2 * (x * z - w * y)); M[7] = (float)(2 * (y * z + w * x)); M[8] = (float)(w * w - x * x - y * y + z * z);
+}
+void cp3(float* d, const double* s) { d[0] = (float)s[0]; d[1] = (float)s[1]; d[2] = (float)s[2]; }
+}  // namespace
+
+int jaco_model_from_blob(const void* buf, size_t size, JacoModelDev* m, std::vector<float>* hull, std::string* error) {
+  Blob B;
+  memset(m, 0, sizeof(*m));
+#define FAIL(msg) do { *error = (msg); return -1; } while (0)
+  if (!B.parse(buf, size)) FAIL(B.err);
+  const int32_t *pnb = B.i32("f_nbody", 1), *pnv = B.i32("nv", 1), *pnq = B.i32("nq", 1), *pnu = B.i32("nu", 1);
+  const int32_t *png = B.i32("f_ngeom", 1), *pnp = B.i32("f_npair", 1), *pns = B.i32("f_nsensor", 1), *pnm = B.i32("nmocap", 1);
+  if (!pnb || !pnv || !pnq || !pnu || !png || !pnp || !pns || !pnm) FAIL(B.err);
+  int nb = *pnb, nv = *pnv, nq = *pnq, nu = *pnu, ng = *png, np = *pnp, ns = *pns;
+  if (nb > JNB || nv > JNV || nq > JNQ || nu > JNU || ng > JMAXGEOM || np > JMAXPAIR || ns > JNSENS || *pnm > JNMOCAP)
+    FAIL("model exceeds compiled capacities (JNB/JNV/JMAXGEOM/JMAXPAIR/...)");
+  m->nbody = nb; m->nv = nv; m->nq = nq; m->nu = nu; m->ngeom = ng; m->npair = np; m->nsensor = ns; m->nmocap = *pnm;
+  const double *ts = B.f64("opt_timestep", 1), *gr = B.f64("opt_gravity", 3), *tol = B.f64("opt_tolerance", 1);
+  const double *mi = B.f64("meaninertia", 1), *mt = B.f64("opt_mpr_tolerance", 1);
+  const int32_t *it = B.i32("opt_iterations", 1), *mpi = B.i32("opt_mpr_iterations", 1);
+  if (!ts || !gr || !tol || !mi || !mt || !it || !mpi) FAIL(B.err);
+  m->timestep = (float)*ts; cp3(m->gravity, gr); m->tolerance = (float)*tol; m->meaninertia = (float)*mi;
+  m->mpr_tolerance = (float)*mt; m->iterations = *it; m->mpr_iterations = *mpi; m->ls_iterations = 50; m->ls_tolerance = 0.01f;
+
+  // ---- bodies
+  const int32_t *par = B.i32("f_parent", nb), *jt = B.i32("f_jtype", nb), *qa = B.i32("f_qposadr", nb), *da = B.i32("f_dofadr", nb);
+  const int32_t* lim = B.i32("f_limited", nb);
+  const double *pos = B.f64("f_pos", 3 * nb), *quat = B.f64("f_quat", 4 * nb), *axis = B.f64("f_axis", 3 * nb), *jpos = B.f64("f_jpos", 3 * nb);
+  const double *q0 = B.f64("f_qpos0", nb), *mass = B.f64("f_mass", nb), *com = B.f64("f_com", 3 * nb), *inr = B.f64("f_inertia", 6 * nb);
+  const double *rng = B.f64("f_range", 2 * nb), *jsr = B.f64("jnt_solref", 2 * nb), *jsi = B.f64("jnt_solimp", 5 * nb);
+  if (!jsr || !jsi) FAIL(B.err);
+  if (!par || !jt || !qa || !da || !lim || !pos || !quat || !axis || !jpos || !q0 || !mass || !com || !inr || !rng) FAIL(B.err);
+  for (int b = 0; b < nb; b++) {
+    if (par[b] >= b) FAIL("body parents must precede children");
+    if (jpos[3 * b] != 0 || jpos[3 * b + 1] != 0 || jpos[3 * b + 2] != 0) FAIL("joint anchors off the body origin are not supported");
+    if (jt[b] != JJ_FREE && jt[b] != JJ_HINGE) FAIL("unsupported joint type");
+    if (jt[b] == JJ_FREE && par[b] != -1) FAIL("free joint must hang off the world");
+    m->b_parent[b] = par[b]; m->b_jtype[b] = jt[b]; m->b_qadr[b] = qa[b]; m->b_dadr[b] = da[b]; m->b_limited[b] = lim[b];
+    cp3(m->b_pos[b], pos + 3 * b); quat2mat(quat + 4 * b, m->b_mat[b]); cp3(m->b_axis[b], axis + 3 * b);
+    m->b_qpos0[b] = (float)q0[b]; m->b_mass[b] = (float)mass[b]; cp3(m->b_com[b], com + 3 * b);
+    for (int k = 0; k < 6; k++) m->b_inertia[b][k] = (float)inr[6 * b + k];
+    m->b_range[b][0] = (float)rng[2 * b]; m->b_range[b][1] = (float)rng[2 * b + 1];
+    m->b_solref[b][0] = (float)fmax(jsr[2 * b], 2 * *ts); m->b_solref[b][1] = (float)jsr[2 * b + 1];  // refsafe
+    for (int k = 0; k < 5; k++) m->b_solimp[b][k] = (float)jsi[5 * b + k];
+  }
+  // ---- dofs
+  const int32_t* dpar = B.i32("dof_parentid", nv);
+  const double *ddamp = B.f64("dof_damping", nv), *diw = B.f64("dof_invweight0", nv);
+  if (!dpar || !ddamp || !diw) FAIL(B.err);
+  for (int b = 0; b < nb; b++) {
+    int n = jt[b] == JJ_FREE ? 6 : 1;
+    for (int k = 0; k < n; k++) m->d_body[da[b] + k] = b;
+  }
+  for (int d = 0; d < nv; d++) {
+    m->d_parent[d] = dpar[d]; m->d_damping[d] = (float)ddamp[d]; m->d_invweight[d] = (float)diw[d];
+    if (ddamp[d] > 0) m->has_damping = 1;
+  }
+  for (int b = 0; b < nb; b++) {
+    unsigned mask = par[b] >= 0 ? m->b_chainmask[par[b]] : 0u;
+    int n = jt[b] == JJ_FREE ? 6 : 1;
+    for (int k = 0; k < n; k++) mask |= 1u << (da[b] + k);
+    m->b_chainmask[b] = mask;
+  }
+  // ---- leaves and root->leaf paths
+  int nleaf = 0;
+  for (int b = 0; b < nb; b++) {
+    bool leaf = true;
+    for (int c = 0; c < nb; c++) if (par[c] == b) leaf = false;
+    if (!leaf) continue;
+    if (nleaf >= JMAXLEAF) FAIL("too many leaves");
+    int path[JMAXDEPTH], depth = 0;
+    for (int x = b; x >= 0; x = par[x]) { if (depth >= JMAXDEPTH) FAIL("tree too deep"); path[depth++] = x; }
+    m->leaf_body[nleaf] = b; m->leaf_depth[nleaf] = depth;
+    for (int k = 0; k < depth; k++) m->leaf_path[nleaf][k] = path[depth - 1 - k];
+    nleaf++;
+  }
+  m->nleaf = nleaf;
+  for (int b = 0; b < nb; b++) m->b_writer[b] = -1;
+  for (int l = 0; l < nleaf; l++)
+    for (int k = 0; k < m->leaf_depth[l]; k++) if (m->b_writer[m->leaf_path[l][k]] < 0) m->b_writer[m->leaf_path[l][k]] = l;
+  // ---- actuators
+  const int32_t *ajnt = B.i32("actuator_jntid", nu), *apos = B.i32("actuator_position", nu), *acl = B.i32("actuator_ctrllimited", nu);
+  const int32_t *afl = B.i32("actuator_forcelimited", nu), *jq = B.i32("jnt_qposadr"), *jd = B.i32("jnt_dofadr");
+  const double *akp = B.f64("actuator_kp", nu), *acr = B.f64("actuator_ctrlrange", 2 * nu), *afr = B.f64("actuator_forcerange", 2 * nu);
+  if (!ajnt || !apos || !acl || !afl || !jq || !jd || !akp || !acr || !afr) FAIL(B.err);
+  unsigned seen = 0;
+  for (int a = 0; a < nu; a++) {
+    m->a_dof[a] = jd[ajnt[a]]; m->a_qadr[a] = jq[ajnt[a]]; m->a_position[a] = apos[a];
+    if (seen & (1u << m->a_dof[a])) FAIL("two actuators on one dof are not supported");
+    seen |= 1u << m->a_dof[a];
+    m->a_ctrllimited[a] = acl[a]; m->a_forcelimited[a] = afl[a]; m->a_kp[a] = (float)akp[a];
+    m->a_ctrlrange[a][0] = (float)acr[2 * a]; m->a_ctrlrange[a][1] = (float)acr[2 * a + 1];
+    m->a_forcerange[a][0] = (float)afr[2 * a]; m->a_forcerange[a][1] = (float)afr[2 * a + 1];
+  }
+  // ---- geoms
+  const int32_t *gb = B.i32("f_geom_body", ng), *gty = B.i32("f_geom_type", ng), *gva = B.i32("f_geom_vertadr", ng), *gvn = B.i32("f_geom_vertnum", ng);
+  const int32_t *gob = B.i32("f_geom_origbody", ng), *gmo = B.i32("f_geom_mocap", ng);
+  const double *gp = B.f64("f_geom_pos", 3 * ng), *gq = B.f64("f_geom_quat", 4 * ng), *gs = B.f64("f_geom_size", 3 * ng);
+  const double *grb = B.f64("f_geom_rbound", ng), *giw = B.f64("f_geom_invweight", 2 * ng);
+  const double *mp0 = B.f64("mocap_pos0"), *mq0 = B.f64("mocap_quat0");
+  if (!gb || !gty || !gva || !gvn || !gob || !gmo || !gp || !gq || !gs || !grb || !giw || !mp0 || !mq0) FAIL(B.err);
+  for (int g = 0; g < ng; g++) {
+    m->g_body[g] = gb[g]; m->g_type[g] = gty[g]; m->g_vertadr[g] = gva[g]; m->g_vertnum[g] = gvn[g];
+    m->g_origbody[g] = gob[g]; m->g_mocap[g] = gmo[g];
+    cp3(m->g_pos[g], gp + 3 * g); quat2mat(gq + 4 * g, m->g_mat[g]); cp3(m->g_size[g], gs + 3 * g);
+    m->g_rbound[g] = (float)grb[g]; m->g_invweight[g][0] = (float)giw[2 * g]; m->g_invweight[g][1] = (float)giw[2 * g + 1];
+    if (gmo[g] >= 0) {  // marker geoms ride on mocap bodies: compose with the XML mocap pose (static until the task layer moves them)
+      float R[9], lp[3] = {m->g_pos[g][0], m->g_pos[g][1], m->g_pos[g][2]}, lm[9];
+      memcpy(lm, m->g_mat[g], sizeof lm);
+      quat2mat(mq0 + 4 * gmo[g], R);
+      for (int i = 0; i < 3; i++) {
+        m->g_pos[g][i] = (float)mp0[3 * gmo[g] + i] + R[3 * i] * lp[0] + R[3 * i + 1] * lp[1] + R[3 * i + 2] * lp[2];
+        for (int j = 0; j < 3; j++) m->g_mat[g][3 * i + j] = R[3 * i] * lm[j] + R[3 * i + 1] * lm[3 + j] + R[3 * i + 2] * lm[6 + j];
+      }
+    }
+  }
+  // ---- pairs
+  const int32_t *pg = B.i32("f_pair_geom", 2 * np), *pd = B.i32("f_pair_condim", np);
+  const double *pmu = B.f64("f_pair_mu", 5 * np), *pref = B.f64("f_pair_solref", 2 * np), *pimp = B.f64("f_pair_solimp", 5 * np), *pmar = B.f64("f_pair_margin", np);
+  if (!pg || !pd || !pmu || !pref || !pimp || !pmar) FAIL(B.err);
+  for (int k = 0; k < np; k++) {
+    JacoPairParam& P = m->pair[k];
+    int g1 = pg[2 * k], g2 = pg[2 * k + 1];
+    if (gty[g1] > gty[g2]) { int t = g1; g1 = g2; g2 = t; }
+    P.g1 = g1; P.g2 = g2; P.condim = pd[k]; P.margin = (float)pmar[k];
+    for (int i = 0; i < 5; i++) { P.mu[i] = (float)pmu[5 * k + i]; P.solimp[i] = (float)pimp[5 * k + i]; }
+    P.solref[0] = (float)pref[2 * k]; P.solref[1] = (float)pref[2 * k + 1];
+  }
+  // ---- touch sites
+  const int32_t *sb = B.i32("f_site_body", ns), *sty = B.i32("f_site_type", ns), *sob = B.i32("f_site_origbody", ns);
+  const double *sp = B.f64("f_site_pos", 3 * ns), *sq = B.f64("f_site_quat", 4 * ns), *ssz = B.f64("f_site_size", 3 * ns);
+  if (!sb || !sty || !sob || !sp || !sq || !ssz) FAIL(B.err);
+  for (int s = 0; s < ns; s++) {
+    m->s_body[s] = sb[s]; m->s_type[s] = sty[s]; m->s_origbody[s] = sob[s];
+    cp3(m->s_pos[s], sp + 3 * s); quat2mat(sq + 4 * s, m->s_mat[s]); cp3(m->s_size[s], ssz + 3 * s);
+  }
+  // ---- named frames
+  auto frame = [&](const char* nm, int* body, float* p, float* R) {
+    const double* f = B.has(nm) ? B.f64(nm, 8) : nullptr;
+    if (!f) { *body = -1; return; }
+    *body = (int)f[0];
+    if (p) cp3(p, f + 1);
+    if (R) quat2mat(f + 4, R);
+  };
+  int dummy;
+  frame("f_frame_EE", &m->ee_body, m->ee_pos, m->ee_mat);
+  frame("f_frame_EE_obj", &m->eeobj_body, m->eeobj_pos, m->eeobj_mat);
+  frame("f_frame_link1", &dummy, m->base_pos, nullptr);
+  if (dummy >= 0) { /* link1 origin sits on joint0's axis: world position is constant = its qpos0 pose */
+    const double* f = B.f64("f_frame_link1", 8);
+    (void)f;
+    m->base_pos[0] = m->b_pos[0][0]; m->base_pos[1] = m->b_pos[0][1]; m->base_pos[2] = m->b_pos[0][2];
+  }
+  frame("f_frame_object_body", &m->obj_body, nullptr, nullptr);
+  frame("f_frame_object_dest", &m->dest_body, nullptr, nullptr);
+  // ---- hull vertices (float4, w = 0)
+  const double* mv = B.f64("mesh_vert");
+  if (!mv) FAIL(B.err);
+  int nvert = B.count("mesh_vert") / 3;
+  m->nhullvert = nvert;
+  hull->assign((size_t)4 * nvert, 0.f);
+  for (int i = 0; i < nvert; i++) for (int k = 0; k < 3; k++) (*hull)[4 * i + k] = (float)mv[3 * i + k];
+  if (!B.err.empty()) FAIL(B.err);
+#undef FAIL
+  return 0;
+}

@@ -1,0 +1,630 @@
+// Batched Jaco physics step for gfx950: one 64-lane wavefront (= one workgroup) per environment.
+//
+// Replaces, per environment, what the reference does in  Mujoco.send_forces -> sim.step()
+// (/root/reference/env_script/mujoco.py:258-278): MuJoCo's mj_step under its default options
+// (SURVEY.md section 8 row a6 / App. D.1).  Stage order inside one substep:
+//   K  tree walk: frames, motion subspaces, velocities, bias accelerations   (lane = root->leaf path)
+//   G  geom poses (lane = geom), body spatial inertias and RNE forces (lane = body)
+//   M  composite inertias -> mass matrix (lane = dof), bias forces, actuation, qacc_smooth (LDL^T, lane = row)
+//   C  collision: pair whitelist + bounding spheres + OBB cull (lane = pair), narrowphase (wave per pair)
+//   R  constraint rows: joint limits + pyramidal contacts (lane = dof / lane = row)
+//   S  primal Newton solve with exact line search (MuJoCo's default solver; see DESIGN.md for why not PGS)
+//   T  touch sensors (lane = sensor)
+//   E  semi-implicit Euler with implicit joint damping, quaternion integration for the free bodies
+// Per-body / per-row state lives in LDS; vectors of length nv live one element per lane and are
+// broadcast with v_readlane; small reductions use DPP butterflies (jaco/wave_ops.h).
+#pragma once
+#include <jaco/model_dev.h>
+#include <jaco/wave_ops.h>
+
+#define JMAXCON 48    // contacts kept per env (overflow sets JFLAG_CON_OVERFLOW)
+#define JMAXEFC 128   // constraint rows per env (2 per lane)
+#define JMAXCAND 64   // narrowphase candidates per env
+#define JLD (JNV)     // row stride of per-row dof vectors in LDS (21: odd, conflict-free for lane-per-row access)
+
+#define JFLAG_CON_OVERFLOW 1u
+#define JFLAG_EFC_OVERFLOW 2u
+#define JFLAG_CAND_OVERFLOW 4u
+#define JFLAG_NAN 8u
+#define JFLAG_SOLVER_MAXITER 16u
+
+#define JMINVAL 1e-15f
+
+struct JacoStepArgs {
+  const JacoModelDev* model;
+  const float* hull;   // float4 per hull vertex
+  float* qpos;         // [nenv][nq]
+  float* qvel;         // [nenv][nv]
+  float* qacc_ws;      // [nenv][nv]  warm start (= last qacc)
+  const float* ctrl;   // [nenv][nu]
+  float* sensordata;   // [nenv][nsensor]
+  unsigned* flags;     // [nenv] sticky error bits
+  int* stats;          // [nenv][4]: ncon, nefc, newton iterations, candidates (last substep) or nullptr
+  int nenv, nsub, disable_contact;
+  float* dbg;          // optional stage dump of env dbg_env (see JDBG_* offsets), else nullptr
+  int dbg_env;
+};
+
+// debug dump layout (floats)
+#define JDBG_XPOS 0                       // [JNB][3]
+#define JDBG_XMAT (JDBG_XPOS + 3 * JNB)   // [JNB][9]
+#define JDBG_M (JDBG_XMAT + 9 * JNB)      // [JNV][JNV]
+#define JDBG_BIAS (JDBG_M + JNV * JNV)    // [JNV]
+#define JDBG_SMOOTH (JDBG_BIAS + 24)      // qfrc_smooth
+#define JDBG_QACC_SMOOTH (JDBG_SMOOTH + 24)
+#define JDBG_QACC (JDBG_QACC_SMOOTH + 24)
+#define JDBG_QFRC_CON (JDBG_QACC + 24)
+#define JDBG_NCON (JDBG_QFRC_CON + 24)    // ncon, nefc, iters, ncand
+#define JDBG_CONTACT (JDBG_NCON + 4)      // [JMAXCON][8]: dist, pos3, normal3, pair
+#define JDBG_EFC (JDBG_CONTACT + 8 * JMAXCON)  // [JMAXEFC][4]: aref, R, x(final jar), force
+#define JDBG_GPOS (JDBG_EFC + 4 * JMAXEFC)     // [JMAXGEOM][3]
+#define JDBG_SIZE (JDBG_GPOS + 3 * JMAXGEOM)
+
+struct JacoLDS {
+  float qpos[24], qvel[24], qacc_ws[24], ctrl[12];
+  float xpos[JNB][3], xmat[JNB][9], xipos[JNB][3];
+  float cdof[JNV][6];
+  float cinert[JNB][10], crb[JNB][10];
+  float cvel[JNB][6], cacc[JNB][6], cfrc[JNB][6];
+  float M[JNV * JNV];
+  float bias[24], smooth[24], qacc_smooth[24], qfrc_con[24];
+  float gpos[JMAXGEOM][3], gmat[JMAXGEOM][9];
+  // contacts
+  float c_dist[JMAXCON], c_pos[JMAXCON][3], c_frame[JMAXCON][9], c_fn[JMAXCON];
+  int c_pair[JMAXCON], c_efc[JMAXCON];
+  int cand[JMAXCAND];
+  // constraint rows
+  float J[JMAXEFC * JLD];
+  float e_aref[JMAXEFC], e_D[JMAXEFC], e_f[JMAXEFC];
+  int e_con[JMAXEFC];
+  int ncon, nefc, ncand;
+  float scratch[64];
+};
+
+// ---------------------------------------------------------------- small vector helpers
+struct v3 { float x, y, z; };
+JDEV v3 mk3(float x, float y, float z) { v3 r; r.x = x; r.y = y; r.z = z; return r; }
+JDEV v3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
+JDEV void st3(float* p, v3 a) { p[0] = a.x; p[1] = a.y; p[2] = a.z; }
+JDEV v3 operator+(v3 a, v3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+JDEV v3 operator-(v3 a, v3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+JDEV v3 operator*(v3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+JDEV v3 operator*(float s, v3 a) { return mk3(a.x * s, a.y * s, a.z * s); }
+JDEV v3 operator-(v3 a) { return mk3(-a.x, -a.y, -a.z); }
+JDEV float dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+JDEV v3 cross(v3 a, v3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+JDEV float norm(v3 a) { return sqrtf(dot(a, a)); }
+JDEV v3 normalized(v3 a) {
+  float n = norm(a);
+  return n < JMINVAL ? mk3(1.f, 0.f, 0.f) : a * (1.f / n);
+}
+// row-major 3x3
+struct m3 { float m[9]; };
+JDEV m3 ldm(const float* p) { m3 r; for (int i = 0; i < 9; i++) r.m[i] = p[i]; return r; }
+JDEV void stm(float* p, const m3& a) { for (int i = 0; i < 9; i++) p[i] = a.m[i]; }
+JDEV v3 mul(const m3& a, v3 v) {
+  return mk3(a.m[0] * v.x + a.m[1] * v.y + a.m[2] * v.z, a.m[3] * v.x + a.m[4] * v.y + a.m[5] * v.z, a.m[6] * v.x + a.m[7] * v.y + a.m[8] * v.z);
+}
+JDEV v3 mulT(const m3& a, v3 v) {
+  return mk3(a.m[0] * v.x + a.m[3] * v.y + a.m[6] * v.z, a.m[1] * v.x + a.m[4] * v.y + a.m[7] * v.z, a.m[2] * v.x + a.m[5] * v.y + a.m[8] * v.z);
+}
+JDEV m3 mul(const m3& a, const m3& b) {
+  m3 r;
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) r.m[3 * i + j] = a.m[3 * i] * b.m[j] + a.m[3 * i + 1] * b.m[3 + j] + a.m[3 * i + 2] * b.m[6 + j];
+  return r;
+}
+JDEV v3 col(const m3& a, int k) { return mk3(a.m[k], a.m[3 + k], a.m[6 + k]); }
+JDEV m3 quat2mat(float w, float x, float y, float z) {
+  m3 r;
+  r.m[0] = w * w + x * x - y * y - z * z; r.m[1] = 2 * (x * y - w * z); r.m[2] = 2 * (x * z + w * y);
+  r.m[3] = 2 * (x * y + w * z); r.m[4] = w * w - x * x + y * y - z * z; r.m[5] = 2 * (y * z - w * x);
+  r.m[6] = 2 * (x * z - w * y); r.m[7] = 2 * (y * z + w * x); r.m[8] = w * w - x * x - y * y + z * z;
+  return r;
+}
+// rotation by angle about unit axis (Rodrigues)
+JDEV m3 axis_rot(v3 a, float ang) {
+  float s = sinf(ang), c = cosf(ang), t = 1.f - c;
+  m3 r;
+  r.m[0] = c + t * a.x * a.x; r.m[1] = t * a.x * a.y - s * a.z; r.m[2] = t * a.x * a.z + s * a.y;
+  r.m[3] = t * a.x * a.y + s * a.z; r.m[4] = c + t * a.y * a.y; r.m[5] = t * a.y * a.z - s * a.x;
+  r.m[6] = t * a.x * a.z - s * a.y; r.m[7] = t * a.y * a.z + s * a.x; r.m[8] = c + t * a.z * a.z;
+  return r;
+}
+// spatial vectors about the world origin: motion (w, v), force (n, f)
+struct sv { v3 a, b; };
+JDEV sv ldsv(const float* p) { sv r; r.a = ld3(p); r.b = ld3(p + 3); return r; }
+JDEV void stsv(float* p, sv s) { st3(p, s.a); st3(p + 3, s.b); }
+JDEV sv operator+(sv x, sv y) { sv r; r.a = x.a + y.a; r.b = x.b + y.b; return r; }
+JDEV sv operator*(sv x, float s) { sv r; r.a = x.a * s; r.b = x.b * s; return r; }
+JDEV float dot(sv x, sv y) { return dot(x.a, y.a) + dot(x.b, y.b); }
+JDEV sv cross_motion(sv v, sv s) { sv r; r.a = cross(v.a, s.a); r.b = cross(v.a, s.b) + cross(v.b, s.a); return r; }
+JDEV sv cross_force(sv v, sv f) { sv r; r.a = cross(v.a, f.a) + cross(v.b, f.b); r.b = cross(v.a, f.b); return r; }
+// spatial inertia [m, h = m c, I_O (xx yy zz xy xz yz)] applied to a motion vector
+JDEV sv inert_mul(const float* I, sv mv) {
+  v3 h = mk3(I[1], I[2], I[3]);
+  sv r;
+  r.b = mv.b * I[0] + cross(mv.a, h);
+  v3 t = cross(h, mv.b);
+  r.a = mk3(I[4] * mv.a.x + I[7] * mv.a.y + I[8] * mv.a.z + t.x, I[7] * mv.a.x + I[5] * mv.a.y + I[9] * mv.a.z + t.y,
+            I[8] * mv.a.x + I[9] * mv.a.y + I[6] * mv.a.z + t.z);
+  return r;
+}
+
+// ---------------------------------------------------------------- LDL^T solve, one matrix row per lane
+// h[j] = A[lane][j] (lanes >= n must hold identity rows), b = rhs[lane]; returns x[lane]. Registers only.
+JDEV float ldl_solve(float (&h)[JNV], float b, int lane) {
+  float dinv = 1.f;
+#pragma unroll
+  for (int k = 0; k < JNV; k++) {
+    float dk = wave_bcast(h[k], k);
+    float inv = 1.f / dk;
+    dinv = lane == k ? inv : dinv;
+    float lik = lane > k ? h[k] * inv : 0.f;
+#pragma unroll
+    for (int j = k + 1; j < JNV; j++) h[j] -= lik * wave_bcast(h[j], k);
+    b -= lik * wave_bcast(b, k);
+  }
+  // now: b = y (L y = rhs); h[k>lane] = d_lane * L[k][lane]
+  float z = b * dinv, acc = 0.f, x = 0.f;
+#pragma unroll
+  for (int k = JNV - 1; k >= 0; k--) {
+    x = lane == k ? z - dinv * acc : x;
+    float xk = wave_bcast(x, k);
+    acc += lane < k ? h[k] * xk : 0.f;
+  }
+  return x;
+}
+JDEV void load_rows(float (&h)[JNV], const float* M, int nv, int lane) {
+#pragma unroll
+  for (int j = 0; j < JNV; j++) h[j] = lane < nv ? M[lane * JNV + j] : (lane == j ? 1.f : 0.f);
+}
+
+// ---------------------------------------------------------------- stage K: tree walk
+JDEV void stage_walk(const JacoModelDev* m, JacoLDS& s, int lane) {
+  int nleaf = m->nleaf;
+  int leaf = lane < nleaf ? lane : nleaf - 1;
+  bool pub = lane < nleaf;
+  int depth = m->leaf_depth[leaf];
+  v3 pos = mk3(0, 0, 0);
+  m3 R;
+  for (int i = 0; i < 9; i++) R.m[i] = (i % 4 == 0) ? 1.f : 0.f;
+  sv cvel, cacc;
+  cvel.a = cvel.b = cacc.a = mk3(0, 0, 0);
+  cacc.b = mk3(-m->gravity[0], -m->gravity[1], -m->gravity[2]);
+  for (int k = 0; k < JMAXDEPTH; k++) {
+    if (k >= depth) break;
+    int b = m->leaf_path[leaf][k];
+    bool wr = pub && m->b_writer[b] == leaf;
+    int da = m->b_dadr[b], qa = m->b_qadr[b];
+    if (m->b_jtype[b] == JJ_HINGE) {
+      v3 ax = ld3(m->b_axis[b]);
+      pos = pos + mul(R, ld3(m->b_pos[b]));
+      m3 Rb = mul(R, ldm(m->b_mat[b]));
+      R = mul(Rb, axis_rot(ax, s.qpos[qa] - m->b_qpos0[b]));
+      sv S;
+      S.a = mul(Rb, ax);
+      S.b = cross(pos, S.a);
+      float qd = s.qvel[da];
+      sv Sd = cross_motion(cvel, S);
+      cacc = cacc + Sd * qd;
+      cvel = cvel + S * qd;
+      if (wr) stsv(s.cdof[da], S);
+    } else {
+      pos = ld3(&s.qpos[qa]);
+      float w = s.qpos[qa + 3], x = s.qpos[qa + 4], y = s.qpos[qa + 5], z = s.qpos[qa + 6];
+      float n = sqrtf(w * w + x * x + y * y + z * z);
+      if (n < JMINVAL) { w = 1.f; x = y = z = 0.f; } else { float in = 1.f / n; w *= in; x *= in; y *= in; z *= in; }
+      R = quat2mat(w, x, y, z);
+      // translational dofs: world axes, no cdof_dot
+      sv St[3], Sr[3];
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        St[c].a = mk3(0, 0, 0);
+        St[c].b = mk3(c == 0 ? 1.f : 0.f, c == 1 ? 1.f : 0.f, c == 2 ? 1.f : 0.f);
+        cvel = cvel + St[c] * s.qvel[da + c];
+        Sr[c].a = col(R, c);
+        Sr[c].b = cross(pos, Sr[c].a);
+      }
+      sv vbase = cvel;
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        float qd = s.qvel[da + 3 + c];
+        cacc = cacc + cross_motion(vbase, Sr[c]) * qd;
+        cvel = cvel + Sr[c] * qd;
+      }
+      if (wr) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) { stsv(s.cdof[da + c], St[c]); stsv(s.cdof[da + 3 + c], Sr[c]); }
+      }
+    }
+    if (wr) {
+      st3(s.xpos[b], pos);
+      stm(s.xmat[b], R);
+      st3(s.xipos[b], pos + mul(R, ld3(m->b_com[b])));
+      stsv(s.cvel[b], cvel);
+      stsv(s.cacc[b], cacc);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- stage G: geom poses, body inertias, RNE body forces
+JDEV void stage_geoms_inertia(const JacoModelDev* m, JacoLDS& s, int lane) {
+  if (lane < m->ngeom) {
+    int b = m->g_body[lane];
+    if (b >= 0) {
+      m3 R = ldm(s.xmat[b]);
+      st3(s.gpos[lane], ld3(s.xpos[b]) + mul(R, ld3(m->g_pos[lane])));
+      stm(s.gmat[lane], mul(R, ldm(m->g_mat[lane])));
+    } else {
+      st3(s.gpos[lane], ld3(m->g_pos[lane]));
+      stm(s.gmat[lane], ldm(m->g_mat[lane]));
+    }
+  }
+  if (lane < m->nbody) {
+    int b = lane;
+    m3 R = ldm(s.xmat[b]);
+    const float* I = m->b_inertia[b];
+    m3 Il;
+    Il.m[0] = I[0]; Il.m[4] = I[1]; Il.m[8] = I[2];
+    Il.m[1] = Il.m[3] = I[3]; Il.m[2] = Il.m[6] = I[4]; Il.m[5] = Il.m[7] = I[5];
+    m3 T = mul(R, Il), Iw;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) Iw.m[3 * i + j] = T.m[3 * i] * R.m[3 * j] + T.m[3 * i + 1] * R.m[3 * j + 1] + T.m[3 * i + 2] * R.m[3 * j + 2];
+    v3 c = ld3(s.xipos[b]);
+    float mass = m->b_mass[b], cc = dot(c, c);
+    float* o = s.cinert[b];
+    o[0] = mass; o[1] = mass * c.x; o[2] = mass * c.y; o[3] = mass * c.z;
+    o[4] = Iw.m[0] + mass * (cc - c.x * c.x); o[5] = Iw.m[4] + mass * (cc - c.y * c.y); o[6] = Iw.m[8] + mass * (cc - c.z * c.z);
+    o[7] = Iw.m[1] - mass * c.x * c.y; o[8] = Iw.m[2] - mass * c.x * c.z; o[9] = Iw.m[5] - mass * c.y * c.z;
+#pragma unroll
+    for (int k = 0; k < 10; k++) s.crb[b][k] = o[k];
+    sv v = ldsv(s.cvel[b]), a = ldsv(s.cacc[b]);
+    sv f = inert_mul(o, a) + cross_force(v, inert_mul(o, v));
+    stsv(s.cfrc[b], f);
+  }
+}
+
+// children -> parents: composite inertias (lanes 0..9) and RNE forces (lanes 16..21), component-parallel
+JDEV void stage_accumulate(const JacoModelDev* m, JacoLDS& s, int lane) {
+  for (int b = m->nbody - 1; b > 0; b--) {
+    int p = m->b_parent[b];
+    if (p < 0) continue;
+    if (lane < 10) s.crb[p][lane] += s.crb[b][lane];
+    else if (lane >= 16 && lane < 22) s.cfrc[p][lane - 16] += s.cfrc[b][lane - 16];
+  }
+}
+
+// ---------------------------------------------------------------- stage M: mass matrix, bias, actuation
+JDEV void stage_mass_bias(const JacoModelDev* m, JacoLDS& s, int lane) {
+  if (lane < m->nv) {
+    int d = lane, b = m->d_body[d];
+    sv S = ldsv(s.cdof[d]);
+    sv F = inert_mul(s.crb[b], S);
+    for (int j = d; j >= 0; j = m->d_parent[j]) {
+      float v = dot(ldsv(s.cdof[j]), F);
+      s.M[d * JNV + j] = v;
+      s.M[j * JNV + d] = v;
+    }
+    float bias = dot(S, ldsv(s.cfrc[b]));
+    s.bias[d] = bias;
+    s.smooth[d] = -m->d_damping[d] * s.qvel[d] - bias;
+  }
+}
+JDEV void stage_actuation(const JacoModelDev* m, JacoLDS& s, int lane) {
+  if (lane < m->nu) {
+    int a = lane;
+    float c = s.ctrl[a];
+    if (m->a_ctrllimited[a]) c = fmaxf(m->a_ctrlrange[a][0], fminf(m->a_ctrlrange[a][1], c));
+    float f = m->a_position[a] ? m->a_kp[a] * (c - s.qpos[m->a_qadr[a]]) : c;
+    if (m->a_forcelimited[a]) f = fmaxf(m->a_forcerange[a][0], fminf(m->a_forcerange[a][1], f));
+    s.smooth[m->a_dof[a]] += f;
+  }
+}
+
+// ---------------------------------------------------------------- stage R: constraint rows
+// impedance d(r) and reference acceleration of MuJoCo's soft constraints
+JDEV float impedance(const float* solimp, float pos) {
+  float dmin = fminf(0.9999f, fmaxf(0.0001f, solimp[0])), dmax = fminf(0.9999f, fmaxf(0.0001f, solimp[1]));
+  float width = fmaxf(JMINVAL, solimp[2]), mid = fminf(0.9999f, fmaxf(0.0001f, solimp[3])), power = fmaxf(1.f, solimp[4]);
+  float x = fabsf(pos) / width, y;
+  if (x >= 1.f) return dmax;
+  if (power == 1.f) y = x;
+  else if (x <= mid) y = powf(x, power) / powf(mid, power - 1.f);
+  else y = 1.f - powf(1.f - x, power) / powf(1.f - mid, power - 1.f);
+  return dmin + y * (dmax - dmin);
+}
+// returns aref; *D = 1/R
+JDEV float row_params(const float* solref, const float* solimp, float pos, float vel, float diagApprox, float* Rout) {
+  float imp = impedance(solimp, pos);
+  float dmax = fminf(0.9999f, fmaxf(0.0001f, solimp[1]));
+  float K = 1.f / fmaxf(JMINVAL, dmax * dmax * solref[0] * solref[0] * solref[1] * solref[1]);
+  float B = 2.f / fmaxf(JMINVAL, dmax * solref[0]);
+  *Rout = fmaxf(JMINVAL, (1.f - imp) * diagApprox / imp);
+  return -B * vel - K * imp * pos;
+}
+
+// joint limits: lane = body; one row per violated limit, compacted with a ballot
+JDEV void stage_limit_rows(const JacoModelDev* m, JacoLDS& s, int lane) {
+  bool act = false;
+  float dist = 0.f, sgn = 1.f;
+  int d = 0;
+  if (lane < m->nbody && m->b_jtype[lane] == JJ_HINGE && m->b_limited[lane]) {
+    float q = s.qpos[m->b_qadr[lane]];
+    float lo = q - m->b_range[lane][0], hi = m->b_range[lane][1] - q;
+    d = m->b_dadr[lane];
+    if (lo < 0.f) { act = true; dist = lo; sgn = 1.f; }
+    else if (hi < 0.f) { act = true; dist = hi; sgn = -1.f; }
+  }
+  unsigned long long mask = wave_ballot(act);
+  int r = wave_prefix_count(mask);
+  if (act) {
+    for (int k = 0; k < JNV; k++) s.J[r * JLD + k] = 0.f;
+    s.J[r * JLD + d] = sgn;
+    float R;
+    s.e_aref[r] = row_params(m->b_solref[lane], m->b_solimp[lane], dist, sgn * s.qvel[d], m->d_invweight[d], &R);
+    s.e_D[r] = 1.f / R;
+  }
+  if (lane == 0) s.nefc = popc64(mask);
+}
+
+// ---------------------------------------------------------------- stage S: primal Newton solver
+// Lane k < nv owns element k of every dof vector; lane r owns constraint rows r and r + 64.
+struct NewtonOut { float qacc, qfrc_con; int iters; };
+
+JDEV float row_dot(const float* Jrow, float vk, int nv) {  // sum_k Jrow[k] * v[k], v distributed one element per lane
+  float acc = 0.f;
+#pragma unroll
+  for (int k = 0; k < JNV; k++) {
+    float vb = wave_bcast(vk, k);
+    acc += (k < nv ? Jrow[k] : 0.f) * vb;
+  }
+  return acc;
+}
+JDEV float mat_vec(const float* M, float vk, int lane, int nv) {  // (M v)[lane]
+  float acc = 0.f;
+  const float* row = M + (lane < nv ? lane : 0) * JNV;
+#pragma unroll
+  for (int k = 0; k < JNV; k++) acc += row[k] * wave_bcast(vk, k);
+  return lane < nv ? acc : 0.f;
+}
+// sum_r J[r][lane] * f_r with f distributed over (f0: rows 0..63, f1: rows 64..127)
+JDEV float jt_vec(const JacoLDS& s, float f0, float f1, int ne, int lane, int nv) {
+  float acc = 0.f;
+  int kk = lane < nv ? lane : 0;
+  for (int r = 0; r < ne; r++) {
+    float fr = r < 64 ? wave_bcast(f0, r) : wave_bcast(f1, r - 64);
+    if (fr != 0.f) acc += s.J[r * JLD + kk] * fr;
+  }
+  return lane < nv ? acc : 0.f;
+}
+
+JDEV NewtonOut stage_newton(const JacoModelDev* m, JacoLDS& s, int lane) {
+  NewtonOut out;
+  int nv = m->nv, ne = s.nefc;
+  float qas = lane < nv ? s.qacc_smooth[lane] : 0.f;
+  out.qacc = qas; out.qfrc_con = 0.f; out.iters = 0;
+  if (ne == 0) return out;
+  int r0 = lane, r1 = lane + 64;
+  bool v0 = r0 < ne, v1 = r1 < ne;
+  const float* J0 = s.J + (v0 ? r0 : 0) * JLD;
+  const float* J1 = s.J + (v1 ? r1 : 0) * JLD;
+  float D0 = v0 ? s.e_D[r0] : 0.f, D1 = v1 ? s.e_D[r1] : 0.f;
+  float ar0 = v0 ? s.e_aref[r0] : 0.f, ar1 = v1 ? s.e_aref[r1] : 0.f;
+  float scale = 1.f / (m->meaninertia * (float)(nv > 1 ? nv : 1));
+  float tol = m->tolerance;
+
+  // starting point: cheaper of warm start and unconstrained acceleration
+  float a = lane < nv ? s.qacc_ws[lane] : 0.f;
+  float Ma = mat_vec(s.M, a - qas, lane, nv);
+  // (cross-lane helpers are always called by all 64 lanes; validity is applied to their results)
+  float t0 = row_dot(J0, a, nv), t1 = row_dot(J1, a, nv);
+  float x0 = v0 ? t0 - ar0 : 0.f, x1 = v1 ? t1 - ar1 : 0.f;
+  t0 = row_dot(J0, qas, nv); t1 = row_dot(J1, qas, nv);
+  float xs0 = v0 ? t0 - ar0 : 0.f, xs1 = v1 ? t1 - ar1 : 0.f;
+  float cw = 0.5f * Ma * (a - qas) + (x0 < 0.f ? 0.5f * D0 * x0 * x0 : 0.f) + (x1 < 0.f ? 0.5f * D1 * x1 * x1 : 0.f);
+  float cs = (xs0 < 0.f ? 0.5f * D0 * xs0 * xs0 : 0.f) + (xs1 < 0.f ? 0.5f * D1 * xs1 * xs1 : 0.f);
+  cw = wave_sum(cw);
+  cs = wave_sum(cs);
+  if (!(cw < cs)) { a = qas; Ma = 0.f; x0 = xs0; x1 = xs1; }
+
+  int it = 0;
+  for (; it < m->iterations; it++) {
+    float f0 = x0 < 0.f ? -D0 * x0 : 0.f, f1 = x1 < 0.f ? -D1 * x1 : 0.f;
+    float grad = Ma - jt_vec(s, f0, f1, ne, lane, nv);
+    float gn = sqrtf(wave_sum(grad * grad));
+    if (gn * scale < tol) break;
+    // Hessian rows: M + sum_active D_r J_r^T J_r
+    float h[JNV];
+    load_rows(h, s.M, nv, lane);
+    float w0 = x0 < 0.f ? D0 : 0.f, w1 = x1 < 0.f ? D1 : 0.f;
+    int kk = lane < nv ? lane : 0;
+    for (int r = 0; r < ne; r++) {
+      float Dr = r < 64 ? wave_bcast(w0, r) : wave_bcast(w1, r - 64);
+      if (Dr == 0.f) continue;
+      const float* Jr = s.J + r * JLD;
+      float w = lane < nv ? Dr * Jr[kk] : 0.f;
+#pragma unroll
+      for (int j = 0; j < JNV; j++) h[j] += w * Jr[j];
+    }
+    float p = ldl_solve(h, -grad, lane);
+    p = lane < nv ? p : 0.f;
+    // exact line search on phi(al) = cost(a + al p)
+    float Mp = mat_vec(s.M, p, lane, nv);
+    float pMp = wave_sum(p * Mp), pMa = wave_sum(p * Ma);
+    float jp0 = row_dot(J0, p, nv), jp1 = row_dot(J1, p, nv);
+    jp0 = v0 ? jp0 : 0.f; jp1 = v1 ? jp1 : 0.f;
+    float al = 0.f, lo = 0.f, hi = 3.0e38f, d10 = 0.f;
+    for (int ls = 0; ls < m->ls_iterations; ls++) {
+      float xa0 = x0 + al * jp0, xa1 = x1 + al * jp1;
+      float s1 = (xa0 < 0.f ? D0 * xa0 * jp0 : 0.f) + (xa1 < 0.f ? D1 * xa1 * jp1 : 0.f);
+      float s2 = (xa0 < 0.f ? D0 * jp0 * jp0 : 0.f) + (xa1 < 0.f ? D1 * jp1 * jp1 : 0.f);
+      float d1 = pMa + al * pMp + wave_sum(s1), d2 = pMp + wave_sum(s2);
+      if (ls == 0) d10 = fabsf(d1);
+      if (ls > 0 && fabsf(d1) <= 1e-6f * d10) break;
+      if (d1 < 0.f) lo = al; else hi = al;
+      float nx = al - d1 / d2;
+      if (!(nx > lo && nx < hi)) nx = hi < 1.0e38f ? 0.5f * (lo + hi) : 2.f * al + 1.f;
+      if (nx == al) break;
+      al = nx;
+    }
+    // move; cost decrease evaluated along the line (no large-number cancellation)
+    float xn0 = x0 + al * jp0, xn1 = x1 + al * jp1;
+    float dc = (xn0 < 0.f ? 0.5f * D0 * xn0 * xn0 : 0.f) - (x0 < 0.f ? 0.5f * D0 * x0 * x0 : 0.f) +
+               (xn1 < 0.f ? 0.5f * D1 * xn1 * xn1 : 0.f) - (x1 < 0.f ? 0.5f * D1 * x1 * x1 : 0.f);
+    float improvement = -(al * pMa + 0.5f * al * al * pMp + wave_sum(dc));
+    a += al * p; Ma += al * Mp; x0 = xn0; x1 = xn1;
+    if (improvement * scale < tol) { it++; break; }
+  }
+  float f0 = x0 < 0.f ? -D0 * x0 : 0.f, f1 = x1 < 0.f ? -D1 * x1 : 0.f;
+  out.qacc = a;
+  out.qfrc_con = jt_vec(s, f0, f1, ne, lane, nv);
+  out.iters = it;
+  if (v0) s.e_f[r0] = f0;
+  if (v1) s.e_f[r1] = f1;
+  return out;
+}
+
+// ---------------------------------------------------------------- stage E: integration
+JDEV void stage_integrate_pos(const JacoModelDev* m, JacoLDS& s, int lane) {
+  float h = m->timestep;
+  if (lane < m->nbody) {
+    int b = lane, qa = m->b_qadr[b], da = m->b_dadr[b];
+    if (m->b_jtype[b] == JJ_HINGE) {
+      s.qpos[qa] += h * s.qvel[da];
+    } else {
+      for (int k = 0; k < 3; k++) s.qpos[qa + k] += h * s.qvel[da + k];
+      v3 w = ld3(&s.qvel[da + 3]);
+      float wn = norm(w), ang = h * wn;
+      float q0 = s.qpos[qa + 3], q1 = s.qpos[qa + 4], q2 = s.qpos[qa + 5], q3 = s.qpos[qa + 6];
+      if (ang > 0.f) {
+        v3 ax = w * (1.f / wn);
+        float sn = sinf(0.5f * ang), c = cosf(0.5f * ang);
+        float d1 = ax.x * sn, d2 = ax.y * sn, d3 = ax.z * sn;
+        float n0 = q0 * c - q1 * d1 - q2 * d2 - q3 * d3;
+        float n1 = q0 * d1 + q1 * c + q2 * d3 - q3 * d2;
+        float n2 = q0 * d2 - q1 * d3 + q2 * c + q3 * d1;
+        float n3 = q0 * d3 + q1 * d2 - q2 * d1 + q3 * c;
+        q0 = n0; q1 = n1; q2 = n2; q3 = n3;
+      }
+      float n = sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
+      if (n < JMINVAL) { q0 = 1.f; q1 = q2 = q3 = 0.f; } else { float in = 1.f / n; q0 *= in; q1 *= in; q2 *= in; q3 *= in; }
+      s.qpos[qa + 3] = q0; s.qpos[qa + 4] = q1; s.qpos[qa + 5] = q2; s.qpos[qa + 6] = q3;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- the kernel
+#ifndef JACO_HAVE_COLLISION
+JDEV void stage_collision(const JacoStepArgs&, const JacoModelDev*, JacoLDS& s, int lane) { if (lane == 0) { s.ncon = 0; s.ncand = 0; } }
+JDEV void stage_contact_rows(const JacoModelDev*, JacoLDS&, int) {}
+JDEV void stage_touch(const JacoModelDev*, JacoLDS&, int, float* sens) { *sens = 0.f; }
+#endif
+
+__global__ __launch_bounds__(64) void jaco_physics_kernel(JacoStepArgs A) {
+  __shared__ JacoLDS s;
+  const int lane = lane_id(), env = env_id();
+  if (env >= A.nenv) return;
+  const JacoModelDev* m = A.model;
+  const int nq = m->nq, nv = m->nv, nu = m->nu, ns = m->nsensor;
+  if (lane < nq) s.qpos[lane] = A.qpos[(size_t)env * nq + lane];
+  if (lane < nv) { s.qvel[lane] = A.qvel[(size_t)env * nv + lane]; s.qacc_ws[lane] = A.qacc_ws[(size_t)env * nv + lane]; }
+  if (lane < nu) s.ctrl[lane] = A.ctrl[(size_t)env * nu + lane];
+  unsigned flags = 0;
+  float sens = 0.f;
+  int iters = 0;
+  wave_sync();
+  for (int sub = 0; sub < A.nsub; sub++) {
+    stage_walk(m, s, lane);
+    for (int i = lane; i < JNV * JNV; i += 64) s.M[i] = 0.f;
+    wave_sync();
+    stage_geoms_inertia(m, s, lane);
+    wave_sync();
+    stage_accumulate(m, s, lane);
+    wave_sync();
+    stage_mass_bias(m, s, lane);
+    wave_sync();
+    stage_actuation(m, s, lane);
+    wave_sync();
+    float h[JNV];
+    load_rows(h, s.M, nv, lane);
+    float smooth = lane < nv ? s.smooth[lane] : 0.f;
+    float qas = ldl_solve(h, smooth, lane);
+    if (lane < nv) s.qacc_smooth[lane] = qas;
+    stage_limit_rows(m, s, lane);
+    wave_sync();
+    if (!A.disable_contact) {
+      stage_collision(A, m, s, lane);
+      wave_sync();
+      stage_contact_rows(m, s, lane);
+      wave_sync();
+    } else if (lane == 0) {
+      s.ncon = 0; s.ncand = 0;
+    }
+    wave_sync();
+    if (s.nefc > JMAXEFC) flags |= JFLAG_EFC_OVERFLOW;
+    NewtonOut nw = stage_newton(m, s, lane);
+    iters = nw.iters;
+    if (iters >= m->iterations) flags |= JFLAG_SOLVER_MAXITER;
+    wave_sync();
+    stage_touch(m, s, lane, &sens);
+    // Euler with implicit joint damping
+    float total = smooth + nw.qfrc_con, qacc_e = nw.qacc;
+    if (m->has_damping) {
+      load_rows(h, s.M, nv, lane);
+      float hd = lane < nv ? m->timestep * m->d_damping[lane] : 0.f;
+#pragma unroll
+      for (int j = 0; j < JNV; j++) h[j] += lane == j ? hd : 0.f;
+      qacc_e = ldl_solve(h, total, lane);
+    }
+    if (A.dbg && env == A.dbg_env && sub == A.nsub - 1) {
+      float* D = A.dbg;
+      if (lane < m->nbody) {
+        for (int k = 0; k < 3; k++) D[JDBG_XPOS + 3 * lane + k] = s.xpos[lane][k];
+        for (int k = 0; k < 9; k++) D[JDBG_XMAT + 9 * lane + k] = s.xmat[lane][k];
+      }
+      for (int i = lane; i < JNV * JNV; i += 64) D[JDBG_M + i] = s.M[i];
+      if (lane < nv) {
+        D[JDBG_BIAS + lane] = s.bias[lane]; D[JDBG_SMOOTH + lane] = smooth; D[JDBG_QACC_SMOOTH + lane] = qas;
+        D[JDBG_QACC + lane] = nw.qacc; D[JDBG_QFRC_CON + lane] = nw.qfrc_con;
+      }
+      if (lane == 0) { D[JDBG_NCON] = (float)s.ncon; D[JDBG_NCON + 1] = (float)s.nefc; D[JDBG_NCON + 2] = (float)iters; D[JDBG_NCON + 3] = (float)s.ncand; }
+      for (int c = lane; c < s.ncon && c < JMAXCON; c += 64) {
+        float* o = D + JDBG_CONTACT + 8 * c;
+        o[0] = s.c_dist[c]; o[1] = s.c_pos[c][0]; o[2] = s.c_pos[c][1]; o[3] = s.c_pos[c][2];
+        o[4] = s.c_frame[c][0]; o[5] = s.c_frame[c][1]; o[6] = s.c_frame[c][2]; o[7] = (float)s.c_pair[c];
+      }
+      for (int r = lane; r < s.nefc && r < JMAXEFC; r += 64) {
+        float* o = D + JDBG_EFC + 4 * r;
+        o[0] = s.e_aref[r]; o[1] = 1.f / s.e_D[r]; o[2] = 0.f; o[3] = s.e_f[r];
+      }
+      if (lane < m->ngeom) for (int k = 0; k < 3; k++) D[JDBG_GPOS + 3 * lane + k] = s.gpos[lane][k];
+    }
+    wave_sync();
+    if (lane < nv) {
+      float v = s.qvel[lane] + m->timestep * qacc_e;
+      s.qvel[lane] = v;
+      s.qacc_ws[lane] = nw.qacc;
+      if (!(v == v) || fabsf(v) > 1e10f) flags |= JFLAG_NAN;
+    }
+    wave_sync();
+    stage_integrate_pos(m, s, lane);
+    wave_sync();
+  }
+  if (lane < nq) A.qpos[(size_t)env * nq + lane] = s.qpos[lane];
+  if (lane < nv) { A.qvel[(size_t)env * nv + lane] = s.qvel[lane]; A.qacc_ws[(size_t)env * nv + lane] = s.qacc_ws[lane]; }
+  if (lane < ns && A.sensordata) A.sensordata[(size_t)env * ns + lane] = sens;
+  unsigned long long anyf = wave_ballot(flags != 0);
+  if (anyf) {
+    unsigned f = flags;
+    for (int o = 1; o < 64; o <<= 1) f |= (unsigned)wave_shfl_i((int)f, lane ^ o);
+    if (lane == 0 && A.flags) A.flags[env] |= f;
+  }
+  if (lane == 0 && A.stats) {
+    A.stats[4 * env] = s.ncon; A.stats[4 * env + 1] = s.nefc; A.stats[4 * env + 2] = iters; A.stats[4 * env + 3] = s.ncand;
+  }
+}

@@ -1,0 +1,75 @@
+// TEST INFRASTRUCTURE: emulation of mujoco_jaco_amd/csrc/include/jaco/wave_ops.h on the host.
+// 64 fibers run the kernel body in lockstep; every cross-lane primitive is a rendezvous.
+// Stricter than hardware: a missing wave_sync() around an LDS hand-off shows up as stale data.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define JACO_WAVE 64
+#define JDEV static inline
+
+union EmuWord { float f; int i; unsigned long long u; };
+extern EmuWord emu_x[2][64];
+extern unsigned emu_cnt[64];
+
+JDEV int lane_id() { return emu_cur_lane; }
+JDEV int env_id() { return emu_block; }
+JDEV void wave_sync() { emu_collective(); }
+
+JDEV int emu_post_f(float v) { int p = emu_cnt[emu_cur_lane]++ & 1; emu_x[p][emu_cur_lane].f = v; return p; }
+JDEV int emu_post_i(int v) { int p = emu_cnt[emu_cur_lane]++ & 1; emu_x[p][emu_cur_lane].i = v; return p; }
+
+JDEV float wave_bcast(float v, int src) { int p = emu_post_f(v); emu_collective(); return emu_x[p][src].f; }
+JDEV int wave_bcast_i(int v, int src) { int p = emu_post_i(v); emu_collective(); return emu_x[p][src].i; }
+JDEV float wave_shfl(float v, int src) { int p = emu_post_f(v); emu_collective(); return emu_x[p][src & 63].f; }
+JDEV int wave_shfl_i(int v, int src) { int p = emu_post_i(v); emu_collective(); return emu_x[p][src & 63].i; }
+JDEV unsigned long long wave_ballot(bool pr) {
+  int p = emu_post_i(pr ? 1 : 0);
+  emu_collective();
+  unsigned long long m = 0;
+  for (int l = 0; l < 64; l++) if (emu_x[p][l].i) m |= 1ull << l;
+  return m;
+}
+JDEV int wave_prefix_count(unsigned long long mask) { return __builtin_popcountll(mask & ((1ull << emu_cur_lane) - 1)); }
+JDEV int popc64(unsigned long long m) { return __builtin_popcountll(m); }
+JDEV int ffs64(unsigned long long m) { return m ? __builtin_ctzll(m) : -1; }
+
+// same association order as the DPP butterfly of the device version (bitwise-identical sums)
+JDEV float wave_sum(float v) {
+  int p = emu_post_f(v);
+  emu_collective();
+  float row[4];
+  for (int r = 0; r < 4; r++) {
+    float t[16];
+    for (int l = 0; l < 16; l++) t[l] = emu_x[p][16 * r + l].f;
+    float a[16];
+    for (int l = 0; l < 16; l++) a[l] = t[l] + t[l ^ 1];
+    for (int l = 0; l < 16; l++) t[l] = a[l] + a[l ^ 2];
+    for (int l = 0; l < 16; l++) a[l] = t[l] + t[(l & 8) | (7 - (l & 7))];
+    for (int l = 0; l < 16; l++) t[l] = a[l] + a[15 - l];
+    row[r] = t[0];
+  }
+  return (row[0] + row[1]) + (row[2] + row[3]);
+}
+JDEV float wave_max(float v) {
+  int p = emu_post_f(v);
+  emu_collective();
+  float m = emu_x[p][0].f;
+  for (int l = 1; l < 64; l++) m = fmaxf(m, emu_x[p][l].f);
+  return m;
+}
+JDEV float wave_min(float v) { return -wave_max(-v); }
+JDEV int wave_argmax(float v, int idx, float* best) {
+  int p = emu_post_f(v);
+  emu_collective();
+  int q = emu_post_i(idx);
+  emu_collective();
+  float bv = emu_x[p][0].f;
+  int bi = emu_x[q][0].i;
+  for (int l = 1; l < 64; l++) {
+    float v2 = emu_x[p][l].f;
+    int i2 = emu_x[q][l].i;
+    if (v2 > bv || (v2 == bv && i2 < bi)) { bv = v2; bi = i2; }
+  }
+  *best = bv;
+  return bi;
+}

@@ -1,0 +1,57 @@
+"""ctypes binding of tests/emu/libjaco_emu.so -- TEST INFRASTRUCTURE ONLY.
+
+Runs the *unmodified* HIP kernel source (mujoco_jaco_amd/csrc/physics_kernel.h) compiled for the host
+against a lockstep 64-lane wavefront emulator, so kernel logic can be checked against the oracle
+without a GPU.  Not a product path: the product library refuses to run without a HIP device.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU_DIR = os.path.join(ROOT, "tests", "emu")
+ASSETS = os.path.join(ROOT, "mujoco_jaco_amd", "assets")
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        subprocess.check_call(["make", "-s", "-C", EMU_DIR])
+        L = ctypes.CDLL(os.path.join(EMU_DIR, "libjaco_emu.so"))
+        fp, ip, up = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint)
+        L.emu_physics_step.argtypes = [ctypes.c_char_p, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int, fp, fp, fp, fp, fp, up, ip, fp, ctypes.c_int]
+        _lib = L
+    return _lib
+
+
+class EmuEnv:
+    """Batched env state (fp32, [nenv][n]) stepped by the emulated kernel."""
+
+    def __init__(self, model="jaco2_curtain_torque", nenv=1):
+        self.L = lib()
+        self.blob = open(os.path.join(ASSETS, model + ".jacomdl"), "rb").read()
+        from mujoco_jaco_amd.modelc import blob as blobmod
+        M = blobmod.loads(self.blob)
+        self.M = M
+        self.nq, self.nv, self.nu, self.ns = int(M["nq"][0]), int(M["nv"][0]), int(M["nu"][0]), int(M["nsensor"][0])
+        self.nenv = nenv
+        self.qpos = np.tile(M["qpos0"].astype(np.float32), (nenv, 1))
+        self.qvel = np.zeros((nenv, self.nv), np.float32)
+        self.qacc_ws = np.zeros((nenv, self.nv), np.float32)
+        self.sensordata = np.zeros((nenv, self.ns), np.float32)
+        self.flags = np.zeros(nenv, np.uint32)
+        self.stats = np.zeros((nenv, 4), np.int32)
+        self.dbg = np.zeros(self.L.emu_dbg_size(), np.float32)
+
+    def step(self, ctrl, nsub=1, disable_contact=False, dbg_env=-1):
+        ctrl = np.ascontiguousarray(np.broadcast_to(np.asarray(ctrl, np.float32), (self.nenv, self.nu)))
+        fp = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+        rc = self.L.emu_physics_step(self.blob, len(self.blob), self.nenv, nsub, int(disable_contact), fp(self.qpos), fp(self.qvel),
+                                     fp(self.qacc_ws), fp(ctrl), fp(self.sensordata),
+                                     self.flags.ctypes.data_as(ctypes.POINTER(ctypes.c_uint)),
+                                     self.stats.ctypes.data_as(ctypes.POINTER(ctypes.c_int)),
+                                     fp(self.dbg) if dbg_env >= 0 else None, dbg_env)
+        assert rc == 0
