@@ -102,6 +102,10 @@ int jaco_debug_dump_floats(void);
 int jaco_kernel_time_ms(JacoHandle* h, double* avg_ms, int* launches);
 int jaco_enable_timing(JacoHandle* h, int enable);
 
+/* Diagnostic builds only (-DJACO_PROFILE_STAGES): per-env, per-stage shader-clock sums [num_envs][12] copied to host;
+ * the shipped library returns JACO_EINVAL. */
+int jaco_stage_profile(JacoHandle* h, uint64_t* out_host, int reset);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libjaco_env.so")
+LIB_PATH = os.path.join(_HERE, os.environ.get("JACO_ENV_LIB", "libjaco_env.so"))
 ASSETS = os.path.join(_HERE, "assets")
 
 
@@ -38,6 +38,7 @@ SYMBOLS = {
     "jaco_debug_dump_floats": (_ci, []),
     "jaco_kernel_time_ms": (_ci, [_vp, ctypes.POINTER(_cd), _ip]),
     "jaco_enable_timing": (_ci, [_vp, _ci]),
+    "jaco_stage_profile": (_ci, [_vp, ctypes.POINTER(ctypes.c_uint64), _ci]),
 }
 
 _lib = None

@@ -1,0 +1,501 @@
+// Collision + contact rows + touch sensors for the one-wavefront-per-env physics kernel.
+// Included by physics_kernel.h.  Restates, per environment, MuJoCo's collision pipeline as the
+// reference runs it inside sim.step() (mujoco.py:278):
+//   static pair whitelist -> bounding-sphere test -> (cull only) OBB test -> narrowphase:
+//   plane-box / plane-sphere / plane-hull analytic, box-box SAT + face polygon intersection,
+//   everything else (hull meshes, sphere) through Minkowski Portal Refinement on support functions.
+// Hull support queries scan the hull vertices with all 64 lanes and reduce with a DPP argmax.
+#pragma once
+
+#define JACO_HAVE_COLLISION 1
+
+struct GeomPose { v3 p; m3 R; };
+JDEV GeomPose geom_pose(const JacoLDS& s, int g) { GeomPose r; r.p = ld3(s.gpos[g]); r.R = ldm(s.gmat[g]); return r; }
+
+// conservative oriented-box separation test (cull only: may say "not separated" for separated boxes, never the reverse)
+JDEV bool obb_separated(const GeomPose& a, v3 sa, const GeomPose& b, v3 sb) {
+  float C[3][3], Q[3][3];
+  v3 d = b.p - a.p;
+  float t[3] = {dot(d, col(a.R, 0)), dot(d, col(a.R, 1)), dot(d, col(a.R, 2))};
+  float ea[3] = {sa.x, sa.y, sa.z}, eb[3] = {sb.x, sb.y, sb.z};
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) { C[i][j] = dot(col(a.R, i), col(b.R, j)); Q[i][j] = fabsf(C[i][j]) + 1e-5f; }
+  bool sep = false;
+#pragma unroll
+  for (int i = 0; i < 3; i++) sep |= fabsf(t[i]) > ea[i] + eb[0] * Q[i][0] + eb[1] * Q[i][1] + eb[2] * Q[i][2];
+#pragma unroll
+  for (int j = 0; j < 3; j++)
+    sep |= fabsf(t[0] * C[0][j] + t[1] * C[1][j] + t[2] * C[2][j]) > eb[j] + ea[0] * Q[0][j] + ea[1] * Q[1][j] + ea[2] * Q[2][j];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+      float ra = ea[i1] * Q[i2][j] + ea[i2] * Q[i1][j], rb = eb[j1] * Q[i][j2] + eb[j2] * Q[i][j1];
+      sep |= fabsf(t[i2] * C[i1][j] - t[i1] * C[i2][j]) > ra + rb;
+    }
+  return sep;
+}
+
+JDEV void make_frame(v3 n, float* fr) {
+  n = normalized(n);
+  v3 y = (n.y < 0.5f && n.y > -0.5f) ? mk3(0.f, 1.f, 0.f) : mk3(0.f, 0.f, 1.f);
+  y = normalized(y - n * dot(n, y));
+  v3 z = cross(n, y);
+  st3(fr, n); st3(fr + 3, y); st3(fr + 6, z);
+}
+
+// Append contacts held by lanes with `have` set (lane order), all lanes must call.
+JDEV void push_contacts(JacoLDS& s, bool have, float dist, v3 pos, v3 normal, int pair, int& ncon, unsigned& flags, int limit) {
+  unsigned long long mask = wave_ballot(have);
+  int idx = wave_prefix_count(mask), n = popc64(mask);
+  if (n > limit) n = limit;
+  bool keep = have && idx < limit;
+  if (keep && ncon + idx < JMAXCON) {
+    int c = ncon + idx;
+    s.c_dist[c] = dist;
+    st3(s.c_pos[c], pos);
+    make_frame(normal, s.c_frame[c]);
+    s.c_pair[c] = pair;
+  }
+  if (ncon + n > JMAXCON) { flags |= JFLAG_CON_OVERFLOW; n = JMAXCON - ncon; }
+  ncon += n;
+}
+
+// ---------------------------------------------------------------- support functions (all lanes, wave-uniform direction)
+JDEV v3 support_geom(const JacoStepArgs& A, const JacoModelDev* m, const JacoLDS& s, int g, int type, v3 dir, int lane) {
+  GeomPose P = geom_pose(s, g);
+  v3 l = mulT(P.R, dir), sp;
+  if (type == JG_BOX) {
+    sp = mk3(l.x > 0.f ? m->g_size[g][0] : -m->g_size[g][0], l.y > 0.f ? m->g_size[g][1] : -m->g_size[g][1], l.z > 0.f ? m->g_size[g][2] : -m->g_size[g][2]);
+  } else if (type == JG_SPHERE) {
+    float n = norm(l);
+    sp = l * (n > JMINVAL ? m->g_size[g][0] / n : 0.f);
+  } else {  // hull mesh: 64-lane scan + argmax (lowest vertex index wins ties, like a serial first-max scan)
+    int adr = m->g_vertadr[g], nvert = m->g_vertnum[g];
+    float best = -3.0e38f;
+    int bi = 0x7fffffff;
+    for (int i = lane; i < nvert; i += 64) {
+      const float* v = A.hull + 4 * (size_t)(adr + i);
+      float t = v[0] * l.x + v[1] * l.y + v[2] * l.z;
+      if (t > best) { best = t; bi = i; }
+    }
+    float bv;
+    int win = wave_argmax(best, bi, &bv);
+    const float* v = A.hull + 4 * (size_t)(adr + win);
+    sp = mk3(v[0], v[1], v[2]);
+  }
+  return P.p + mul(P.R, sp);
+}
+
+// ---------------------------------------------------------------- plane narrowphase
+JDEV void collide_plane_box(const JacoModelDev* m, JacoLDS& s, int g1, int g2, int pair, int lane, int& ncon, unsigned& flags) {
+  GeomPose P = geom_pose(s, g1), B = geom_pose(s, g2);
+  v3 n = col(P.R, 2);
+  int i = lane & 7;
+  v3 l = mk3((i & 1) ? m->g_size[g2][0] : -m->g_size[g2][0], (i & 2) ? m->g_size[g2][1] : -m->g_size[g2][1], (i & 4) ? m->g_size[g2][2] : -m->g_size[g2][2]);
+  v3 c = B.p + mul(B.R, l);
+  float dist = dot(c - P.p, n);
+  push_contacts(s, lane < 8 && !(dist > 0.f), dist, c - n * (0.5f * dist), n, pair, ncon, flags, 4);
+}
+JDEV void collide_plane_sphere(const JacoModelDev* m, JacoLDS& s, int g1, int g2, int pair, int lane, int& ncon, unsigned& flags) {
+  GeomPose P = geom_pose(s, g1);
+  v3 n = col(P.R, 2), c = ld3(s.gpos[g2]);
+  float r = m->g_size[g2][0], dist = dot(c - P.p, n) - r;
+  push_contacts(s, lane == 0 && !(dist > 0.f), dist, c - n * (r + 0.5f * dist), n, pair, ncon, flags, 1);
+}
+JDEV void collide_plane_convex(const JacoStepArgs& A, const JacoModelDev* m, JacoLDS& s, int g1, int g2, int t2, int pair, int lane, int& ncon, unsigned& flags) {
+  GeomPose P = geom_pose(s, g1);
+  v3 n = col(P.R, 2);
+  v3 sp = support_geom(A, m, s, g2, t2, -n, lane);
+  float dist = dot(sp - P.p, n);
+  push_contacts(s, lane == 0 && !(dist > 0.f), dist, sp - n * (0.5f * dist), n, pair, ncon, flags, 1);
+}
+
+// ---------------------------------------------------------------- box-box
+JDEV void collide_box_box(const JacoModelDev* m, JacoLDS& s, int g1, int g2, int pair, int lane, int& ncon, unsigned& flags) {
+  GeomPose P1 = geom_pose(s, g1), P2 = geom_pose(s, g2);
+  float s1[3] = {m->g_size[g1][0], m->g_size[g1][1], m->g_size[g1][2]}, s2[3] = {m->g_size[g2][0], m->g_size[g2][1], m->g_size[g2][2]};
+  v3 Aa[3] = {col(P1.R, 0), col(P1.R, 1), col(P1.R, 2)}, Ba[3] = {col(P2.R, 0), col(P2.R, 1), col(P2.R, 2)};
+  v3 pp = P2.p - P1.p;
+  // lane a < 6: face axis; 6 <= a < 15: edge axis A[i] x B[j]
+  int a = lane < 15 ? lane : 0;
+  int ei = a >= 6 ? (a - 6) / 3 : 0, ej = a >= 6 ? (a - 6) % 3 : 0;
+  v3 ax;
+  if (a < 3) ax = Aa[a]; else if (a < 6) ax = Ba[a - 3]; else ax = cross(Aa[ei], Ba[ej]);
+  float len = norm(ax);
+  bool degenerate = a >= 6 && len < 1e-6f;
+  ax = ax * (1.f / fmaxf(len, 1e-30f));
+  float ra = s1[0] * fabsf(dot(ax, Aa[0])) + s1[1] * fabsf(dot(ax, Aa[1])) + s1[2] * fabsf(dot(ax, Aa[2]));
+  float rb = s2[0] * fabsf(dot(ax, Ba[0])) + s2[1] * fabsf(dot(ax, Ba[1])) + s2[2] * fabsf(dot(ax, Ba[2]));
+  float dp = dot(pp, ax), pen = ra + rb - fabsf(dp);
+  bool mine = lane < 15 && !degenerate;
+  if (wave_ballot(mine && pen < 0.f)) return;  // separated
+  float fbest, ebest;
+  int fcode = wave_argmax(lane < 6 ? -pen : -3.0e38f, lane, &fbest);
+  int ecode = wave_argmax((lane >= 6 && mine) ? -pen : -3.0e38f, lane, &ebest);
+  fbest = -fbest; ebest = -ebest;
+  bool edge = ebest < 1.0e38f && ebest * 1.05f < fbest;
+  if (edge) {
+    int i = (ecode - 6) / 3, j = (ecode - 6) % 3;
+    float sgn = wave_bcast(dp, ecode) < 0.f ? -1.f : 1.f;
+    v3 n = mk3(wave_bcast(ax.x, ecode), wave_bcast(ax.y, ecode), wave_bcast(ax.z, ecode)) * sgn;
+    v3 ea = P1.p, eb = P2.p;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      if (k != i) ea = ea + Aa[k] * (dot(n, Aa[k]) > 0.f ? s1[k] : -s1[k]);
+      if (k != j) eb = eb + Ba[k] * (dot(n, Ba[k]) > 0.f ? -s2[k] : s2[k]);
+    }
+    v3 ua = i == 0 ? Aa[0] : (i == 1 ? Aa[1] : Aa[2]), ub = j == 0 ? Ba[0] : (j == 1 ? Ba[1] : Ba[2]);
+    v3 r = eb - ea;
+    float uv = dot(ua, ub), du = dot(r, ua), dv = dot(r, ub), den = 1.f - uv * uv;
+    float sa = den > 1e-12f ? (du - uv * dv) / den : 0.f, tb = den > 1e-12f ? (uv * du - dv) / den : 0.f;
+    v3 pos = ((ea + ua * sa) + (eb + ub * tb)) * 0.5f;
+    push_contacts(s, lane == 0, -ebest, pos, n, pair, ncon, flags, 1);
+    return;
+  }
+  // face contact: reference box (axis ia), incident box
+  bool refis1 = fcode < 3;
+  int ia = refis1 ? fcode : fcode - 3;
+  float bsign = wave_bcast(dp, fcode) < 0.f ? -1.f : 1.f;
+  v3 RA[3], IA[3];
+  float rs[3], is[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) { RA[k] = refis1 ? Aa[k] : Ba[k]; IA[k] = refis1 ? Ba[k] : Aa[k]; rs[k] = refis1 ? s1[k] : s2[k]; is[k] = refis1 ? s2[k] : s1[k]; }
+  v3 rp = refis1 ? P1.p : P2.p, ip = refis1 ? P2.p : P1.p;
+  // rotate so that the reference axis is index 0 (ia), then iu, iv
+  v3 Rn = ia == 0 ? RA[0] : (ia == 1 ? RA[1] : RA[2]);
+  v3 Ru = ia == 0 ? RA[1] : (ia == 1 ? RA[2] : RA[0]);
+  v3 Rv = ia == 0 ? RA[2] : (ia == 1 ? RA[0] : RA[1]);
+  float rn = ia == 0 ? rs[0] : (ia == 1 ? rs[1] : rs[2]);
+  float a_ = ia == 0 ? rs[1] : (ia == 1 ? rs[2] : rs[0]);
+  float b_ = ia == 0 ? rs[2] : (ia == 1 ? rs[0] : rs[1]);
+  v3 nref = Rn * (refis1 ? bsign : -bsign);
+  // incident face: most anti-parallel to nref (first index wins ties)
+  float d0 = dot(IA[0], nref), d1 = dot(IA[1], nref), d2 = dot(IA[2], nref);
+  int ib = 0;
+  float mind = -fabsf(d0);
+  if (-fabsf(d1) < mind) { mind = -fabsf(d1); ib = 1; }
+  if (-fabsf(d2) < mind) { mind = -fabsf(d2); ib = 2; }
+  float dd = ib == 0 ? d0 : (ib == 1 ? d1 : d2), isg = dd > 0.f ? -1.f : 1.f;
+  v3 In = ib == 0 ? IA[0] : (ib == 1 ? IA[1] : IA[2]);
+  v3 Iu = ib == 0 ? IA[1] : (ib == 1 ? IA[2] : IA[0]);
+  v3 Iv = ib == 0 ? IA[2] : (ib == 1 ? IA[0] : IA[1]);
+  float in_ = ib == 0 ? is[0] : (ib == 1 ? is[1] : is[2]);
+  float iu_ = ib == 0 ? is[1] : (ib == 1 ? is[2] : is[0]);
+  float iv_ = ib == 0 ? is[2] : (ib == 1 ? is[0] : is[1]);
+  v3 fc = ip + In * (isg * in_);
+  v3 rel = fc - rp;
+  v3 c2 = mk3(dot(rel, Ru), dot(rel, Rv), dot(rel, nref) - rn);
+  v3 eu = mk3(dot(Iu, Ru), dot(Iu, Rv), dot(Iu, nref)) * iu_;
+  v3 ev = mk3(dot(Iv, Ru), dot(Iv, Rv), dot(Iv, nref)) * iv_;
+  // candidate points: lanes 0..3 incident vertices, 4..7 reference corners, 8..23 edge crossings (k*4+e)
+  const float sgx[4] = {-1.f, 1.f, 1.f, -1.f}, sgy[4] = {-1.f, -1.f, 1.f, 1.f};
+  bool have = false;
+  v3 pt = mk3(0, 0, 0);
+  int k = lane < 8 ? (lane & 3) : ((lane - 8) >> 2) & 3;
+  float kx = k == 0 ? sgx[0] : (k == 1 ? sgx[1] : (k == 2 ? sgx[2] : sgx[3]));
+  float ky = k == 0 ? sgy[0] : (k == 1 ? sgy[1] : (k == 2 ? sgy[2] : sgy[3]));
+  int k1 = (k + 1) & 3;
+  float k1x = k1 == 0 ? sgx[0] : (k1 == 1 ? sgx[1] : (k1 == 2 ? sgx[2] : sgx[3]));
+  float k1y = k1 == 0 ? sgy[0] : (k1 == 1 ? sgy[1] : (k1 == 2 ? sgy[2] : sgy[3]));
+  v3 q0 = c2 + eu * kx + ev * ky, q1 = c2 + eu * k1x + ev * k1y;
+  if (lane < 4) {
+    have = fabsf(q0.x) <= a_ && fabsf(q0.y) <= b_;
+    pt = q0;
+  } else if (lane < 8) {
+    float det = eu.x * ev.y - eu.y * ev.x;
+    if (fabsf(det) > 1e-14f) {
+      float x = kx * a_ - c2.x, y = ky * b_ - c2.y;
+      float al = (x * ev.y - y * ev.x) / det, be = (eu.x * y - eu.y * x) / det;
+      have = fabsf(al) < 1.f && fabsf(be) < 1.f;
+      pt = mk3(kx * a_, ky * b_, c2.z + al * eu.z + be * ev.z);
+    }
+  } else if (lane < 24) {
+    int e = (lane - 8) & 3, axn = e & 1;
+    float lim = ((e & 2) ? 1.f : -1.f) * (axn ? b_ : a_), other = axn ? a_ : b_;
+    float q0a = axn ? q0.y : q0.x, q1a = axn ? q1.y : q1.x, q0o = axn ? q0.x : q0.y, q1o = axn ? q1.x : q1.y;
+    float e0 = q0a - lim, e1 = q1a - lim;
+    if (!((e0 < 0.f) == (e1 < 0.f) || e0 == e1)) {
+      float t = e0 / (e0 - e1);
+      float o = q0o + t * (q1o - q0o);
+      if (t > 0.f && t < 1.f && fabsf(o) < other) {
+        have = true;
+        pt = axn ? mk3(o, lim, q0.z + t * (q1.z - q0.z)) : mk3(lim, o, q0.z + t * (q1.z - q0.z));
+      }
+    }
+  }
+  have = have && !(pt.z > 0.f);
+  v3 pos = rp + Ru * pt.x + Rv * pt.y + nref * (rn + 0.5f * pt.z);
+  v3 n12 = nref * (refis1 ? 1.f : -1.f);
+  push_contacts(s, have, pt.z, pos, n12, pair, ncon, flags, 64);
+}
+
+// ---------------------------------------------------------------- MPR (all lanes run the same serial control flow)
+struct Sup { v3 v, v1, v2; };
+JDEV Sup mpr_support(const JacoStepArgs& A, const JacoModelDev* m, const JacoLDS& s, int g1, int t1, int g2, int t2, v3 dir, int lane) {
+  Sup r;
+  r.v1 = support_geom(A, m, s, g1, t1, dir, lane);
+  r.v2 = support_geom(A, m, s, g2, t2, -dir, lane);
+  r.v = r.v1 - r.v2;
+  return r;
+}
+JDEV v3 portal_dir(const Sup* p) { return normalized(cross(p[2].v - p[1].v, p[3].v - p[1].v)); }
+JDEV bool reach_tol(const Sup* p, const Sup& v4, v3 dir, float tol) {
+  float dv4 = dot(v4.v, dir);
+  float mn = fminf(dv4 - dot(p[1].v, dir), fminf(dv4 - dot(p[2].v, dir), dv4 - dot(p[3].v, dir)));
+  return mn <= tol;
+}
+JDEV void expand_portal(Sup* p, const Sup& v4) {
+  v3 c = cross(v4.v, p[0].v);
+  if (dot(p[1].v, c) > 0.f) {
+    if (dot(p[2].v, c) > 0.f) p[1] = v4; else p[3] = v4;
+  } else {
+    if (dot(p[3].v, c) > 0.f) p[2] = v4; else p[1] = v4;
+  }
+}
+JDEV float point_tri_closest(v3 a, v3 b, v3 c, v3* cp) {  // closest point of triangle abc to the origin
+  v3 ab = b - a, ac = c - a, ap = -a;
+  float d1 = dot(ab, ap), d2 = dot(ac, ap);
+  if (d1 <= 0.f && d2 <= 0.f) { *cp = a; return norm(a); }
+  v3 bp = -b;
+  float d3 = dot(ab, bp), d4 = dot(ac, bp);
+  if (d3 >= 0.f && d4 <= d3) { *cp = b; return norm(b); }
+  float vc = d1 * d4 - d3 * d2;
+  if (vc <= 0.f && d1 >= 0.f && d3 <= 0.f) { *cp = a + ab * (d1 / (d1 - d3)); return norm(*cp); }
+  v3 cpv = -c;
+  float d5 = dot(ab, cpv), d6 = dot(ac, cpv);
+  if (d6 >= 0.f && d5 <= d6) { *cp = c; return norm(c); }
+  float vb = d5 * d2 - d1 * d6;
+  if (vb <= 0.f && d2 >= 0.f && d6 <= 0.f) { *cp = a + ac * (d2 / (d2 - d6)); return norm(*cp); }
+  float va = d3 * d6 - d5 * d4;
+  if (va <= 0.f && (d4 - d3) >= 0.f && (d5 - d6) >= 0.f) { *cp = b + (c - b) * ((d4 - d3) / ((d4 - d3) + (d5 - d6))); return norm(*cp); }
+  float den = 1.f / (va + vb + vc);
+  *cp = a + ab * (vb * den) + ac * (vc * den);
+  return norm(*cp);
+}
+JDEV v3 mpr_find_pos(const Sup* p) {
+  float b0 = dot(cross(p[1].v, p[2].v), p[3].v), b1 = dot(cross(p[3].v, p[2].v), p[0].v);
+  float b2 = dot(cross(p[0].v, p[1].v), p[3].v), b3 = dot(cross(p[2].v, p[1].v), p[0].v);
+  float sum = b0 + b1 + b2 + b3;
+  if (sum <= 0.f) {
+    v3 dir = portal_dir(p);
+    b0 = 0.f;
+    b1 = dot(cross(p[2].v, p[3].v), dir); b2 = dot(cross(p[3].v, p[1].v), dir); b3 = dot(cross(p[1].v, p[2].v), dir);
+    sum = b1 + b2 + b3;
+  }
+  v3 a1 = p[0].v1 * b0 + p[1].v1 * b1 + p[2].v1 * b2 + p[3].v1 * b3;
+  v3 a2 = p[0].v2 * b0 + p[1].v2 * b1 + p[2].v2 * b2 + p[3].v2 * b3;
+  return (a1 + a2) * (0.5f / sum);
+}
+// returns true on penetration
+JDEV bool mpr_penetration(const JacoStepArgs& A, const JacoModelDev* m, const JacoLDS& s, int g1, int t1, int g2, int t2, int lane,
+                          float* depth, v3* dirout, v3* pos) {
+  Sup p[4], v4;
+  float tol = m->mpr_tolerance;
+  p[0].v1 = ld3(s.gpos[g1]); p[0].v2 = ld3(s.gpos[g2]); p[0].v = p[0].v1 - p[0].v2;
+  if (norm(p[0].v) < 1e-9f) p[0].v.x = 1e-5f;
+  v3 dr = normalized(-p[0].v);
+  p[1] = mpr_support(A, m, s, g1, t1, g2, t2, dr, lane);
+  if (dot(p[1].v, dr) <= 0.f) return false;
+  dr = cross(p[0].v, p[1].v);
+  if (norm(dr) < 1e-9f) {
+    *depth = norm(p[1].v); *dirout = normalized(p[1].v); *pos = (p[1].v1 + p[1].v2) * 0.5f;
+    return true;
+  }
+  dr = normalized(dr);
+  p[2] = mpr_support(A, m, s, g1, t1, g2, t2, dr, lane);
+  if (dot(p[2].v, dr) <= 0.f) return false;
+  dr = normalized(cross(p[1].v - p[0].v, p[2].v - p[0].v));
+  if (dot(dr, p[0].v) > 0.f) { Sup t = p[1]; p[1] = p[2]; p[2] = t; dr = -dr; }
+  for (int it = 0;; it++) {
+    if (it > 100) return false;
+    p[3] = mpr_support(A, m, s, g1, t1, g2, t2, dr, lane);
+    if (dot(p[3].v, dr) <= 0.f) return false;
+    bool cont = false;
+    if (dot(cross(p[1].v, p[3].v), p[0].v) < -1e-11f) { p[2] = p[3]; cont = true; }
+    if (!cont && dot(cross(p[3].v, p[2].v), p[0].v) < -1e-11f) { p[1] = p[3]; cont = true; }
+    if (!cont) break;
+    dr = normalized(cross(p[1].v - p[0].v, p[2].v - p[0].v));
+  }
+  for (int it = 0;; it++) {
+    dr = portal_dir(p);
+    if (dot(dr, p[1].v) >= 0.f) break;
+    v4 = mpr_support(A, m, s, g1, t1, g2, t2, dr, lane);
+    if (dot(v4.v, dr) < 0.f || reach_tol(p, v4, dr, tol) || it > m->mpr_iterations) return false;
+    expand_portal(p, v4);
+  }
+  for (int it = 0;; it++) {
+    dr = portal_dir(p);
+    v4 = mpr_support(A, m, s, g1, t1, g2, t2, dr, lane);
+    if (reach_tol(p, v4, dr, tol) || it > m->mpr_iterations) {
+      v3 cp;
+      *depth = point_tri_closest(p[1].v, p[2].v, p[3].v, &cp);
+      *dirout = *depth < 1e-10f ? dr : normalized(cp);
+      *pos = mpr_find_pos(p);
+      return true;
+    }
+    expand_portal(p, v4);
+  }
+}
+
+// ---------------------------------------------------------------- stage C
+JDEV void stage_collision(const JacoStepArgs& A, const JacoModelDev* m, JacoLDS& s, int lane, unsigned& flags) {
+  // phase 1: bounding spheres, lane = pair
+  int n1 = 0;
+  for (int base = 0; base < m->npair; base += 64) {
+    int k = base + lane;
+    bool valid = k < m->npair;
+    int code = m->pair_code[valid ? k : 0];
+    int g1 = code & 255, g2 = (code >> 8) & 255, t1 = (code >> 16) & 15;
+    v3 df = ld3(s.gpos[g2]) - ld3(s.gpos[g1]);
+    bool pass;
+    if (t1 == JG_PLANE) pass = !(dot(df, col(ldm(s.gmat[g1]), 2)) > m->g_rbound[g2]);
+    else { float r = m->g_rbound[g1] + m->g_rbound[g2]; pass = !(dot(df, df) > r * r); }
+    pass = pass && valid;
+    unsigned long long mask = wave_ballot(pass);
+    int idx = n1 + wave_prefix_count(mask);
+    if (pass && idx < JMAXCAND) s.cand[idx] = k;
+    n1 += popc64(mask);
+  }
+  if (n1 > JMAXCAND) { flags |= JFLAG_CAND_OVERFLOW; n1 = JMAXCAND; }
+  wave_sync();
+  // phase 2: oriented-box cull of the survivors, lane = survivor; compacted in place (order preserved)
+  int ncand = 0;
+  for (int base = 0; base < n1; base += 64) {
+    int ci = base + lane;
+    int k = ci < n1 ? s.cand[ci] : 0;
+    bool keep = ci < n1;
+    if (keep) {
+      int code = m->pair_code[k];
+      int g1 = code & 255, g2 = (code >> 8) & 255, t1 = (code >> 16) & 15, t2 = (code >> 20) & 15;
+      if (t1 != JG_PLANE) {
+        v3 sa = t1 == JG_SPHERE ? mk3(m->g_size[g1][0], m->g_size[g1][0], m->g_size[g1][0]) : ld3(m->g_size[g1]);
+        v3 sb = t2 == JG_SPHERE ? mk3(m->g_size[g2][0], m->g_size[g2][0], m->g_size[g2][0]) : ld3(m->g_size[g2]);
+        keep = !obb_separated(geom_pose(s, g1), sa, geom_pose(s, g2), sb);
+      }
+    }
+    wave_sync();
+    unsigned long long mask = wave_ballot(keep);
+    if (keep) s.cand[ncand + wave_prefix_count(mask)] = k;
+    ncand += popc64(mask);
+    wave_sync();
+  }
+  // phase 3: narrowphase, whole wave per candidate
+  int ncon = 0;
+  for (int c = 0; c < ncand; c++) {
+    int pk = s.cand[c];
+    int code = m->pair_code[pk];
+    int g1 = code & 255, g2 = (code >> 8) & 255, t1 = (code >> 16) & 15, t2 = (code >> 20) & 15;
+    if (t1 == JG_PLANE) {
+      if (t2 == JG_BOX) collide_plane_box(m, s, g1, g2, pk, lane, ncon, flags);
+      else if (t2 == JG_SPHERE) collide_plane_sphere(m, s, g1, g2, pk, lane, ncon, flags);
+      else if (t2 == JG_MESH) collide_plane_convex(A, m, s, g1, g2, t2, pk, lane, ncon, flags);
+    } else if (t1 == JG_BOX && t2 == JG_BOX) {
+      collide_box_box(m, s, g1, g2, pk, lane, ncon, flags);
+    } else {
+      float depth;
+      v3 dir, pos;
+      bool hit = mpr_penetration(A, m, s, g1, t1, g2, t2, lane, &depth, &dir, &pos);
+      push_contacts(s, hit && lane == 0, -depth, pos, dir, pk, ncon, flags, 1);
+    }
+  }
+  if (lane == 0) { s.ncon = ncon; s.ncand = ncand; }
+}
+
+// ---------------------------------------------------------------- stage R (contacts): pyramidal rows
+JDEV void stage_contact_rows(const JacoModelDev* m, JacoLDS& s, int lane, unsigned& flags) {
+  int nv = m->nv, ncon = s.ncon, r = s.nefc;  // rows after the joint-limit rows
+  int kk = lane < nv ? lane : 0;
+  sv S = ldsv(s.cdof[kk]);
+  int ncon_kept = ncon;
+  for (int c = 0; c < ncon; c++) {
+    const JacoPairParam& P = m->pair[s.c_pair[c]];
+    int dim = P.condim, nrow = dim == 1 ? 1 : 2 * (dim - 1);
+    if (r + nrow > JMAXEFC) { flags |= JFLAG_EFC_OVERFLOW; ncon_kept = c; break; }
+    int b1 = m->g_body[P.g1], b2 = m->g_body[P.g2];
+    unsigned m1 = b1 >= 0 ? m->b_chainmask[b1] : 0u, m2 = b2 >= 0 ? m->b_chainmask[b2] : 0u;
+    float coef = (float)((int)((m2 >> kk) & 1u) - (int)((m1 >> kk) & 1u));
+    v3 pos = ld3(s.c_pos[c]);
+    v3 jp = (S.b + cross(S.a, pos)) * coef, jr = S.a * coef;
+    const float* fr = s.c_frame[c];
+    float Jc[6];
+#pragma unroll
+    for (int a = 0; a < 3; a++) { Jc[a] = dot(ld3(fr + 3 * a), jp); Jc[3 + a] = dot(ld3(fr + 3 * a), jr); }
+    if (lane < nv) {
+      if (dim == 1) s.J[r * JLD + lane] = Jc[0];
+      else
+        for (int e = 0; e < nrow; e++) {
+          int k = 1 + (e >> 1);
+          float jk = k == 1 ? Jc[1] : (k == 2 ? Jc[2] : (k == 3 ? Jc[3] : (k == 4 ? Jc[4] : Jc[5])));
+          s.J[(r + e) * JLD + lane] = Jc[0] + ((e & 1) ? -1.f : 1.f) * P.mu[k - 1] * jk;
+        }
+    }
+    if (lane < nrow) s.e_con[r + lane] = c | (lane << 8);
+    if (lane == 0) s.c_efc[c] = r;
+    r += nrow;
+  }
+  wave_sync();  // every lane has read the incoming row / contact counts
+  if (lane == 0) { s.nefc = r; s.ncon = ncon_kept; }
+  wave_sync();
+  // per-row parameters, lane = row
+  int nlim = s.nlimit;
+  for (int rr = nlim + lane; rr < r; rr += 64) {
+    int ce = s.e_con[rr], c = ce & 255, e = ce >> 8;
+    const JacoPairParam& P = m->pair[s.c_pair[c]];
+    int dim = P.condim;
+    float vel = 0.f;
+    for (int k = 0; k < nv; k++) vel += s.J[rr * JLD + k] * s.qvel[k];
+    float tran = m->g_invweight[P.g1][0] + m->g_invweight[P.g2][0], rot = m->g_invweight[P.g1][1] + m->g_invweight[P.g2][1];
+    float pos = s.c_dist[c] - P.margin;
+    int k = dim == 1 ? 0 : 1 + (e >> 1);
+    float mu = dim == 1 ? 0.f : P.mu[k - 1];
+    float da = dim == 1 ? tran : tran + mu * mu * (k < 3 ? tran : rot);
+    float R;
+    float aref = row_params(P.solref, P.solimp, pos, vel, da, &R);
+    if (dim > 1) {  // pyramidal: every edge uses 2 mu^2 R of the contact's first row (impratio = 1)
+      float R0;
+      row_params(P.solref, P.solimp, pos, 0.f, tran + P.mu[0] * P.mu[0] * tran, &R0);
+      R = fmaxf(JMINVAL, 2.f * P.mu[0] * P.mu[0] * R0);
+    }
+    s.e_aref[rr] = aref;
+    s.e_D[rr] = 1.f / R;
+  }
+}
+
+// ---------------------------------------------------------------- stage T: touch sensors (env_mujoco_util.py:470-475 reads them)
+JDEV void stage_touch(const JacoModelDev* m, JacoLDS& s, int lane, float* sens) {
+  int ncon = s.ncon;
+  if (lane < ncon) {
+    const JacoPairParam& P = m->pair[s.c_pair[lane]];
+    int nrow = P.condim == 1 ? 1 : 2 * (P.condim - 1), r0 = s.c_efc[lane];
+    float fn = 0.f;
+    for (int e = 0; e < nrow; e++) fn += s.e_f[r0 + e];
+    s.c_fn[lane] = fn;
+  }
+  wave_sync();
+  float sum = 0.f;
+  if (lane < m->nsensor) {
+    int b = m->s_body[lane];
+    m3 R = ldm(m->s_mat[lane]);
+    v3 p = ld3(m->s_pos[lane]);
+    if (b >= 0) { m3 Rb = ldm(s.xmat[b]); p = ld3(s.xpos[b]) + mul(Rb, p); R = mul(Rb, R); }
+    int ob = m->s_origbody[lane], type = m->s_type[lane];
+    float sx = m->s_size[lane][0], sy = m->s_size[lane][1], sz = m->s_size[lane][2];
+    for (int c = 0; c < ncon; c++) {
+      const JacoPairParam& P = m->pair[s.c_pair[c]];
+      if (m->g_origbody[P.g1] != ob && m->g_origbody[P.g2] != ob) continue;
+      float fn = s.c_fn[c];
+      if (!(fn > JMINVAL)) continue;
+      v3 l = mulT(R, ld3(s.c_pos[c]) - p);
+      bool inside;
+      if (type == JG_BOX) inside = fabsf(l.x) <= sx && fabsf(l.y) <= sy && fabsf(l.z) <= sz;
+      else if (type == JG_CYLINDER) inside = l.x * l.x + l.y * l.y <= sx * sx && fabsf(l.z) <= sy;
+      else inside = dot(l, l) <= sx * sx;
+      if (inside) sum += fn;
+    }
+  }
+  *sens = sum;
+}

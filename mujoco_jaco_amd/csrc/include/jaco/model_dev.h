@@ -58,6 +58,7 @@ struct JacoModelDev {
   float g_pos[JMAXGEOM][3], g_mat[JMAXGEOM][9], g_size[JMAXGEOM][3], g_rbound[JMAXGEOM], g_invweight[JMAXGEOM][2];
 
   JacoPairParam pair[JMAXPAIR];
+  int pair_code[JMAXPAIR];   // g1 | g2 << 8 | type(g1) << 16 | type(g2) << 20, for the lane-per-pair broadphase
 
   // touch sites, one per sensor, in sensordata order
   int s_body[JNSENS], s_type[JNSENS], s_origbody[JNSENS];

@@ -24,6 +24,7 @@ struct JacoHandle {
   float *qpos = nullptr, *qvel = nullptr, *qacc_ws = nullptr, *sensordata = nullptr, *dbg = nullptr;
   unsigned* flags = nullptr;
   int* stats = nullptr;
+  unsigned long long* prof = nullptr;
   std::vector<float> qpos0;
   int num_envs = 0, device = 0, frame_skip = 50, task = 0, disable_contact = 0;
   uint64_t seed = 0;
@@ -115,16 +116,16 @@ extern "C" int jaco_create(const JacoConfig* cfg, JacoHandle** out) {
   *out = h;
   int rc = jaco_reset_state(h, nullptr);
   if (rc) { g_create_error = h->err; jaco_destroy(h); *out = nullptr; return rc; }
-  hipDeviceSynchronize();
+  (void)hipDeviceSynchronize();
   return JACO_OK;
 }
 
 extern "C" int jaco_destroy(JacoHandle* h) {
   if (!h) return JACO_EINVAL;
-  hipSetDevice(h->device);
-  for (auto& e : h->events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
-  void* ptrs[] = {h->model_dev, h->hull_dev, h->qpos, h->qvel, h->qacc_ws, h->sensordata, h->flags, h->stats, h->dbg};
-  for (void* p : ptrs) if (p) hipFree(p);
+  (void)hipSetDevice(h->device);
+  for (auto& e : h->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  void* ptrs[] = {h->model_dev, h->hull_dev, h->qpos, h->qvel, h->qacc_ws, h->sensordata, h->flags, h->stats, h->dbg, h->prof};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
   delete h;
   return JACO_OK;
 }
@@ -184,7 +185,7 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
   JacoStepArgs A{};
   A.model = h->model_dev; A.hull = h->hull_dev; A.qpos = h->qpos; A.qvel = h->qvel; A.qacc_ws = h->qacc_ws; A.ctrl = ctrl;
   A.sensordata = h->sensordata; A.flags = h->flags; A.stats = h->stats; A.nenv = h->num_envs; A.nsub = nsub;
-  A.disable_contact = h->disable_contact; A.dbg = dbg; A.dbg_env = dbg_env;
+  A.disable_contact = h->disable_contact; A.dbg = dbg; A.dbg_env = dbg_env; A.prof = h->prof;
   std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
   if (h->timing) {
     if (h->events_used == h->events.size()) {
@@ -250,6 +251,23 @@ extern "C" int jaco_set_option(JacoHandle* h, const char* name, double v) {
   else { h->err = std::string("jaco_set_option: unknown option ") + name; return JACO_EINVAL; }
   HIPCHK(h, hipDeviceSynchronize());
   return upload_model(h);
+}
+
+// Diagnostic build (-DJACO_PROFILE_STAGES) only: per-env per-stage shader-cycle sums; returns JACO_EINVAL otherwise.
+extern "C" int jaco_stage_profile(JacoHandle* h, uint64_t* out_host, int reset) {
+#ifdef JACO_PROFILE_STAGES
+  if (!h) return JACO_EINVAL;
+  size_t n = (size_t)h->num_envs * JPROF_N;
+  if (!h->prof) { HIPCHK(h, hipMalloc(&h->prof, n * 8)); HIPCHK(h, hipMemset(h->prof, 0, n * 8)); }
+  HIPCHK(h, hipDeviceSynchronize());
+  if (out_host) HIPCHK(h, hipMemcpy(out_host, h->prof, n * 8, hipMemcpyDeviceToHost));
+  if (reset) HIPCHK(h, hipMemset(h->prof, 0, n * 8));
+  return JACO_OK;
+#else
+  (void)out_host; (void)reset;
+  if (h) h->err = "jaco_stage_profile: library built without JACO_PROFILE_STAGES";
+  return JACO_EINVAL;
+#endif
 }
 
 extern "C" int jaco_enable_timing(JacoHandle* h, int enable) {

@@ -182,6 +182,7 @@ int jaco_model_from_blob(const void* buf, size_t size, JacoModelDev* m, std::vec
     P.g1 = g1; P.g2 = g2; P.condim = pd[k]; P.margin = (float)pmar[k];
     for (int i = 0; i < 5; i++) { P.mu[i] = (float)pmu[5 * k + i]; P.solimp[i] = (float)pimp[5 * k + i]; }
     P.solref[0] = (float)pref[2 * k]; P.solref[1] = (float)pref[2 * k + 1];
+    m->pair_code[k] = g1 | (g2 << 8) | (gty[g1] << 16) | (gty[g2] << 20);
   }
   // ---- touch sites
   const int32_t *sb = B.i32("f_site_body", ns), *sty = B.i32("f_site_type", ns), *sob = B.i32("f_site_origbody", ns);

@@ -17,9 +17,10 @@
 #include <jaco/model_dev.h>
 #include <jaco/wave_ops.h>
 
-#define JMAXCON 48    // contacts kept per env (overflow sets JFLAG_CON_OVERFLOW)
-#define JMAXEFC 128   // constraint rows per env (2 per lane)
-#define JMAXCAND 64   // narrowphase candidates per env
+#define JMAXCON 64    // contacts kept per env (overflow sets JFLAG_CON_OVERFLOW)
+#define JMAXEFC 256   // constraint rows per env (JNR row slots per lane)
+#define JNR (JMAXEFC / 64)
+#define JMAXCAND 128  // bounding-sphere survivors per env
 #define JLD (JNV)     // row stride of per-row dof vectors in LDS (21: odd, conflict-free for lane-per-row access)
 
 #define JFLAG_CON_OVERFLOW 1u
@@ -29,6 +30,22 @@
 #define JFLAG_SOLVER_MAXITER 16u
 
 #define JMINVAL 1e-15f
+
+// Diagnostic build only (-DJACO_PROFILE_STAGES): lane 0 accumulates shader-clock cycles per stage into
+// JacoStepArgs::prof[env][JPROF_N]. The shipped library is built without it (no stamp executes).
+#define JPROF_N 12
+#ifdef JACO_PROFILE_STAGES
+#define JSTAMP(i)                                                             \
+  do {                                                                        \
+    unsigned long long t_ = __builtin_amdgcn_s_memtime();                     \
+    if (lane == 0 && A.prof) A.prof[(size_t)env * JPROF_N + (i)] += t_ - tprev_; \
+    tprev_ = __builtin_amdgcn_s_memtime();                                    \
+  } while (0)
+#define JSTAMP_INIT unsigned long long tprev_ = __builtin_amdgcn_s_memtime();
+#else
+#define JSTAMP(i)
+#define JSTAMP_INIT
+#endif
 
 struct JacoStepArgs {
   const JacoModelDev* model;
@@ -41,6 +58,7 @@ struct JacoStepArgs {
   unsigned* flags;     // [nenv] sticky error bits
   int* stats;          // [nenv][4]: ncon, nefc, newton iterations, candidates (last substep) or nullptr
   int nenv, nsub, disable_contact;
+  unsigned long long* prof;  // diagnostic build only: [nenv][JPROF_N] cycle sums, else nullptr
   float* dbg;          // optional stage dump of env dbg_env (see JDBG_* offsets), else nullptr
   int dbg_env;
 };
@@ -77,7 +95,7 @@ struct JacoLDS {
   float J[JMAXEFC * JLD];
   float e_aref[JMAXEFC], e_D[JMAXEFC], e_f[JMAXEFC];
   int e_con[JMAXEFC];
-  int ncon, nefc, ncand;
+  int ncon, nefc, ncand, nlimit;
   float scratch[64];
 };
 
@@ -369,21 +387,24 @@ JDEV void stage_limit_rows(const JacoModelDev* m, JacoLDS& s, int lane) {
     s.e_aref[r] = row_params(m->b_solref[lane], m->b_solimp[lane], dist, sgn * s.qvel[d], m->d_invweight[d], &R);
     s.e_D[r] = 1.f / R;
   }
-  if (lane == 0) s.nefc = popc64(mask);
+  if (lane == 0) { s.nefc = popc64(mask); s.nlimit = s.nefc; }
 }
 
 // ---------------------------------------------------------------- stage S: primal Newton solver
 // Lane k < nv owns element k of every dof vector; lane r owns constraint rows r and r + 64.
 struct NewtonOut { float qacc, qfrc_con; int iters; };
 
-JDEV float row_dot(const float* Jrow, float vk, int nv) {  // sum_k Jrow[k] * v[k], v distributed one element per lane
-  float acc = 0.f;
+// out[q] = sum_k J[row(q)][k] * v[k] for the lane's JNR rows; v distributed one element per lane
+JDEV void rows_dot(const JacoLDS& s, float vk, int lane, int ne, int nv, float (&out)[JNR]) {
+  const float* Jr[JNR];
+#pragma unroll
+  for (int q = 0; q < JNR; q++) { int r = lane + 64 * q; Jr[q] = s.J + (r < ne ? r : 0) * JLD; out[q] = 0.f; }
 #pragma unroll
   for (int k = 0; k < JNV; k++) {
-    float vb = wave_bcast(vk, k);
-    acc += (k < nv ? Jrow[k] : 0.f) * vb;
+    float vb = k < nv ? wave_bcast(vk, k) : 0.f;
+#pragma unroll
+    for (int q = 0; q < JNR; q++) out[q] += Jr[q][k < nv ? k : 0] * vb;
   }
-  return acc;
 }
 JDEV float mat_vec(const float* M, float vk, int lane, int nv) {  // (M v)[lane]
   float acc = 0.f;
@@ -392,13 +413,18 @@ JDEV float mat_vec(const float* M, float vk, int lane, int nv) {  // (M v)[lane]
   for (int k = 0; k < JNV; k++) acc += row[k] * wave_bcast(vk, k);
   return lane < nv ? acc : 0.f;
 }
-// sum_r J[r][lane] * f_r with f distributed over (f0: rows 0..63, f1: rows 64..127)
-JDEV float jt_vec(const JacoLDS& s, float f0, float f1, int ne, int lane, int nv) {
+// sum_r J[r][lane] * f_r, f distributed over the row slots
+JDEV float jt_vec(const JacoLDS& s, const float (&f)[JNR], int ne, int lane, int nv) {
   float acc = 0.f;
   int kk = lane < nv ? lane : 0;
-  for (int r = 0; r < ne; r++) {
-    float fr = r < 64 ? wave_bcast(f0, r) : wave_bcast(f1, r - 64);
-    if (fr != 0.f) acc += s.J[r * JLD + kk] * fr;
+#pragma unroll
+  for (int q = 0; q < JNR; q++) {
+    int n = ne - 64 * q;
+    n = n > 64 ? 64 : n;
+    for (int rl = 0; rl < n; rl++) {
+      float fr = wave_bcast(f[q], rl);
+      if (fr != 0.f) acc += s.J[(64 * q + rl) * JLD + kk] * fr;
+    }
   }
   return lane < nv ? acc : 0.f;
 }
@@ -409,60 +435,83 @@ JDEV NewtonOut stage_newton(const JacoModelDev* m, JacoLDS& s, int lane) {
   float qas = lane < nv ? s.qacc_smooth[lane] : 0.f;
   out.qacc = qas; out.qfrc_con = 0.f; out.iters = 0;
   if (ne == 0) return out;
-  int r0 = lane, r1 = lane + 64;
-  bool v0 = r0 < ne, v1 = r1 < ne;
-  const float* J0 = s.J + (v0 ? r0 : 0) * JLD;
-  const float* J1 = s.J + (v1 ? r1 : 0) * JLD;
-  float D0 = v0 ? s.e_D[r0] : 0.f, D1 = v1 ? s.e_D[r1] : 0.f;
-  float ar0 = v0 ? s.e_aref[r0] : 0.f, ar1 = v1 ? s.e_aref[r1] : 0.f;
+  if (ne > JMAXEFC) ne = JMAXEFC;
+  bool valid[JNR];
+  float D[JNR], ar[JNR], x[JNR], xs[JNR], f[JNR], jp[JNR];
+#pragma unroll
+  for (int q = 0; q < JNR; q++) {
+    int r = lane + 64 * q;
+    valid[q] = r < ne;
+    D[q] = valid[q] ? s.e_D[r] : 0.f;
+    ar[q] = valid[q] ? s.e_aref[r] : 0.f;
+  }
   float scale = 1.f / (m->meaninertia * (float)(nv > 1 ? nv : 1));
   float tol = m->tolerance;
 
   // starting point: cheaper of warm start and unconstrained acceleration
+  // (cross-lane helpers are always called by all 64 lanes; validity is applied to their results)
   float a = lane < nv ? s.qacc_ws[lane] : 0.f;
   float Ma = mat_vec(s.M, a - qas, lane, nv);
-  // (cross-lane helpers are always called by all 64 lanes; validity is applied to their results)
-  float t0 = row_dot(J0, a, nv), t1 = row_dot(J1, a, nv);
-  float x0 = v0 ? t0 - ar0 : 0.f, x1 = v1 ? t1 - ar1 : 0.f;
-  t0 = row_dot(J0, qas, nv); t1 = row_dot(J1, qas, nv);
-  float xs0 = v0 ? t0 - ar0 : 0.f, xs1 = v1 ? t1 - ar1 : 0.f;
-  float cw = 0.5f * Ma * (a - qas) + (x0 < 0.f ? 0.5f * D0 * x0 * x0 : 0.f) + (x1 < 0.f ? 0.5f * D1 * x1 * x1 : 0.f);
-  float cs = (xs0 < 0.f ? 0.5f * D0 * xs0 * xs0 : 0.f) + (xs1 < 0.f ? 0.5f * D1 * xs1 * xs1 : 0.f);
+  rows_dot(s, a, lane, ne, nv, x);
+  rows_dot(s, qas, lane, ne, nv, xs);
+  float cw = 0.5f * Ma * (a - qas), cs = 0.f;
+#pragma unroll
+  for (int q = 0; q < JNR; q++) {
+    x[q] = valid[q] ? x[q] - ar[q] : 0.f;
+    xs[q] = valid[q] ? xs[q] - ar[q] : 0.f;
+    cw += x[q] < 0.f ? 0.5f * D[q] * x[q] * x[q] : 0.f;
+    cs += xs[q] < 0.f ? 0.5f * D[q] * xs[q] * xs[q] : 0.f;
+  }
   cw = wave_sum(cw);
   cs = wave_sum(cs);
-  if (!(cw < cs)) { a = qas; Ma = 0.f; x0 = xs0; x1 = xs1; }
-
+  if (!(cw < cs)) {
+    a = qas; Ma = 0.f;
+#pragma unroll
+    for (int q = 0; q < JNR; q++) x[q] = xs[q];
+  }
   int it = 0;
   for (; it < m->iterations; it++) {
-    float f0 = x0 < 0.f ? -D0 * x0 : 0.f, f1 = x1 < 0.f ? -D1 * x1 : 0.f;
-    float grad = Ma - jt_vec(s, f0, f1, ne, lane, nv);
+#pragma unroll
+    for (int q = 0; q < JNR; q++) f[q] = x[q] < 0.f ? -D[q] * x[q] : 0.f;
+    float jtf = jt_vec(s, f, ne, lane, nv);
+    float grad = Ma - jtf;
     float gn = sqrtf(wave_sum(grad * grad));
     if (gn * scale < tol) break;
     // Hessian rows: M + sum_active D_r J_r^T J_r
     float h[JNV];
     load_rows(h, s.M, nv, lane);
-    float w0 = x0 < 0.f ? D0 : 0.f, w1 = x1 < 0.f ? D1 : 0.f;
     int kk = lane < nv ? lane : 0;
-    for (int r = 0; r < ne; r++) {
-      float Dr = r < 64 ? wave_bcast(w0, r) : wave_bcast(w1, r - 64);
-      if (Dr == 0.f) continue;
-      const float* Jr = s.J + r * JLD;
-      float w = lane < nv ? Dr * Jr[kk] : 0.f;
 #pragma unroll
-      for (int j = 0; j < JNV; j++) h[j] += w * Jr[j];
+    for (int q = 0; q < JNR; q++) {
+      float w = x[q] < 0.f ? D[q] : 0.f;
+      int n = ne - 64 * q;
+      n = n > 64 ? 64 : n;
+      for (int rl = 0; rl < n; rl++) {
+        float Dr = wave_bcast(w, rl);
+        if (Dr == 0.f) continue;
+        const float* Jr = s.J + (64 * q + rl) * JLD;
+        float wj = lane < nv ? Dr * Jr[kk] : 0.f;
+#pragma unroll
+        for (int j = 0; j < JNV; j++) h[j] += wj * Jr[j];
+      }
     }
     float p = ldl_solve(h, -grad, lane);
     p = lane < nv ? p : 0.f;
     // exact line search on phi(al) = cost(a + al p)
     float Mp = mat_vec(s.M, p, lane, nv);
     float pMp = wave_sum(p * Mp), pMa = wave_sum(p * Ma);
-    float jp0 = row_dot(J0, p, nv), jp1 = row_dot(J1, p, nv);
-    jp0 = v0 ? jp0 : 0.f; jp1 = v1 ? jp1 : 0.f;
+    rows_dot(s, p, lane, ne, nv, jp);
+#pragma unroll
+    for (int q = 0; q < JNR; q++) jp[q] = valid[q] ? jp[q] : 0.f;
     float al = 0.f, lo = 0.f, hi = 3.0e38f, d10 = 0.f;
     for (int ls = 0; ls < m->ls_iterations; ls++) {
-      float xa0 = x0 + al * jp0, xa1 = x1 + al * jp1;
-      float s1 = (xa0 < 0.f ? D0 * xa0 * jp0 : 0.f) + (xa1 < 0.f ? D1 * xa1 * jp1 : 0.f);
-      float s2 = (xa0 < 0.f ? D0 * jp0 * jp0 : 0.f) + (xa1 < 0.f ? D1 * jp1 * jp1 : 0.f);
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int q = 0; q < JNR; q++) {
+        float xa = x[q] + al * jp[q];
+        s1 += xa < 0.f ? D[q] * xa * jp[q] : 0.f;
+        s2 += xa < 0.f ? D[q] * jp[q] * jp[q] : 0.f;
+      }
       float d1 = pMa + al * pMp + wave_sum(s1), d2 = pMp + wave_sum(s2);
       if (ls == 0) d10 = fabsf(d1);
       if (ls > 0 && fabsf(d1) <= 1e-6f * d10) break;
@@ -472,20 +521,27 @@ JDEV NewtonOut stage_newton(const JacoModelDev* m, JacoLDS& s, int lane) {
       if (nx == al) break;
       al = nx;
     }
-    // move; cost decrease evaluated along the line (no large-number cancellation)
-    float xn0 = x0 + al * jp0, xn1 = x1 + al * jp1;
-    float dc = (xn0 < 0.f ? 0.5f * D0 * xn0 * xn0 : 0.f) - (x0 < 0.f ? 0.5f * D0 * x0 * x0 : 0.f) +
-               (xn1 < 0.f ? 0.5f * D1 * xn1 * xn1 : 0.f) - (x1 < 0.f ? 0.5f * D1 * x1 * x1 : 0.f);
+    // move; the cost decrease is evaluated along the line in cancellation-free form so that MuJoCo's absolute
+    // tolerance stays meaningful in fp32 (the 1280 kg pedestal's cost terms are ~1e3, the object's ~1e-3)
+    float dc = 0.f;
+#pragma unroll
+    for (int q = 0; q < JNR; q++) {
+      float dx = al * jp[q], xn = x[q] + dx;
+      bool was = x[q] < 0.f, is = xn < 0.f;
+      dc += (was && is) ? 0.5f * D[q] * dx * (2.f * x[q] + dx) : (is ? 0.5f * D[q] * xn * xn : (was ? -0.5f * D[q] * x[q] * x[q] : 0.f));
+      x[q] = xn;
+    }
     float improvement = -(al * pMa + 0.5f * al * al * pMp + wave_sum(dc));
-    a += al * p; Ma += al * Mp; x0 = xn0; x1 = xn1;
+    a += al * p; Ma += al * Mp;
     if (improvement * scale < tol) { it++; break; }
   }
-  float f0 = x0 < 0.f ? -D0 * x0 : 0.f, f1 = x1 < 0.f ? -D1 * x1 : 0.f;
+#pragma unroll
+  for (int q = 0; q < JNR; q++) f[q] = x[q] < 0.f ? -D[q] * x[q] : 0.f;
   out.qacc = a;
-  out.qfrc_con = jt_vec(s, f0, f1, ne, lane, nv);
+  out.qfrc_con = jt_vec(s, f, ne, lane, nv);
   out.iters = it;
-  if (v0) s.e_f[r0] = f0;
-  if (v1) s.e_f[r1] = f1;
+#pragma unroll
+  for (int q = 0; q < JNR; q++) if (valid[q]) s.e_f[lane + 64 * q] = f[q];
   return out;
 }
 
@@ -518,13 +574,9 @@ JDEV void stage_integrate_pos(const JacoModelDev* m, JacoLDS& s, int lane) {
   }
 }
 
-// ---------------------------------------------------------------- the kernel
-#ifndef JACO_HAVE_COLLISION
-JDEV void stage_collision(const JacoStepArgs&, const JacoModelDev*, JacoLDS& s, int lane) { if (lane == 0) { s.ncon = 0; s.ncand = 0; } }
-JDEV void stage_contact_rows(const JacoModelDev*, JacoLDS&, int) {}
-JDEV void stage_touch(const JacoModelDev*, JacoLDS&, int, float* sens) { *sens = 0.f; }
-#endif
+#include "collision.h"
 
+// ---------------------------------------------------------------- the kernel
 __global__ __launch_bounds__(64) void jaco_physics_kernel(JacoStepArgs A) {
   __shared__ JacoLDS s;
   const int lane = lane_id(), env = env_id();
@@ -538,18 +590,22 @@ __global__ __launch_bounds__(64) void jaco_physics_kernel(JacoStepArgs A) {
   float sens = 0.f;
   int iters = 0;
   wave_sync();
+  JSTAMP_INIT
   for (int sub = 0; sub < A.nsub; sub++) {
     stage_walk(m, s, lane);
     for (int i = lane; i < JNV * JNV; i += 64) s.M[i] = 0.f;
     wave_sync();
+    JSTAMP(0);
     stage_geoms_inertia(m, s, lane);
     wave_sync();
+    JSTAMP(1);
     stage_accumulate(m, s, lane);
     wave_sync();
     stage_mass_bias(m, s, lane);
     wave_sync();
     stage_actuation(m, s, lane);
     wave_sync();
+    JSTAMP(2);
     float h[JNV];
     load_rows(h, s.M, nv, lane);
     float smooth = lane < nv ? s.smooth[lane] : 0.f;
@@ -557,21 +613,26 @@ __global__ __launch_bounds__(64) void jaco_physics_kernel(JacoStepArgs A) {
     if (lane < nv) s.qacc_smooth[lane] = qas;
     stage_limit_rows(m, s, lane);
     wave_sync();
+    JSTAMP(3);
     if (!A.disable_contact) {
-      stage_collision(A, m, s, lane);
+      stage_collision(A, m, s, lane, flags);
       wave_sync();
-      stage_contact_rows(m, s, lane);
+      JSTAMP(4);
+      stage_contact_rows(m, s, lane, flags);
       wave_sync();
+      JSTAMP(5);
     } else if (lane == 0) {
       s.ncon = 0; s.ncand = 0;
     }
     wave_sync();
     if (s.nefc > JMAXEFC) flags |= JFLAG_EFC_OVERFLOW;
     NewtonOut nw = stage_newton(m, s, lane);
+    JSTAMP(6);
     iters = nw.iters;
     if (iters >= m->iterations) flags |= JFLAG_SOLVER_MAXITER;
     wave_sync();
     stage_touch(m, s, lane, &sens);
+    JSTAMP(7);
     // Euler with implicit joint damping
     float total = smooth + nw.qfrc_con, qacc_e = nw.qacc;
     if (m->has_damping) {
@@ -614,6 +675,7 @@ __global__ __launch_bounds__(64) void jaco_physics_kernel(JacoStepArgs A) {
     wave_sync();
     stage_integrate_pos(m, s, lane);
     wave_sync();
+    JSTAMP(8);
   }
   if (lane < nq) A.qpos[(size_t)env * nq + lane] = s.qpos[lane];
   if (lane < nv) { A.qvel[(size_t)env * nv + lane] = s.qvel[lane]; A.qacc_ws[(size_t)env * nv + lane] = s.qacc_ws[lane]; }

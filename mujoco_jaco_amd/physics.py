@@ -72,6 +72,10 @@ class BatchedMujoco:
         self._chk(self.L.jaco_get_state(self.h, self._dev(qpos, self.nq), self._dev(qvel, self.nv), self._dev(qacc, self.nv), self._stream()))
         return qpos, qvel, qacc
 
+    def state_views(self):
+        """Copies of (qpos, qvel, qacc_warmstart) as [num_envs, n] tensors on the current stream."""
+        return self.get_state()
+
     def reset_state(self):
         self._chk(self.L.jaco_reset_state(self.h, self._stream()))
 

@@ -1,0 +1,31 @@
+"""Synthetic workloads shared by bench.py, the GPU tests and the probes.
+
+`reset_states` draws the reference's `picking` reset distribution (env_mujoco_util.py:177-180,
+:215-217, Appendix A of SURVEY.md): arm joint angles, fingers at qpos0, object on the holder,
+destination pedestal; `random_ctrl` draws ctrl = U(-1,1) * motor force range, fingers held at 0.6.
+"""
+import numpy as np
+
+
+def reset_states(qpos0, nenv, seed=0, contact=True):
+    rng = np.random.default_rng(seed)
+    nq = len(qpos0)
+    q = np.tile(np.asarray(qpos0, np.float64), (nenv, 1))
+    lo = np.array([0.7, 3.8, 1.0, 1.8, 1.0, 0.8]); hi = np.array([2.5, 4.0, 1.7, 2.5, 2.5, 2.3])
+    q[:, :6] = rng.uniform(lo, hi, (nenv, 6))
+    if nq >= 23:
+        q[:, 9] = rng.uniform(-0.1, 0.1, nenv)
+        q[:, 10] = 0.65 + rng.uniform(-0.08, 0.02, nenv)
+        q[:, 11] = 0.1898 if contact else 0.5
+        q[:, 12:16] = [1, 0, 0, 0]
+        q[:, 16] = 0.4 + rng.uniform(-0.05, 0.05, nenv)
+        q[:, 17] = 0.3 + rng.uniform(-0.05, 0.05, nenv)
+    return q
+
+
+def random_ctrl(nenv, seed=1, scale=1.0, grip=0.6):
+    rng = np.random.default_rng(seed)
+    c = np.zeros((nenv, 9))
+    c[:, :6] = rng.uniform(-1, 1, (nenv, 6)) * np.array([30, 30, 30, 15, 15, 15]) * scale
+    c[:, 6:] = grip
+    return c

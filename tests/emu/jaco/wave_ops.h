@@ -61,12 +61,14 @@ JDEV float wave_min(float v) { return -wave_max(-v); }
 JDEV int wave_argmax(float v, int idx, float* best) {
   int p = emu_post_f(v);
   emu_collective();
+  float vs[64];  // copy before the second post: a lane running ahead may reuse buffer p right after it
+  for (int l = 0; l < 64; l++) vs[l] = emu_x[p][l].f;
   int q = emu_post_i(idx);
   emu_collective();
-  float bv = emu_x[p][0].f;
+  float bv = vs[0];
   int bi = emu_x[q][0].i;
   for (int l = 1; l < 64; l++) {
-    float v2 = emu_x[p][l].f;
+    float v2 = vs[l];
     int i2 = emu_x[q][l].i;
     if (v2 > bv || (v2 == bv && i2 < bi)) { bv = v2; bi = i2; }
   }

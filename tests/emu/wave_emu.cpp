@@ -1,7 +1,10 @@
 // TEST INFRASTRUCTURE: lockstep wavefront emulator runtime (64 cooperative fibers, x86-64).
 #include <cstdio>
 #include <cstdlib>
+#include <execinfo.h>
 #include <functional>
+#include <signal.h>
+#include <unistd.h>
 
 #include <jaco/wave_ops.h>
 
@@ -23,8 +26,11 @@ static char* g_stack[64];
 static std::function<void()>* g_body;
 static int g_done;
 
-void emu_collective() {
+static void* g_site[64][2];
+__attribute__((noinline)) void emu_collective() {
   int prev = emu_cur_lane, next = (prev + 1) & 63;
+  g_site[prev][0] = __builtin_return_address(0);
+  g_site[prev][1] = __builtin_frame_address(0) ? __builtin_return_address(1) : nullptr;
   emu_cur_lane = next;
   emu_switch(&g_sp[prev], g_sp[next]);
 }
@@ -38,10 +44,27 @@ static void trampoline() {
     emu_cur_lane = (me + 1) & 63;
     emu_switch(&g_sp[me], g_sp[emu_cur_lane]);
   }
-  fprintf(stderr, "wave_emu: finished lane resumed (lanes diverged at a cross-lane op)\n");
+  fprintf(stderr, "wave_emu: finished lane %d resumed (lanes diverged at a cross-lane op)\n", me);
+  for (int l = 0; l < 64; l++) fprintf(stderr, "  lane %2d last collective at %p <- %p\n", l, g_site[l][0], g_site[l][1]);
   abort();
 }
+static void segv_handler(int) {
+  void* bt[32];
+  int n = backtrace(bt, 32);
+  fprintf(stderr, "wave_emu: SIGSEGV in lane %d, block %d\n", emu_cur_lane, emu_block);
+  backtrace_symbols_fd(bt, n, 2);
+  _exit(139);
+}
 void emu_run_wave(int block, std::function<void()> body) {
+  static bool installed = false;
+  if (!installed) {
+    static char altstack[1 << 16];
+    stack_t ss; ss.ss_sp = altstack; ss.ss_size = sizeof altstack; ss.ss_flags = 0;
+    sigaltstack(&ss, nullptr);
+    struct sigaction sa; sa.sa_handler = segv_handler; sigemptyset(&sa.sa_mask); sa.sa_flags = SA_ONSTACK;
+    sigaction(SIGSEGV, &sa, nullptr);
+    installed = true;
+  }
   g_body = &body;
   g_done = 0;
   emu_block = block;

@@ -5,12 +5,15 @@ against a lockstep 64-lane wavefront emulator, so kernel logic can be checked ag
 without a GPU.  Not a product path: the product library refuses to run without a HIP device.
 """
 import ctypes
+import sys
 import os
 import subprocess
 
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 EMU_DIR = os.path.join(ROOT, "tests", "emu")
 ASSETS = os.path.join(ROOT, "mujoco_jaco_amd", "assets")
 _lib = None

@@ -1,0 +1,30 @@
+"""Per-stage cycle profile of the physics kernel (diagnostic build libjaco_env_prof.so)."""
+import ctypes, os, sys, time
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
+os.environ["JACO_ENV_LIB"] = "libjaco_env_prof.so"
+import numpy as np, torch
+from mujoco_jaco_amd.physics import BatchedMujoco
+from mujoco_jaco_amd.modelc import blob
+from mujoco_jaco_amd import workload
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+nsub = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+M = blob.load(os.path.join(ROOT, "mujoco_jaco_amd", "assets", "jaco2_curtain_torque.jacomdl"))
+env = BatchedMujoco(B)
+q = torch.tensor(workload.reset_states(M["qpos0"], B), dtype=torch.float32, device=env.device)
+c = torch.tensor(workload.random_ctrl(B, scale=0.2), dtype=torch.float32, device=env.device)
+env.set_state(q, None, None)
+env.send_forces(c, nsub=100); torch.cuda.synchronize()   # settle initial interpenetration
+prof = np.zeros((B, 12), np.uint64)
+env._chk(env.L.jaco_stage_profile(env.h, prof.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), 1))
+t = time.time(); env.send_forces(c, nsub=nsub); torch.cuda.synchronize(); dt = time.time() - t
+env._chk(env.L.jaco_stage_profile(env.h, prof.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), 1))
+names = ["walk", "geoms+inertia", "accum+mass+act", "qacc_smooth+limits", "collision", "contact rows", "newton", "touch", "euler+integrate"]
+per = prof[:, :9].astype(np.float64) / nsub
+print("B", B, "nsub", nsub, "substeps/s %.3g" % (B * nsub / dt), "flags", int(env.flags().max()))
+st = env.stats().cpu().numpy()
+print("stats mean", st.mean(0), "max", st.max(0))
+tot = per.sum(1)
+for i, n in enumerate(names):
+    print("%-20s mean %9.0f cyc  (%4.1f%%)  p99 %9.0f" % (n, per[:, i].mean(), 100 * per[:, i].mean() / tot.mean(), np.percentile(per[:, i], 99)))
+print("total per substep: mean %.0f cycles, p50 %.0f, p99 %.0f, max %.0f" % (tot.mean(), np.median(tot), np.percentile(tot, 99), tot.max()))
