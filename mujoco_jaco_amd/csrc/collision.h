@@ -466,6 +466,49 @@ JDEV void stage_contact_rows(const JacoModelDev* m, JacoLDS& s, int lane, unsign
 }
 
 // ---------------------------------------------------------------- stage T: touch sensors (env_mujoco_util.py:470-475 reads them)
+// A contact counts when one of its geoms is on the site's own body and the ray from the contact point along the
+// normal, pointing away from that body, meets the site volume (always true for a point inside it).
+JDEV bool ray_hits_site(int type, float sx, float sy, float sz, v3 p, v3 d) {
+  // 10 um of slack: pad contacts routinely sit exactly on their site's lateral boundary (same footprint), where
+  // the inclusive test would be decided by rounding noise; the slack makes that case deterministic.
+  sx += 1e-5f; sy += 1e-5f; sz += 1e-5f;
+  float t0 = 0.f, t1 = 3.0e38f;
+  bool ok = true;
+  if (type == JG_BOX) {
+    float pp[3] = {p.x, p.y, p.z}, dd[3] = {d.x, d.y, d.z}, ss[3] = {sx, sy, sz};
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      if (fabsf(dd[i]) < JMINVAL) { ok = ok && !(fabsf(pp[i]) > ss[i]); continue; }
+      float a = (-ss[i] - pp[i]) / dd[i], b = (ss[i] - pp[i]) / dd[i];
+      t0 = fmaxf(t0, fminf(a, b));
+      t1 = fminf(t1, fmaxf(a, b));
+    }
+    return ok && t1 >= t0;
+  }
+  if (type == JG_CYLINDER) {
+    if (fabsf(d.z) < JMINVAL) ok = !(fabsf(p.z) > sy);
+    else {
+      float a = (-sy - p.z) / d.z, b = (sy - p.z) / d.z;
+      t0 = fmaxf(t0, fminf(a, b));
+      t1 = fminf(t1, fmaxf(a, b));
+    }
+    float A = d.x * d.x + d.y * d.y, B = p.x * d.x + p.y * d.y, C = p.x * p.x + p.y * p.y - sx * sx;
+    if (A < JMINVAL) ok = ok && !(C > 0.f);
+    else {
+      float disc = B * B - A * C;
+      if (disc < 0.f) return false;
+      float sq = sqrtf(disc);
+      t0 = fmaxf(t0, (-B - sq) / A);
+      t1 = fminf(t1, (-B + sq) / A);
+    }
+    return ok && t1 >= t0;
+  }
+  float A = dot(d, d), B = dot(p, d), C = dot(p, p) - sx * sx;
+  if (A < JMINVAL) return C <= 0.f;
+  float disc = B * B - A * C;
+  if (disc < 0.f) return false;
+  return (-B + sqrtf(disc)) / A >= 0.f;
+}
 JDEV void stage_touch(const JacoModelDev* m, JacoLDS& s, int lane, float* sens) {
   int ncon = s.ncon;
   if (lane < ncon) {
@@ -486,15 +529,13 @@ JDEV void stage_touch(const JacoModelDev* m, JacoLDS& s, int lane, float* sens) 
     float sx = m->s_size[lane][0], sy = m->s_size[lane][1], sz = m->s_size[lane][2];
     for (int c = 0; c < ncon; c++) {
       const JacoPairParam& P = m->pair[s.c_pair[c]];
-      if (m->g_origbody[P.g1] != ob && m->g_origbody[P.g2] != ob) continue;
+      bool on1 = m->g_origbody[P.g1] == ob, on2 = m->g_origbody[P.g2] == ob;
+      if (!on1 && !on2) continue;
       float fn = s.c_fn[c];
       if (!(fn > JMINVAL)) continue;
       v3 l = mulT(R, ld3(s.c_pos[c]) - p);
-      bool inside;
-      if (type == JG_BOX) inside = fabsf(l.x) <= sx && fabsf(l.y) <= sy && fabsf(l.z) <= sz;
-      else if (type == JG_CYLINDER) inside = l.x * l.x + l.y * l.y <= sx * sx && fabsf(l.z) <= sy;
-      else inside = dot(l, l) <= sx * sx;
-      if (inside) sum += fn;
+      v3 ray = mulT(R, ld3(s.c_frame[c]) * (on2 ? -1.f : 1.f));
+      if (ray_hits_site(type, sx, sy, sz, l, ray)) sum += fn;
     }
   }
   *sens = sum;

@@ -76,7 +76,9 @@ struct JacoStepArgs {
 #define JDBG_CONTACT (JDBG_NCON + 4)      // [JMAXCON][8]: dist, pos3, normal3, pair
 #define JDBG_EFC (JDBG_CONTACT + 8 * JMAXCON)  // [JMAXEFC][4]: aref, R, x(final jar), force
 #define JDBG_GPOS (JDBG_EFC + 4 * JMAXEFC)     // [JMAXGEOM][3]
-#define JDBG_SIZE (JDBG_GPOS + 3 * JMAXGEOM)
+#define JDBG_CFN (JDBG_GPOS + 3 * JMAXGEOM)      // [JMAXCON] per-contact normal force seen by the touch stage
+#define JDBG_SENS (JDBG_CFN + JMAXCON)         // [JNSENS] sensordata
+#define JDBG_SIZE (JDBG_SENS + JNSENS)
 
 struct JacoLDS {
   float qpos[24], qvel[24], qacc_ws[24], ctrl[12];
@@ -664,6 +666,8 @@ __global__ __launch_bounds__(64) void jaco_physics_kernel(JacoStepArgs A) {
         o[0] = s.e_aref[r]; o[1] = 1.f / s.e_D[r]; o[2] = 0.f; o[3] = s.e_f[r];
       }
       if (lane < m->ngeom) for (int k = 0; k < 3; k++) D[JDBG_GPOS + 3 * lane + k] = s.gpos[lane][k];
+      if (lane < s.ncon) D[JDBG_CFN + lane] = s.c_fn[lane];
+      if (lane < m->nsensor) D[JDBG_SENS + lane] = sens;
     }
     wave_sync();
     if (lane < nv) {

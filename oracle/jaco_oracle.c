@@ -1161,27 +1161,71 @@ static void solve_newton(const OrcModel* m, OrcData* d) {
 }
 
 /* ------------------------------------------------------------------ 8. touch sensors
- * (sensordata read by _get_touch, env_mujoco_util.py:470-475) */
+ * (sensordata read by _get_touch, env_mujoco_util.py:470-475).  A contact counts when one of its geoms
+ * is on the site's own body and the ray from the contact point along the normal, pointing away from
+ * that body, meets the site volume (always true for a point inside it) [EXT: MuJoCo sensor/touch]. */
+/* SITE_EPS: pad contacts routinely sit exactly on the lateral boundary of their site (the pad and its site have
+ * the same footprint and a pad face lying inside the object's face contributes its own corners), where the
+ * inclusive test is decided by rounding noise; 10 um of slack makes that case deterministic across precisions. */
+#define SITE_EPS 1e-5
+static int ray_hits_site(int type, const double* size, const double* p, const double* d) {
+  double sz[3] = {size[0] + SITE_EPS, size[1] + SITE_EPS, size[2] + SITE_EPS};
+  if (type == G_BOX) {
+    double t0 = 0, t1 = 1e300;
+    for (int i = 0; i < 3; i++) {
+      if (fabs(d[i]) < MINVAL) { if (fabs(p[i]) > sz[i]) return 0; continue; }
+      double a = (-sz[i] - p[i]) / d[i], b = (sz[i] - p[i]) / d[i];
+      if (a > b) { double t = a; a = b; b = t; }
+      if (a > t0) t0 = a;
+      if (b < t1) t1 = b;
+    }
+    return t1 >= t0;
+  }
+  if (type == G_CYLINDER) { /* radius sz[0], half height sz[1], axis z */
+    double t0 = 0, t1 = 1e300;
+    if (fabs(d[2]) < MINVAL) { if (fabs(p[2]) > sz[1]) return 0; }
+    else {
+      double a = (-sz[1] - p[2]) / d[2], b = (sz[1] - p[2]) / d[2];
+      if (a > b) { double t = a; a = b; b = t; }
+      if (a > t0) t0 = a;
+      if (b < t1) t1 = b;
+    }
+    double A = d[0] * d[0] + d[1] * d[1], B = p[0] * d[0] + p[1] * d[1], C = p[0] * p[0] + p[1] * p[1] - sz[0] * sz[0];
+    if (A < MINVAL) { if (C > 0) return 0; }
+    else {
+      double disc = B * B - A * C;
+      if (disc < 0) return 0;
+      double sq = sqrt(disc), a = (-B - sq) / A, b = (-B + sq) / A;
+      if (a > t0) t0 = a;
+      if (b < t1) t1 = b;
+    }
+    return t1 >= t0;
+  }
+  /* sphere */
+  double A = dot3(d, d), B = dot3(p, d), C = dot3(p, p) - sz[0] * sz[0];
+  if (A < MINVAL) return C <= 0;
+  double disc = B * B - A * C;
+  if (disc < 0) return 0;
+  return (-B + sqrt(disc)) / A >= 0;
+}
 static void touch_sensors(const OrcModel* m, OrcData* d) {
   for (int s = 0; s < m->nsensor; s++) {
     int site = m->sensor_siteid[s], sb = m->site_bodyid[site];
     double sum = 0;
     for (int c = 0; c < d->ncon; c++) {
       const Contact* con = d->contact + c;
-      if (m->geom_bodyid[con->geom1] != sb && m->geom_bodyid[con->geom2] != sb) continue;
+      int on1 = m->geom_bodyid[con->geom1] == sb, on2 = m->geom_bodyid[con->geom2] == sb;
+      if (!on1 && !on2) continue;
       int nrow = con->dim == 1 ? 1 : 2 * (con->dim - 1);
       double fn = 0;
       for (int e = 0; e < nrow; e++) fn += d->efc_force[con->efc_address + e];
       if (fn <= MINVAL) continue;
-      double rel[3], l[3];
+      double rel[3], l[3], ray[3], lr[3];
       sub3(rel, con->pos, d->site_xpos + 3 * site);
       mulmtv(l, d->site_xmat + 9 * site, rel);
-      const double* sz = m->site_size + 3 * site;
-      int inside;
-      if (m->site_type[site] == G_BOX) inside = fabs(l[0]) <= sz[0] && fabs(l[1]) <= sz[1] && fabs(l[2]) <= sz[2];
-      else if (m->site_type[site] == G_CYLINDER) inside = l[0] * l[0] + l[1] * l[1] <= sz[0] * sz[0] && fabs(l[2]) <= sz[1];
-      else inside = dot3(l, l) <= sz[0] * sz[0];
-      if (inside) sum += fn;
+      scl3(ray, con->frame, on2 ? -1.0 : 1.0);
+      mulmtv(lr, d->site_xmat + 9 * site, ray);
+      if (ray_hits_site(m->site_type[site], m->site_size + 3 * site, l, lr)) sum += fn;
     }
     d->sensordata[s] = sum;
   }

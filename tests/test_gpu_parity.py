@@ -1,0 +1,198 @@
+"""GPU tier: the HIP path (through the C ABI, libjaco_env.so) against the fp64 oracle on identical inputs.
+
+Tolerances (stated per BASELINE.json's "stated fp32 tolerance"):
+  * single step from identical state:  |dqpos| <= 2e-6, |dqvel| <= 2e-3 (finger dofs accelerate at ~1e3 rad/s^2)
+  * free-running over N substeps: bulk of the batch (median) <= 1e-5; contact-rich chaotic tails are reported,
+    not bounded (a reset draw can put the hand 5 cm inside the pedestal, see DESIGN.md "Parity")
+  * integer-like outputs (contact count, row count, flags) exact on the single-step check.
+Full-size (65 536 env) checks use size-independent properties: bitwise determinism, independence of an env from
+its batch neighbours, nsub composition, unit quaternions, finite state.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def _env(B, model="jaco2_curtain_torque"):
+    from mujoco_jaco_amd.physics import BatchedMujoco
+    return BatchedMujoco(B, robot_file=model)
+
+
+def _t(a, dev):
+    return torch.tensor(np.ascontiguousarray(a), dtype=torch.float32, device=dev)
+
+
+def _oracle_batch(model, q, v, w, c, nsub):
+    from oracle_binding import Oracle
+    o = Oracle(model)
+    q, v, w = q.copy(), v.copy(), w.copy()
+    o.step_batch(q, v, w, np.ascontiguousarray(c), nsub=nsub, nthreads=16)
+    return q, v, w
+
+
+def test_single_step_parity_reset_distribution(model_arrays):
+    from mujoco_jaco_amd import workload
+    B = 512
+    q = workload.reset_states(model_arrays["qpos0"], B, seed=21)
+    c = workload.random_ctrl(B, seed=22, scale=0.2)
+    # advance a few steps on the oracle first so velocities / warm starts are non-trivial
+    q, v, w = _oracle_batch("jaco2_curtain_torque", q, np.zeros((B, 21)), np.zeros((B, 21)), c, 12)
+    env = _env(B)
+    env.set_state(_t(q, env.device), _t(v, env.device), _t(w, env.device))
+    env.send_forces(_t(c, env.device), nsub=1)
+    gq, gv, _ = [t.cpu().numpy().astype(np.float64) for t in env.get_state()]
+    # oracle from the fp32-rounded state the GPU actually received
+    q32, v32, w32 = [a.astype(np.float32).astype(np.float64) for a in (q, v, w)]
+    qo, vo, _ = _oracle_batch("jaco2_curtain_torque", q32, v32, w32, c.astype(np.float32).astype(np.float64), 1)
+    eq, ev = np.abs(gq - qo).max(1), np.abs(gv - vo).max(1)
+    print("single step: qpos err median %.2e p90 %.2e p99 %.2e max %.2e" % (np.median(eq), *np.percentile(eq, [90, 99]), eq.max()))
+    # bulk: fp32 rounding.  The tail (few %) are envs whose hand starts inside the pedestal: >256 rows (buffer overflow,
+    # flagged) or hull contacts whose MPR portal path differs between fp32 and fp64 (DESIGN.md "Parity")
+    assert np.median(eq) <= 3e-7 and np.percentile(eq, 90) <= 2e-6, (np.median(eq), eq.max())
+    assert np.percentile(ev, 90) <= 2e-3
+    fl = env.flags().cpu().numpy()
+    clean = (fl & 3) == 0
+    assert np.percentile(eq[clean], 97) <= 1e-4
+    assert int(env.flags().max()) & 8 == 0
+
+
+def test_stage_dump_and_counts_match(model_arrays):
+    from mujoco_jaco_amd import workload
+    from oracle_binding import Oracle
+    B = 16
+    q = workload.reset_states(model_arrays["qpos0"], B, seed=31)
+    c = workload.random_ctrl(B, seed=32, scale=0.2)
+    # settle 12 steps on the oracle first: at the reset state itself the pedestal touches the floor with dist == 0
+    # exactly, where the presence of its 4 contacts is decided by the rounding of 0.09 + 0.07 - 0.16
+    q, v, w = _oracle_batch("jaco2_curtain_torque", q, np.zeros((B, 21)), np.zeros((B, 21)), c, 12)
+    f32 = lambda a: a.astype(np.float32).astype(np.float64)
+    env = _env(B)
+    o = Oracle()
+    for k in (0, 5, 11):
+        env.set_state(_t(q, env.device), _t(v, env.device), _t(w, env.device))
+        D = env.send_forces_debug(_t(c, env.device), k, nsub=1)
+        o.set("qpos", f32(q[k])); o.set("qvel", f32(v[k])); o.set("qacc_warmstart", f32(w[k])); o.set("ctrl", f32(c[k])); o.forward()
+        off = 33 + 99
+        Mo = o.get("qM").reshape(21, 21)
+        assert np.abs(D[off:off + 441].reshape(21, 21) - Mo).max() <= 1e-6 * np.abs(Mo).max()
+        off += 441 + 5 * 24
+        assert (int(D[off]), int(D[off + 1])) == (o.ncon, o.nefc)         # contact / row counts: exact
+        nc = o.ncon
+        C = D[off + 4:off + 4 + 8 * nc].reshape(nc, 8); oc = o.get("contact").reshape(-1, 11)
+        box = oc[:, 9] == 3                                               # analytic (plane / box) contacts; hull contacts: see DESIGN.md
+        assert np.abs(C[box, 0] - oc[box, 0]).max() < 1e-6 and np.abs(C[box, 1:4] - oc[box, 1:4]).max() < 1e-6
+        assert np.abs(C[box, 4:7] - oc[box, 4:7]).max() < 1e-5
+
+
+def test_free_running_drift_bulk(model_arrays):
+    from mujoco_jaco_amd import workload
+    B, nsub = 256, 200
+    q = workload.reset_states(model_arrays["qpos0"], B, seed=41)
+    c = workload.random_ctrl(B, seed=42, scale=0.2)
+    env = _env(B)
+    env.set_state(_t(q, env.device), None, None)
+    env.send_forces(_t(c, env.device), nsub=nsub)
+    gq = env.get_state()[0].cpu().numpy().astype(np.float64)
+    qo, _, _ = _oracle_batch("jaco2_curtain_torque", q.astype(np.float32).astype(np.float64), np.zeros((B, 21)), np.zeros((B, 21)),
+                             c.astype(np.float32).astype(np.float64), nsub)
+    err = np.abs(gq - qo).max(1)
+    print("drift after %d substeps: median %.2e p90 %.2e p99 %.2e max %.2e" % (nsub, np.median(err), *np.percentile(err, [90, 99]), err.max()))
+    assert np.median(err) <= 1e-5
+    assert np.mean(err <= 1e-4) >= 0.85
+
+
+def test_arm_only_config2_4096_envs():
+    """BASELINE config 2: 4 096 envs, arm-only model (jaco2_reaching_torque), no contacts."""
+    from mujoco_jaco_amd import workload
+    from mujoco_jaco_amd.modelc import blob
+    from mujoco_jaco_amd import _lib
+    M = blob.load(_lib.model_path("jaco2_reaching_torque"))
+    B, nsub = 4096, 100
+    q = workload.reset_states(M["qpos0"], B, seed=51)
+    c = workload.random_ctrl(B, seed=52)
+    env = _env(B, "jaco2_reaching_torque")
+    env.set_option("disable_contact", 1)
+    env.set_state(_t(q, env.device), None, None)
+    env.send_forces(_t(c, env.device), nsub=nsub)
+    gq = env.get_state()[0].cpu().numpy().astype(np.float64)
+    sub = slice(0, 256)
+    from oracle_binding import Oracle
+    o = Oracle("jaco2_reaching_torque"); o.option("disable_contact", 1)
+    qo = q[sub].astype(np.float32).astype(np.float64); vo = np.zeros((256, 9)); wo = np.zeros((256, 9))
+    o.step_batch(qo, vo, wo, np.ascontiguousarray(c[sub].astype(np.float32).astype(np.float64)), nsub=nsub, nthreads=16)
+    err = np.abs(gq[sub] - qo).max(1)
+    assert np.percentile(err, 99) <= 1e-4 and np.median(err) <= 2e-5, (np.median(err), err.max())
+
+
+def test_full_size_properties_65536(model_arrays):
+    from mujoco_jaco_amd import workload
+    B = 65536
+    q = workload.reset_states(model_arrays["qpos0"], B, seed=61)
+    c = workload.random_ctrl(B, seed=62, scale=0.2)
+    env = _env(B)
+    dev = env.device
+    tq, tc = _t(q, dev), _t(c, dev)
+    z = torch.zeros(B, 21, device=dev)
+
+    def run(nsubs):
+        env.set_state(tq, z, z)
+        for n in nsubs:
+            env.send_forces(tc, nsub=n)
+        return [t.clone() for t in env.get_state()]
+    a = run([8])
+    b = run([8])
+    assert all(torch.equal(x, y) for x, y in zip(a, b))                       # bitwise deterministic
+    d = run([3, 5])
+    assert all(torch.equal(x, y) for x, y in zip(a, d))                       # nsub composes exactly
+    # an env's result does not depend on its neighbours: run a 4096-env slice alone
+    sl = slice(30000, 34096)
+    small = _env(4096)
+    small.set_state(tq[sl].contiguous(), z[sl].contiguous(), z[sl].contiguous())
+    small.send_forces(tc[sl].contiguous(), nsub=8)
+    s = small.get_state()
+    assert torch.equal(s[0], a[0][sl]) and torch.equal(s[1], a[1][sl])
+    qq = a[0]
+    assert torch.isfinite(qq).all() and torch.isfinite(a[1]).all()
+    for adr in (12, 19):
+        assert (qq[:, adr:adr + 4].norm(dim=1) - 1).abs().max() < 1e-5       # free-joint quaternions stay unit
+    assert int(env.flags().max()) & 8 == 0                                     # no NaN flag
+
+
+def test_touch_sensors_in_grasp(model_arrays, names):
+    """In-hand object (placing-style reset): sensordata of the HIP path vs oracle, and the touch class derived from it."""
+    from mujoco_jaco_amd.modelc import rot
+    from oracle_binding import Oracle
+    o = Oracle()
+    q = model_arrays["qpos0"].copy()
+    q[:6] = [1.3, 3.85, 1.05, 2.05, 1.5, -1.15]; q[6:9] = 0.6; q[16:18] = [.4, .3]
+    o.set("qpos", q); o.forward()
+    b = names["body"].index("EE_obj")
+    xp = o.get("xpos").reshape(-1, 3)[b]; xq = o.get("xquat").reshape(-1, 4)[b]
+    q[9:12] = xp + rot.quat_to_mat(xq) @ np.array([-0.04, 0, 0]); q[12:16] = xq
+    B = 64
+    env = _env(B)
+    C = np.tile(np.array([0, 0, 0, 0, 0, 0, .8, .8, .8]), (B, 1))
+    o.reset(); o.set("qpos", q.astype(np.float32).astype(np.float64))
+    f32 = lambda a: a.astype(np.float32).astype(np.float64)
+    nmatch, nclass = 0, 0
+
+    def touch_class(t):   # env_mujoco_util.py:470-490 with sensordata order EE_touch, 0_touch ... 18_touch
+        a = np.concatenate([t[1:20], t[0:1]]) > 0.001
+        thumb, index, pinky = a[1:5].any(), a[5:9].any(), a[9:13].any()
+        return 3 if (thumb and index) or (thumb and pinky) else (1 if a[:13].any() else (2 if a[13:].any() else 0))
+    for i in range(30):
+        st = [f32(o.get(n)) for n in ("qpos", "qvel", "qacc_warmstart")]          # re-synchronise: single-step comparison
+        for n, x in zip(("qpos", "qvel", "qacc_warmstart"), st):
+            o.set(n, x)
+        env.set_state(*[_t(np.tile(x, (B, 1)), env.device) for x in st])
+        env.send_forces(_t(C, env.device), nsub=1)
+        o.step(C[0])
+        s = env.sensordata().cpu().numpy()
+        assert np.array_equal(s[0], s[-1])                                     # identical envs -> identical bits
+        so = o.get("sensordata")
+        nmatch += int(np.abs(s[0] - so).max() <= 2e-2 * max(1.0, so.max()))
+        nclass += int(touch_class(s[0]) == touch_class(so))
+    assert nmatch >= 24 and nclass >= 27   # hull contacts can differ for single steps (MPR path, DESIGN.md "Parity")

@@ -1,0 +1,92 @@
+"""CPU tier: the *unmodified* HIP kernel source, compiled for the host against the lockstep 64-lane wavefront
+emulator (tests/emu), checked against the fp64 oracle.  This is development/test infrastructure: the product
+library has no CPU path.  Tolerances are fp32-vs-fp64 single-step bounds (state re-synchronised every step);
+free-running drift is measured on the GPU tier.
+"""
+import numpy as np
+import pytest
+
+from emu_binding import EmuEnv
+from mujoco_jaco_amd import workload
+from oracle_binding import Oracle
+
+
+def _sync_step(o, e, ctrl, **kw):
+    st = [o.get(n) for n in ("qpos", "qvel", "qacc_warmstart")]
+    e.qpos[0], e.qvel[0], e.qacc_ws[0] = st
+    e.step(ctrl, **kw)
+    o.step(ctrl)
+    return np.abs(o.get("qpos") - e.qpos[0]).max(), np.abs(o.get("qvel") - e.qvel[0]).max()
+
+
+def test_smooth_dynamics_single_step(model_arrays):
+    o = Oracle(); o.option("disable_contact", 1)
+    e = EmuEnv()
+    rng = np.random.default_rng(0)
+    for _ in range(4):
+        q = model_arrays["qpos0"].copy(); q[:9] += rng.uniform(-1, 1, 9) * 0.5
+        q[9:12] = [0, .65, .5]; q[12:16] = rng.normal(size=4); q[12:16] /= np.linalg.norm(q[12:16]); q[16:19] = [.4, .3, .6]
+        o.set("qpos", q); o.set("qvel", rng.normal(size=21) * 0.3); o.set("qacc_warmstart", np.zeros(21))
+        ctrl = np.concatenate([rng.uniform(-1, 1, 6) * 5, rng.uniform(0, 1.5, 3)])
+        eq, ev = _sync_step(o, e, ctrl, disable_contact=True)
+        assert eq < 1e-6 and ev < 1e-3   # qvel: finger dofs have 1e-5 kg m^2 inertia, accelerations ~1e3 rad/s^2
+
+
+def test_contact_pipeline_matches_oracle_on_reset_distribution(model_arrays):
+    o = Oracle(); e = EmuEnv()
+    q = workload.reset_states(model_arrays["qpos0"], 6, seed=11)
+    c = workload.random_ctrl(6, seed=12, scale=0.2)
+    worst = 0.0
+    for k in range(6):
+        o.reset(); o.set("qpos", q[k])
+        for i in range(25):
+            eq, ev = _sync_step(o, e, c[k])
+            assert (e.stats[0, 0], e.stats[0, 1]) == (o.ncon, o.nefc), (k, i)   # same contacts, same rows
+            worst = max(worst, eq)
+    assert worst < 2e-6 and e.flags[0] == 0
+
+
+def test_in_hand_grasp_with_hull_contacts(model_arrays, names):
+    """Placing-style reset (env_mujoco_util.py:106-117): object put between the fingers -> ~45 contacts / 230 rows,
+    condim-6 hull contacts through MPR, touch sensors."""
+    from mujoco_jaco_amd.modelc import rot
+    o = Oracle(); e = EmuEnv()
+    q = model_arrays["qpos0"].copy()
+    q[:6] = [1.3, 3.85, 1.05, 2.05, 1.5, -1.15]; q[6:9] = 0.6; q[16:18] = [.4, .3]
+    o.set("qpos", q); o.forward()
+    b = names["body"].index("EE_obj")
+    xp = o.get("xpos").reshape(-1, 3)[b]; xq = o.get("xquat").reshape(-1, 4)[b]
+    q[9:12] = xp + rot.quat_to_mat(xq) @ np.array([-0.04, 0, 0]); q[12:16] = xq
+    o.set("qpos", q)
+    errs, sens = [], []
+    for i in range(60):
+        g = min(1.0, 0.6 + 0.004 * i)
+        eq, _ = _sync_step(o, e, np.array([0, 0, 0, 0, 0, 0, g, g, g]))
+        errs.append(eq)
+        if (e.stats[0, 0], e.stats[0, 1]) == (o.ncon, o.nefc):
+            sens.append(np.abs(o.get("sensordata") - e.sensordata[0]).max() / max(1.0, o.get("sensordata").max()))
+    assert max(o.ncon, 0) >= 0 and e.flags[0] == 0
+    assert np.median(errs) < 1e-6 and max(errs) < 2e-4      # a grazing contact may flip for one step
+    assert np.median(sens) < 1e-3
+
+
+def test_arm_only_model_config2():
+    o = Oracle("jaco2_reaching_torque"); o.option("disable_contact", 1)
+    e = EmuEnv("jaco2_reaching_torque")
+    assert (e.nq, e.nv) == (9, 9)
+    rng = np.random.default_rng(3)
+    q = e.M["qpos0"].copy(); q[:6] = [1.5, 3.9, 1.3, 2.0, 2.0, 1.5]
+    o.set("qpos", q)
+    for i in range(20):
+        eq, ev = _sync_step(o, e, np.concatenate([rng.uniform(-1, 1, 6) * [30, 30, 30, 15, 15, 15], [0.6] * 3]), disable_contact=True)
+        assert eq < 1e-6
+
+
+def test_bitwise_deterministic(model_arrays):
+    q = workload.reset_states(model_arrays["qpos0"], 1, seed=5)[0]
+    out = []
+    for _ in range(2):
+        e = EmuEnv(); e.qpos[0] = q
+        e.step(workload.random_ctrl(1, seed=6)[0], nsub=5)
+        out.append((e.qpos.copy(), e.qvel.copy()))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])

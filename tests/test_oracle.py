@@ -1,0 +1,179 @@
+"""CPU tier: the fp64 oracle against analytic known answers and an independent numpy formulation.
+
+The reference has no tests and its physics lives in an absent closed-source binary (SURVEY.md 8c:
+"parity unpinned"), so the oracle is pinned by first principles instead: closed-form solutions,
+conservation laws, two independent algorithms reaching the same optimum, and the dumbest possible
+numpy restatement of the kinematics / mass matrix (mujoco_jaco_amd/modelc/kin.py).
+"""
+import numpy as np
+import pytest
+
+from oracle_binding import Oracle
+
+
+def _rand_state(M, rng):
+    q = M["qpos0"].copy()
+    q[:9] += rng.uniform(-1, 1, 9) * 0.5
+    q[9:12] = [0.0, 0.65, 0.8]
+    q[12:16] = rng.normal(size=4)
+    q[16:19] = [0.4, 0.3, 0.9]
+    q[19:23] = rng.normal(size=4)
+    return q, rng.normal(size=21) * 0.3
+
+
+def test_model_sizes_match_survey(model_arrays):
+    M = model_arrays  # nq 23, nv 21, nu 9, 56 bodies, 66 geoms, 20 touch sensors
+    assert (M["nq"][0], M["nv"][0], M["nu"][0], M["nbody"][0], M["ngeom"][0], M["nsensor"][0]) == (23, 21, 9, 56, 66, 20)
+    assert M["nmocap"][0] == 15 and M["f_nbody"][0] == 11
+    # hull sizes measured in the survey (finger_distal 340 ... link0 1511)
+    assert sorted(M["mesh_vertnum"].tolist()) == sorted([1511, 914, 1226, 809, 555, 754, 340, 295, 152, 152])
+    assert abs(M["f_mass"][9] - 0.0175) < 1e-4 and abs(M["f_mass"][10] - 1280.0) < 1e-6  # object, pedestal
+
+
+def test_kinematics_and_mass_matrix_vs_numpy(model_arrays):
+    from mujoco_jaco_amd.modelc import kin
+    rng = np.random.default_rng(0)
+    o = Oracle()
+    for _ in range(3):
+        q, v = _rand_state(model_arrays, rng)
+        o.set("qpos", q); o.set("qvel", v); o.forward()
+        H, _ = kin.mass_matrix(model_arrays, q)
+        xp, xq, _, _ = kin.fk(model_arrays, q)
+        assert np.abs(o.get("xpos").reshape(-1, 3) - xp).max() < 1e-12
+        assert np.abs(o.get("qM").reshape(21, 21) - H).max() < 1e-9
+
+
+def test_free_fall_closed_form():
+    o = Oracle(); o.option("disable_contact", 1)
+    q = o.get("qpos"); q[9:12] = [0, 0, 5.0]; o.set("qpos", q)
+    n, h = 500, 0.001
+    o.step(np.zeros(9), n=n)
+    # semi-implicit Euler: v_n = -g n h, z_n = z0 - g h^2 n(n+1)/2
+    assert abs(o.get("qvel")[11] + 9.81 * n * h) < 1e-10
+    assert abs(o.get("qpos")[11] - (5.0 - 9.81 * h * h * n * (n + 1) / 2)) < 1e-9
+
+
+def test_bias_is_gravity_torque_at_rest(model_arrays):
+    """With qvel = 0, qfrc_bias must equal -dU/dq (finite difference of the potential energy)."""
+    from mujoco_jaco_amd.modelc import kin, rot
+    M = model_arrays
+    rng = np.random.default_rng(1)
+    q, _ = _rand_state(M, rng)
+    o = Oracle(); o.set("qpos", q); o.set("qvel", np.zeros(21)); o.forward()
+    bias = o.get("qfrc_bias")
+
+    def U(qq):
+        xp, xq, _, _ = kin.fk(M, qq)
+        u = 0.0
+        for b in range(1, int(M["nbody"][0])):
+            com = xp[b] + rot.rot_vec(xq[b], M["body_ipos"][3 * b:3 * b + 3])
+            u += M["body_mass"][b] * 9.81 * com[2]
+        return u
+    for d in range(9):  # hinge dofs: qpos index == dof index
+        e = np.zeros(23); e[d] = 1e-6
+        assert abs((U(q + e) - U(q - e)) / 2e-6 - bias[d]) < 1e-5 * max(1, abs(bias[d]))
+
+
+def test_energy_conserved_without_dissipation():
+    """Torque-free, contact-free, gravity on: total energy drift of the arm stays at integrator order."""
+    from mujoco_jaco_amd.modelc import blob  # noqa: F401
+    o = Oracle(); o.option("disable_contact", 1); o.option("timestep", 1e-4)
+    q = o.get("qpos"); q[:6] = [1.5, 3.9, 1.3, 2.0, 2.0, 1.5]; q[6:9] = 0.8
+    o.set("qpos", q)
+
+    def energy():
+        o.forward()
+        v = o.get("qvel"); Mq = o.get("qM").reshape(21, 21)
+        xi = o.get("xipos").reshape(-1, 3)
+        return 0.5 * v[:9] @ Mq[:9, :9] @ v[:9], xi
+    # potential from body masses (arm subtree only: bodies with z-dependence through the arm dofs)
+    import os
+    from mujoco_jaco_amd.modelc import blob as B
+    M = B.load(os.path.join(os.path.dirname(__file__), "..", "mujoco_jaco_amd", "assets", "jaco2_curtain_torque.jacomdl"))
+    arm = [b for b in range(int(M["nbody"][0])) if 15 <= b <= 50]
+
+    def total():
+        k, xi = energy()
+        return k + sum(M["body_mass"][b] * 9.81 * xi[b, 2] for b in arm)
+    # fingers have damping 0.15 and position servos: hold them with the servo at their angle, measure the arm only
+    e0 = total()
+    ctrl = np.zeros(9); ctrl[6:] = 0.8
+    o.step(ctrl, n=2000)
+    e1 = total()
+    assert abs(e1 - e0) < 2e-3 * abs(e0) + 1e-3, (e0, e1)
+
+
+def test_newton_and_pgs_reach_the_same_optimum():
+    """Two unrelated algorithms (primal Newton, dual PGS run to convergence) on the same soft-contact QP."""
+    o = Oracle()
+    p = Oracle(); p.option("solver", 0); p.option("iterations", 200000); p.option("tolerance", 1e-30)
+    q = o.get("qpos"); q[:6] = [1.5, 3.9, 1.3, 2.0, 2.0, 1.5]; q[9:12] = [0, .65, .1898]
+    o.set("qpos", q)
+    ctrl = np.array([0, 0, 0, 0, 0, 0, .6, .6, .6])
+    for s in range(120):
+        if s in (0, 60, 119):
+            for nm in ("qpos", "qvel", "qacc_warmstart"):
+                p.set(nm, o.get(nm))
+            p.set("ctrl", ctrl); p.forward()
+            st = [o.get(nm) for nm in ("qpos", "qvel", "qacc_warmstart")]
+            o.set("ctrl", ctrl); o.forward()
+            assert o.nefc == p.nefc and o.nefc >= 16
+            assert np.abs(o.get("qacc") - p.get("qacc")).max() < 1e-7 * max(1.0, np.abs(o.get("qacc")).max())
+            for nm, v in zip(("qpos", "qvel", "qacc_warmstart"), st):
+                o.set(nm, v)
+        o.step(ctrl)
+
+
+def test_resting_contact_forces_carry_the_weight():
+    o = Oracle()
+    q = o.get("qpos"); q[9:12] = [0, .65, .2]; o.set("qpos", q)   # object resting on the holder (top at z = 0.17)
+    o.step(np.array([0, 0, 0, 0, 0, 0, .6, .6, .6]), n=1500)
+    o.forward()
+    c = o.get("contact").reshape(-1, 11)
+    f = o.get("efc_force")
+    ped = [i for i in range(len(c)) if abs(c[i, 3]) < 0.01]        # pedestal corners on the floor (z ~ 0)
+    obj = [i for i in range(len(c)) if abs(c[i, 3] - 0.17) < 0.01]  # object corners on the holder
+    assert len(ped) == 4 and len(obj) == 4
+    fsum = lambda idx: sum(f[int(c[i, 10]):int(c[i, 10]) + 4].sum() for i in idx)
+    assert abs(fsum(ped) - 1280 * 9.81) < 1e-3 * 1280 * 9.81        # pyramid edge forces sum to the normal force
+    assert abs(fsum(obj) - 0.017496 * 9.81) < 2e-3 * 0.017496 * 9.81
+    assert abs(o.get("qpos")[11] - 0.2) < 1e-3 and np.abs(o.get("qvel")[9:15]).max() < 1e-3
+
+
+def test_joint_limit_holds_finger():
+    o = Oracle(); o.option("disable_contact", 1)
+    q = o.get("qpos"); q[:6] = [1.5, 3.9, 1.3, 2.0, 2.0, 1.5]; q[6:9] = [0.05, 0.7, 1.45]; q[9:12] = [0, 0, 50]; q[16:19] = [5, 5, 50]
+    o.set("qpos", q)
+    o.step(np.array([0, 0, 0, 0, 0, 0, 0.0, 0.7, 1.51]), n=400)
+    qq = o.get("qpos")
+    assert -2e-3 < qq[6] < 1e-3 and abs(qq[7] - 0.7) < 0.02 and qq[8] < 1.51 + 2e-3
+
+
+def test_touch_sensor_uses_the_normal_ray(names, model_arrays):
+    """Box pressed into the open hand: every pad contact that carries force must show up on that pad's sensor even
+    though its contact point lies outside the site volume (the sites float 0.5-1.5 mm above the pads, contact points
+    sit half a penetration depth below the surface): MuJoCo's touch sensor re-projects along the contact normal."""
+    from mujoco_jaco_amd.modelc import rot
+    M = model_arrays
+    o = Oracle()
+    q = o.get("qpos"); q[:6] = [1.5, 3.9, 1.3, 2.0, 2.0, 1.5]; q[6:9] = 1.4   # fingers open
+    o.set("qpos", q); o.forward()
+    b = names["body"].index("palm_plane")
+    xp = o.get("xpos").reshape(-1, 3)[b]; xq = o.get("xquat").reshape(-1, 4)[b]
+    q[9:12] = xp + rot.quat_to_mat(xq) @ np.array([0, 0, 0.029]); q[12:16] = xq   # box (half height 0.03) 1.5 mm into the palm pad
+    o.set("qpos", q); o.forward()
+    s = o.get("sensordata"); c = o.get("contact").reshape(-1, 11); f = o.get("efc_force")
+    sx = o.get("site_xpos").reshape(-1, 3); sm = o.get("site_xmat").reshape(-1, 3, 3)
+    checked = 0
+    for r in c:
+        fn = f[int(r[10]):int(r[10]) + 2 * (int(r[9]) - 1)].sum()
+        for g in (int(r[7]), int(r[8])):
+            body = M["geom_bodyid"][g]
+            for k, site in enumerate(M["sensor_siteid"]):
+                if M["site_bodyid"][site] != body or fn <= 1e-9 or M["site_type"][site] != 6:
+                    continue
+                local = sm[site].T @ (r[1:4] - sx[site])
+                inside = np.all(np.abs(local) <= M["site_size"][3 * site:3 * site + 3])
+                assert s[k] >= fn * (1 - 1e-9)          # counted
+                checked += int(not inside)               # ... although the point is outside the site box
+    assert checked >= 1 and np.all(s[14:20] == 0)        # inner pads fire, outer pads do not
