@@ -129,7 +129,8 @@ def main():
                                    % (B, args.model),
                        "envs_per_gpu": B, "frame_skip": fs, "substeps_per_s": world * B * args.steps * fs / dt,
                        "sharding": "independent env shards per rank" + ("; one all_gather of [B,%d] f32 rows per step" % env.nq if world > 1 else ""),
-                       "mean_contacts": float(stats[0]), "mean_rows": float(stats[1]), "mean_newton_iters": float(stats[2]), "flags_or": flags},
+                       "mean_contacts": float(stats[0]), "mean_rows": float(stats[1]), "mean_newton_iters": float(stats[2]), "flags_or": flags,
+                       "heavy_tier_fraction": float(((env.flags() & 32) != 0).float().mean().item())},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "kernel": "jaco_physics_kernel", "kernel_ms": kern_ms, "launches": launches,
                          "algorithmic_bytes_per_env_launch": bytes_per_env,

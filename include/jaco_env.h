@@ -36,6 +36,7 @@ extern "C" {
 #define JACO_FLAG_CAND_OVERFLOW 4u  /* more broadphase survivors than the candidate buffer */
 #define JACO_FLAG_NAN 8u            /* non-finite velocity: env should be reset */
 #define JACO_FLAG_SOLVER_MAXITER 16u
+#define JACO_FLAG_HEAVY_TIER 32u     /* informational: stepped by the 256-row tier at least once (not an error) */
 
 /* task ids (env_script/env_mujoco.py:18-23; only picking/placing return the 4-tuple step() unpacks) */
 #define JACO_TASK_PICKING 0

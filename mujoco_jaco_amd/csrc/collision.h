@@ -10,7 +10,8 @@
 #define JACO_HAVE_COLLISION 1
 
 struct GeomPose { v3 p; m3 R; };
-JDEV GeomPose geom_pose(const JacoLDS& s, int g) { GeomPose r; r.p = ld3(s.gpos[g]); r.R = ldm(s.gmat[g]); return r; }
+template <class L>
+JDEV GeomPose geom_pose(const L& s, int g) { GeomPose r; r.p = ld3(s.gpos[g]); r.R = ldm(s.gmat[g]); return r; }
 
 // conservative oriented-box separation test (cull only: may say "not separated" for separated boxes, never the reverse)
 JDEV bool obb_separated(const GeomPose& a, v3 sa, const GeomPose& b, v3 sb) {
@@ -48,24 +49,27 @@ JDEV void make_frame(v3 n, float* fr) {
 }
 
 // Append contacts held by lanes with `have` set (lane order), all lanes must call.
-JDEV void push_contacts(JacoLDS& s, bool have, float dist, v3 pos, v3 normal, int pair, int& ncon, unsigned& flags, int limit) {
+template <class L>
+JDEV void push_contacts(L& s, bool have, float dist, v3 pos, v3 normal, int pair, int& ncon, unsigned& flags, int limit) {
+  constexpr int MAXCON = L::Caps::MAXCON;
   unsigned long long mask = wave_ballot(have);
   int idx = wave_prefix_count(mask), n = popc64(mask);
   if (n > limit) n = limit;
   bool keep = have && idx < limit;
-  if (keep && ncon + idx < JMAXCON) {
+  if (keep && ncon + idx < MAXCON) {
     int c = ncon + idx;
     s.c_dist[c] = dist;
     st3(s.c_pos[c], pos);
     make_frame(normal, s.c_frame[c]);
     s.c_pair[c] = pair;
   }
-  if (ncon + n > JMAXCON) { flags |= JFLAG_CON_OVERFLOW; n = JMAXCON - ncon; }
+  if (ncon + n > MAXCON) { flags |= JFLAG_CON_OVERFLOW; n = MAXCON - ncon; }
   ncon += n;
 }
 
 // ---------------------------------------------------------------- support functions (all lanes, wave-uniform direction)
-JDEV v3 support_geom(const JacoStepArgs& A, const JacoModelDev* m, const JacoLDS& s, int g, int type, v3 dir, int lane) {
+template <class L>
+JDEV v3 support_geom(const JacoStepArgs& A, const JacoModelDev* m, const L& s, int g, int type, v3 dir, int lane) {
   GeomPose P = geom_pose(s, g);
   v3 l = mulT(P.R, dir), sp;
   if (type == JG_BOX) {
@@ -91,7 +95,8 @@ JDEV v3 support_geom(const JacoStepArgs& A, const JacoModelDev* m, const JacoLDS
 }
 
 // ---------------------------------------------------------------- plane narrowphase
-JDEV void collide_plane_box(const JacoModelDev* m, JacoLDS& s, int g1, int g2, int pair, int lane, int& ncon, unsigned& flags) {
+template <class L>
+JDEV void collide_plane_box(const JacoModelDev* m, L& s, int g1, int g2, int pair, int lane, int& ncon, unsigned& flags) {
   GeomPose P = geom_pose(s, g1), B = geom_pose(s, g2);
   v3 n = col(P.R, 2);
   int i = lane & 7;
@@ -100,13 +105,15 @@ JDEV void collide_plane_box(const JacoModelDev* m, JacoLDS& s, int g1, int g2, i
   float dist = dot(c - P.p, n);
   push_contacts(s, lane < 8 && !(dist > 0.f), dist, c - n * (0.5f * dist), n, pair, ncon, flags, 4);
 }
-JDEV void collide_plane_sphere(const JacoModelDev* m, JacoLDS& s, int g1, int g2, int pair, int lane, int& ncon, unsigned& flags) {
+template <class L>
+JDEV void collide_plane_sphere(const JacoModelDev* m, L& s, int g1, int g2, int pair, int lane, int& ncon, unsigned& flags) {
   GeomPose P = geom_pose(s, g1);
   v3 n = col(P.R, 2), c = ld3(s.gpos[g2]);
   float r = m->g_size[g2][0], dist = dot(c - P.p, n) - r;
   push_contacts(s, lane == 0 && !(dist > 0.f), dist, c - n * (r + 0.5f * dist), n, pair, ncon, flags, 1);
 }
-JDEV void collide_plane_convex(const JacoStepArgs& A, const JacoModelDev* m, JacoLDS& s, int g1, int g2, int t2, int pair, int lane, int& ncon, unsigned& flags) {
+template <class L>
+JDEV void collide_plane_convex(const JacoStepArgs& A, const JacoModelDev* m, L& s, int g1, int g2, int t2, int pair, int lane, int& ncon, unsigned& flags) {
   GeomPose P = geom_pose(s, g1);
   v3 n = col(P.R, 2);
   v3 sp = support_geom(A, m, s, g2, t2, -n, lane);
@@ -115,16 +122,18 @@ JDEV void collide_plane_convex(const JacoStepArgs& A, const JacoModelDev* m, Jac
 }
 
 // ---------------------------------------------------------------- box-box
-JDEV void collide_box_box(const JacoModelDev* m, JacoLDS& s, int g1, int g2, int pair, int lane, int& ncon, unsigned& flags) {
+template <class L>
+JDEV void collide_box_box(const JacoModelDev* m, L& s, int g1, int g2, int pair, int lane, int& ncon, unsigned& flags) {
   GeomPose P1 = geom_pose(s, g1), P2 = geom_pose(s, g2);
   float s1[3] = {m->g_size[g1][0], m->g_size[g1][1], m->g_size[g1][2]}, s2[3] = {m->g_size[g2][0], m->g_size[g2][1], m->g_size[g2][2]};
   v3 Aa[3] = {col(P1.R, 0), col(P1.R, 1), col(P1.R, 2)}, Ba[3] = {col(P2.R, 0), col(P2.R, 1), col(P2.R, 2)};
   v3 pp = P2.p - P1.p;
   // lane a < 6: face axis; 6 <= a < 15: edge axis A[i] x B[j]
   int a = lane < 15 ? lane : 0;
-  int ei = a >= 6 ? (a - 6) / 3 : 0, ej = a >= 6 ? (a - 6) % 3 : 0;
-  v3 ax;
-  if (a < 3) ax = Aa[a]; else if (a < 6) ax = Ba[a - 3]; else ax = cross(Aa[ei], Ba[ej]);
+  int ei = a >= 6 ? (a - 6) / 3 : (a < 3 ? a : 0), ej = a >= 6 ? (a - 6) % 3 : (a >= 3 ? a - 3 : 0);
+  // (selects instead of runtime-indexed arrays: those would live in scratch memory)
+  v3 Ai = ei == 0 ? Aa[0] : (ei == 1 ? Aa[1] : Aa[2]), Bj = ej == 0 ? Ba[0] : (ej == 1 ? Ba[1] : Ba[2]);
+  v3 ax = a < 3 ? Ai : (a < 6 ? Bj : cross(Ai, Bj));
   float len = norm(ax);
   bool degenerate = a >= 6 && len < 1e-6f;
   ax = ax * (1.f / fmaxf(len, 1e-30f));
@@ -235,25 +244,27 @@ JDEV void collide_box_box(const JacoModelDev* m, JacoLDS& s, int g1, int g2, int
 
 // ---------------------------------------------------------------- MPR (all lanes run the same serial control flow)
 struct Sup { v3 v, v1, v2; };
-JDEV Sup mpr_support(const JacoStepArgs& A, const JacoModelDev* m, const JacoLDS& s, int g1, int t1, int g2, int t2, v3 dir, int lane) {
+template <class L>
+JDEV Sup mpr_support(const JacoStepArgs& A, const JacoModelDev* m, const L& s, int g1, int t1, int g2, int t2, v3 dir, int lane) {
   Sup r;
   r.v1 = support_geom(A, m, s, g1, t1, dir, lane);
   r.v2 = support_geom(A, m, s, g2, t2, -dir, lane);
   r.v = r.v1 - r.v2;
   return r;
 }
-JDEV v3 portal_dir(const Sup* p) { return normalized(cross(p[2].v - p[1].v, p[3].v - p[1].v)); }
-JDEV bool reach_tol(const Sup* p, const Sup& v4, v3 dir, float tol) {
+// The portal (p0 interior point, p1..p3 triangle) is kept in four named variables: an indexed array would live in scratch.
+JDEV v3 portal_dir(const Sup& p1, const Sup& p2, const Sup& p3) { return normalized(cross(p2.v - p1.v, p3.v - p1.v)); }
+JDEV bool reach_tol(const Sup& p1, const Sup& p2, const Sup& p3, const Sup& v4, v3 dir, float tol) {
   float dv4 = dot(v4.v, dir);
-  float mn = fminf(dv4 - dot(p[1].v, dir), fminf(dv4 - dot(p[2].v, dir), dv4 - dot(p[3].v, dir)));
+  float mn = fminf(dv4 - dot(p1.v, dir), fminf(dv4 - dot(p2.v, dir), dv4 - dot(p3.v, dir)));
   return mn <= tol;
 }
-JDEV void expand_portal(Sup* p, const Sup& v4) {
-  v3 c = cross(v4.v, p[0].v);
-  if (dot(p[1].v, c) > 0.f) {
-    if (dot(p[2].v, c) > 0.f) p[1] = v4; else p[3] = v4;
+JDEV void expand_portal(const Sup& p0, Sup& p1, Sup& p2, Sup& p3, const Sup& v4) {
+  v3 c = cross(v4.v, p0.v);
+  if (dot(p1.v, c) > 0.f) {
+    if (dot(p2.v, c) > 0.f) p1 = v4; else p3 = v4;
   } else {
-    if (dot(p[3].v, c) > 0.f) p[2] = v4; else p[1] = v4;
+    if (dot(p3.v, c) > 0.f) p2 = v4; else p1 = v4;
   }
 }
 JDEV float point_tri_closest(v3 a, v3 b, v3 c, v3* cp) {  // closest point of triangle abc to the origin
@@ -276,73 +287,75 @@ JDEV float point_tri_closest(v3 a, v3 b, v3 c, v3* cp) {  // closest point of tr
   *cp = a + ab * (vb * den) + ac * (vc * den);
   return norm(*cp);
 }
-JDEV v3 mpr_find_pos(const Sup* p) {
-  float b0 = dot(cross(p[1].v, p[2].v), p[3].v), b1 = dot(cross(p[3].v, p[2].v), p[0].v);
-  float b2 = dot(cross(p[0].v, p[1].v), p[3].v), b3 = dot(cross(p[2].v, p[1].v), p[0].v);
+JDEV v3 mpr_find_pos(const Sup& p0, const Sup& p1, const Sup& p2, const Sup& p3) {
+  float b0 = dot(cross(p1.v, p2.v), p3.v), b1 = dot(cross(p3.v, p2.v), p0.v);
+  float b2 = dot(cross(p0.v, p1.v), p3.v), b3 = dot(cross(p2.v, p1.v), p0.v);
   float sum = b0 + b1 + b2 + b3;
   if (sum <= 0.f) {
-    v3 dir = portal_dir(p);
+    v3 dir = portal_dir(p1, p2, p3);
     b0 = 0.f;
-    b1 = dot(cross(p[2].v, p[3].v), dir); b2 = dot(cross(p[3].v, p[1].v), dir); b3 = dot(cross(p[1].v, p[2].v), dir);
+    b1 = dot(cross(p2.v, p3.v), dir); b2 = dot(cross(p3.v, p1.v), dir); b3 = dot(cross(p1.v, p2.v), dir);
     sum = b1 + b2 + b3;
   }
-  v3 a1 = p[0].v1 * b0 + p[1].v1 * b1 + p[2].v1 * b2 + p[3].v1 * b3;
-  v3 a2 = p[0].v2 * b0 + p[1].v2 * b1 + p[2].v2 * b2 + p[3].v2 * b3;
+  v3 a1 = p0.v1 * b0 + p1.v1 * b1 + p2.v1 * b2 + p3.v1 * b3;
+  v3 a2 = p0.v2 * b0 + p1.v2 * b1 + p2.v2 * b2 + p3.v2 * b3;
   return (a1 + a2) * (0.5f / sum);
 }
 // returns true on penetration
-JDEV bool mpr_penetration(const JacoStepArgs& A, const JacoModelDev* m, const JacoLDS& s, int g1, int t1, int g2, int t2, int lane,
+template <class L>
+JDEV bool mpr_penetration(const JacoStepArgs& A, const JacoModelDev* m, const L& s, int g1, int t1, int g2, int t2, int lane,
                           float* depth, v3* dirout, v3* pos) {
-  Sup p[4], v4;
+  Sup p0, p1, p2, p3, v4;
   float tol = m->mpr_tolerance;
-  p[0].v1 = ld3(s.gpos[g1]); p[0].v2 = ld3(s.gpos[g2]); p[0].v = p[0].v1 - p[0].v2;
-  if (norm(p[0].v) < 1e-9f) p[0].v.x = 1e-5f;
-  v3 dr = normalized(-p[0].v);
-  p[1] = mpr_support(A, m, s, g1, t1, g2, t2, dr, lane);
-  if (dot(p[1].v, dr) <= 0.f) return false;
-  dr = cross(p[0].v, p[1].v);
+  p0.v1 = ld3(s.gpos[g1]); p0.v2 = ld3(s.gpos[g2]); p0.v = p0.v1 - p0.v2;
+  if (norm(p0.v) < 1e-9f) p0.v.x = 1e-5f;
+  v3 dr = normalized(-p0.v);
+  p1 = mpr_support(A, m, s, g1, t1, g2, t2, dr, lane);
+  if (dot(p1.v, dr) <= 0.f) return false;
+  dr = cross(p0.v, p1.v);
   if (norm(dr) < 1e-9f) {
-    *depth = norm(p[1].v); *dirout = normalized(p[1].v); *pos = (p[1].v1 + p[1].v2) * 0.5f;
+    *depth = norm(p1.v); *dirout = normalized(p1.v); *pos = (p1.v1 + p1.v2) * 0.5f;
     return true;
   }
   dr = normalized(dr);
-  p[2] = mpr_support(A, m, s, g1, t1, g2, t2, dr, lane);
-  if (dot(p[2].v, dr) <= 0.f) return false;
-  dr = normalized(cross(p[1].v - p[0].v, p[2].v - p[0].v));
-  if (dot(dr, p[0].v) > 0.f) { Sup t = p[1]; p[1] = p[2]; p[2] = t; dr = -dr; }
+  p2 = mpr_support(A, m, s, g1, t1, g2, t2, dr, lane);
+  if (dot(p2.v, dr) <= 0.f) return false;
+  dr = normalized(cross(p1.v - p0.v, p2.v - p0.v));
+  if (dot(dr, p0.v) > 0.f) { Sup t = p1; p1 = p2; p2 = t; dr = -dr; }
   for (int it = 0;; it++) {
     if (it > 100) return false;
-    p[3] = mpr_support(A, m, s, g1, t1, g2, t2, dr, lane);
-    if (dot(p[3].v, dr) <= 0.f) return false;
+    p3 = mpr_support(A, m, s, g1, t1, g2, t2, dr, lane);
+    if (dot(p3.v, dr) <= 0.f) return false;
     bool cont = false;
-    if (dot(cross(p[1].v, p[3].v), p[0].v) < -1e-11f) { p[2] = p[3]; cont = true; }
-    if (!cont && dot(cross(p[3].v, p[2].v), p[0].v) < -1e-11f) { p[1] = p[3]; cont = true; }
+    if (dot(cross(p1.v, p3.v), p0.v) < -1e-11f) { p2 = p3; cont = true; }
+    if (!cont && dot(cross(p3.v, p2.v), p0.v) < -1e-11f) { p1 = p3; cont = true; }
     if (!cont) break;
-    dr = normalized(cross(p[1].v - p[0].v, p[2].v - p[0].v));
+    dr = normalized(cross(p1.v - p0.v, p2.v - p0.v));
   }
   for (int it = 0;; it++) {
-    dr = portal_dir(p);
-    if (dot(dr, p[1].v) >= 0.f) break;
+    dr = portal_dir(p1, p2, p3);
+    if (dot(dr, p1.v) >= 0.f) break;
     v4 = mpr_support(A, m, s, g1, t1, g2, t2, dr, lane);
-    if (dot(v4.v, dr) < 0.f || reach_tol(p, v4, dr, tol) || it > m->mpr_iterations) return false;
-    expand_portal(p, v4);
+    if (dot(v4.v, dr) < 0.f || reach_tol(p1, p2, p3, v4, dr, tol) || it > m->mpr_iterations) return false;
+    expand_portal(p0, p1, p2, p3, v4);
   }
   for (int it = 0;; it++) {
-    dr = portal_dir(p);
+    dr = portal_dir(p1, p2, p3);
     v4 = mpr_support(A, m, s, g1, t1, g2, t2, dr, lane);
-    if (reach_tol(p, v4, dr, tol) || it > m->mpr_iterations) {
+    if (reach_tol(p1, p2, p3, v4, dr, tol) || it > m->mpr_iterations) {
       v3 cp;
-      *depth = point_tri_closest(p[1].v, p[2].v, p[3].v, &cp);
+      *depth = point_tri_closest(p1.v, p2.v, p3.v, &cp);
       *dirout = *depth < 1e-10f ? dr : normalized(cp);
-      *pos = mpr_find_pos(p);
+      *pos = mpr_find_pos(p0, p1, p2, p3);
       return true;
     }
-    expand_portal(p, v4);
+    expand_portal(p0, p1, p2, p3, v4);
   }
 }
 
 // ---------------------------------------------------------------- stage C
-JDEV void stage_collision(const JacoStepArgs& A, const JacoModelDev* m, JacoLDS& s, int lane, unsigned& flags) {
+template <class L>
+JDEV void stage_collision(const JacoStepArgs& A, const JacoModelDev* m, L& s, int lane, unsigned& flags) {
   // phase 1: bounding spheres, lane = pair
   int n1 = 0;
   for (int base = 0; base < m->npair; base += 64) {
@@ -357,10 +370,10 @@ JDEV void stage_collision(const JacoStepArgs& A, const JacoModelDev* m, JacoLDS&
     pass = pass && valid;
     unsigned long long mask = wave_ballot(pass);
     int idx = n1 + wave_prefix_count(mask);
-    if (pass && idx < JMAXCAND) s.cand[idx] = k;
+    if (pass && idx < L::Caps::MAXCAND) s.cand[idx] = k;
     n1 += popc64(mask);
   }
-  if (n1 > JMAXCAND) { flags |= JFLAG_CAND_OVERFLOW; n1 = JMAXCAND; }
+  if (n1 > L::Caps::MAXCAND) { flags |= JFLAG_CAND_OVERFLOW; n1 = L::Caps::MAXCAND; }
   wave_sync();
   // phase 2: oriented-box cull of the survivors, lane = survivor; compacted in place (order preserved)
   int ncand = 0;
@@ -389,6 +402,7 @@ JDEV void stage_collision(const JacoStepArgs& A, const JacoModelDev* m, JacoLDS&
     int pk = s.cand[c];
     int code = m->pair_code[pk];
     int g1 = code & 255, g2 = (code >> 8) & 255, t1 = (code >> 16) & 15, t2 = (code >> 20) & 15;
+    int before = ncon;
     if (t1 == JG_PLANE) {
       if (t2 == JG_BOX) collide_plane_box(m, s, g1, g2, pk, lane, ncon, flags);
       else if (t2 == JG_SPHERE) collide_plane_sphere(m, s, g1, g2, pk, lane, ncon, flags);
@@ -401,61 +415,92 @@ JDEV void stage_collision(const JacoStepArgs& A, const JacoModelDev* m, JacoLDS&
       bool hit = mpr_penetration(A, m, s, g1, t1, g2, t2, lane, &depth, &dir, &pos);
       push_contacts(s, hit && lane == 0, -depth, pos, dir, pk, ncon, flags, 1);
     }
+    if (ncon > before) {   // dof chain masks of the two bodies, cached for the row builder
+      int b1 = m->g_body[g1], b2 = m->g_body[g2];
+      unsigned m1 = b1 >= 0 ? m->b_chainmask[b1] : 0u, m2 = b2 >= 0 ? m->b_chainmask[b2] : 0u;
+      int c = before + lane;
+      if (c < ncon) { s.c_m1[c] = m1; s.c_m2[c] = m2; }
+    }
   }
   if (lane == 0) { s.ncon = ncon; s.ncand = ncand; }
 }
 
 // ---------------------------------------------------------------- stage R (contacts): pyramidal rows
-JDEV void stage_contact_rows(const JacoModelDev* m, JacoLDS& s, int lane, unsigned& flags) {
-  int nv = m->nv, ncon = s.ncon, r = s.nefc;  // rows after the joint-limit rows
-  int kk = lane < nv ? lane : 0;
-  sv S = ldsv(s.cdof[kk]);
-  int ncon_kept = ncon;
-  for (int c = 0; c < ncon; c++) {
-    const JacoPairParam& P = m->pair[s.c_pair[c]];
-    int dim = P.condim, nrow = dim == 1 ? 1 : 2 * (dim - 1);
-    if (r + nrow > JMAXEFC) { flags |= JFLAG_EFC_OVERFLOW; ncon_kept = c; break; }
-    int b1 = m->g_body[P.g1], b2 = m->g_body[P.g2];
-    unsigned m1 = b1 >= 0 ? m->b_chainmask[b1] : 0u, m2 = b2 >= 0 ? m->b_chainmask[b2] : 0u;
-    float coef = (float)((int)((m2 >> kk) & 1u) - (int)((m1 >> kk) & 1u));
-    v3 pos = ld3(s.c_pos[c]);
-    v3 jp = (S.b + cross(S.a, pos)) * coef, jr = S.a * coef;
-    const float* fr = s.c_frame[c];
-    float Jc[6];
-#pragma unroll
-    for (int a = 0; a < 3; a++) { Jc[a] = dot(ld3(fr + 3 * a), jp); Jc[3 + a] = dot(ld3(fr + 3 * a), jr); }
-    if (lane < nv) {
-      if (dim == 1) s.J[r * JLD + lane] = Jc[0];
-      else
-        for (int e = 0; e < nrow; e++) {
-          int k = 1 + (e >> 1);
-          float jk = k == 1 ? Jc[1] : (k == 2 ? Jc[2] : (k == 3 ? Jc[3] : (k == 4 ? Jc[4] : Jc[5])));
-          s.J[(r + e) * JLD + lane] = Jc[0] + ((e & 1) ? -1.f : 1.f) * P.mu[k - 1] * jk;
-        }
-    }
-    if (lane < nrow) s.e_con[r + lane] = c | (lane << 8);
-    if (lane == 0) s.c_efc[c] = r;
-    r += nrow;
+template <class L>
+JDEV void stage_contact_rows(const JacoModelDev* m, L& s, int lane, unsigned& flags) {
+  constexpr int MAXEFC = L::Caps::MAXEFC;
+  const int nv = m->nv, ncon = s.ncon, nlim = s.nlimit;
+  // rows per contact and row offsets: lane = contact
+  int dim = 0, nrow = 0;
+  float mu0 = 0.f, mu1 = 0.f, mu2 = 0.f;
+  unsigned cm1 = 0, cm2 = 0;
+  if (lane < ncon) {
+    const JacoPairParam& P = m->pair[s.c_pair[lane]];
+    dim = P.condim; nrow = dim == 1 ? 1 : 2 * (dim - 1);
+    mu0 = P.mu[0]; mu1 = P.mu[2]; mu2 = P.mu[3];
+    cm1 = s.c_m1[lane]; cm2 = s.c_m2[lane];
   }
-  wave_sync();  // every lane has read the incoming row / contact counts
-  if (lane == 0) { s.nefc = r; s.ncon = ncon_kept; }
-  wave_sync();
+  int end = nlim + wave_scan_incl(nrow, lane);
+  unsigned long long fm = wave_ballot(lane < ncon && end <= MAXEFC);
+  int kept = popc64(fm);   // row offsets are monotone, so the contacts that fit form a prefix
+  if (kept < ncon) flags |= JFLAG_EFC_OVERFLOW;
+  int total = wave_bcast_i(end, kept > 0 ? kept - 1 : 0);
+  total = kept > 0 ? total : nlim;
+  int r0 = end - nrow;
+  if (lane < kept) {
+    s.c_efc[lane] = r0;
+    unsigned mm = cm1 | cm2;
+    int blk = ((mm & ((1u << JB0) - 1u)) ? 1 : 0) | (((mm >> JB0) & ((1u << (JB1 - JB0)) - 1u)) ? 2 : 0) | ((mm >> JB1) ? 4 : 0);
+    for (int e = 0; e < nrow; e++) s.e_con[r0 + e] = lane | (e << 8) | (blk << 16);
+  }
+  // Jacobian rows: lane = (contact slot 0..2, dof); the slot's contact data is fetched from its owner lane
+  const int cl = lane / JNV, k = lane - cl * JNV;
+  const bool dofok = cl < 3 && k < nv;
+  sv S = ldsv(s.cdof[dofok ? k : 0]);
+  for (int c0 = 0; c0 < kept; c0 += 3) {
+    int c = c0 + (cl < 3 ? cl : 0);
+    int src = c < 64 ? c : 0;
+    int cdim = wave_shfl_i(dim, src), cr0 = wave_shfl_i(r0, src);
+    float f0 = wave_shfl(mu0, src), f1 = wave_shfl(mu1, src), f2 = wave_shfl(mu2, src);
+    unsigned a1 = (unsigned)wave_shfl_i((int)cm1, src), a2 = (unsigned)wave_shfl_i((int)cm2, src);
+    if (dofok && c < kept) {
+      float coef = (float)((int)((a2 >> k) & 1u) - (int)((a1 >> k) & 1u));
+      v3 pos = ld3(s.c_pos[c]);
+      v3 jp = (S.b + cross(S.a, pos)) * coef, jr = S.a * coef;
+      const float* fr = s.c_frame[c];
+      float Jc[6];
+#pragma unroll
+      for (int a = 0; a < 3; a++) { Jc[a] = dot(ld3(fr + 3 * a), jp); Jc[3 + a] = dot(ld3(fr + 3 * a), jr); }
+      float* Jw = s.J + cr0 * JLD + k;
+      if (cdim == 1) Jw[0] = Jc[0];
+      else {
+        Jw[0] = Jc[0] + f0 * Jc[1]; Jw[JLD] = Jc[0] - f0 * Jc[1];
+        Jw[2 * JLD] = Jc[0] + f0 * Jc[2]; Jw[3 * JLD] = Jc[0] - f0 * Jc[2];
+        if (cdim > 3) {
+          Jw[4 * JLD] = Jc[0] + f1 * Jc[3]; Jw[5 * JLD] = Jc[0] - f1 * Jc[3];
+          Jw[6 * JLD] = Jc[0] + f2 * Jc[4]; Jw[7 * JLD] = Jc[0] - f2 * Jc[4];
+          Jw[8 * JLD] = Jc[0] + f2 * Jc[5]; Jw[9 * JLD] = Jc[0] - f2 * Jc[5];
+        }
+      }
+    }
+  }
+  wave_sync();  // every lane has read the incoming row / contact counts; J rows and e_con are visible
+  if (lane == 0) { s.nefc = total; s.ncon = kept; }
   // per-row parameters, lane = row
-  int nlim = s.nlimit;
-  for (int rr = nlim + lane; rr < r; rr += 64) {
-    int ce = s.e_con[rr], c = ce & 255, e = ce >> 8;
+  for (int rr = nlim + lane; rr < total; rr += 64) {
+    int ce = s.e_con[rr], c = ce & 255, e = (ce >> 8) & 255;
     const JacoPairParam& P = m->pair[s.c_pair[c]];
-    int dim = P.condim;
+    int pd = P.condim;
     float vel = 0.f;
-    for (int k = 0; k < nv; k++) vel += s.J[rr * JLD + k] * s.qvel[k];
+    for (int kk = 0; kk < nv; kk++) vel += s.J[rr * JLD + kk] * s.qvel[kk];
     float tran = m->g_invweight[P.g1][0] + m->g_invweight[P.g2][0], rot = m->g_invweight[P.g1][1] + m->g_invweight[P.g2][1];
     float pos = s.c_dist[c] - P.margin;
-    int k = dim == 1 ? 0 : 1 + (e >> 1);
-    float mu = dim == 1 ? 0.f : P.mu[k - 1];
-    float da = dim == 1 ? tran : tran + mu * mu * (k < 3 ? tran : rot);
+    int kf = pd == 1 ? 0 : 1 + (e >> 1);
+    float mu = pd == 1 ? 0.f : P.mu[kf - 1];
+    float da = pd == 1 ? tran : tran + mu * mu * (kf < 3 ? tran : rot);
     float R;
     float aref = row_params(P.solref, P.solimp, pos, vel, da, &R);
-    if (dim > 1) {  // pyramidal: every edge uses 2 mu^2 R of the contact's first row (impratio = 1)
+    if (pd > 1) {  // pyramidal: every edge uses 2 mu^2 R of the contact's first row (impratio = 1)
       float R0;
       row_params(P.solref, P.solimp, pos, 0.f, tran + P.mu[0] * P.mu[0] * tran, &R0);
       R = fmaxf(JMINVAL, 2.f * P.mu[0] * P.mu[0] * R0);
@@ -509,7 +554,8 @@ JDEV bool ray_hits_site(int type, float sx, float sy, float sz, v3 p, v3 d) {
   if (disc < 0.f) return false;
   return (-B + sqrtf(disc)) / A >= 0.f;
 }
-JDEV void stage_touch(const JacoModelDev* m, JacoLDS& s, int lane, float* sens) {
+template <class L>
+JDEV void stage_touch(const JacoModelDev* m, L& s, int lane, float* sens) {
   int ncon = s.ncon;
   if (lane < ncon) {
     const JacoPairParam& P = m->pair[s.c_pair[lane]];

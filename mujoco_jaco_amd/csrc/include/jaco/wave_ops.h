@@ -81,3 +81,14 @@ JDEV int wave_argmax(float v, int idx, float* best) {
   *best = bv;
   return bi;
 }
+
+JDEV int grid_size() { return (int)gridDim.x; }
+JDEV int jaco_atomic_inc(int* p) { return atomicAdd(p, 1); }
+
+// Hide a (wave-uniform) pointer's provenance from the optimiser: stops it from hoisting per-lane model
+// loads out of the substep loop and keeping them live (in VGPRs) across the whole loop body.
+template <class T>
+JDEV const T* opaque_ptr(const T* p) {
+  asm volatile("" : "+s"(p));
+  return p;
+}

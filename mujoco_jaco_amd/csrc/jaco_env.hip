@@ -14,7 +14,7 @@
 
 static_assert(JFLAG_CON_OVERFLOW == JACO_FLAG_CON_OVERFLOW && JFLAG_EFC_OVERFLOW == JACO_FLAG_EFC_OVERFLOW &&
                   JFLAG_CAND_OVERFLOW == JACO_FLAG_CAND_OVERFLOW && JFLAG_NAN == JACO_FLAG_NAN &&
-                  JFLAG_SOLVER_MAXITER == JACO_FLAG_SOLVER_MAXITER,
+                  JFLAG_SOLVER_MAXITER == JACO_FLAG_SOLVER_MAXITER && JFLAG_HEAVY_TIER == JACO_FLAG_HEAVY_TIER,
               "flag bits of the kernel and the public header must agree");
 
 struct JacoHandle {
@@ -24,6 +24,7 @@ struct JacoHandle {
   float *qpos = nullptr, *qvel = nullptr, *qacc_ws = nullptr, *sensordata = nullptr, *dbg = nullptr;
   unsigned* flags = nullptr;
   int* stats = nullptr;
+  int *remaining = nullptr, *heavy_list = nullptr, *heavy_count = nullptr;
   unsigned long long* prof = nullptr;
   std::vector<float> qpos0;
   int num_envs = 0, device = 0, frame_skip = 50, task = 0, disable_contact = 0;
@@ -90,6 +91,10 @@ extern "C" int jaco_create(const JacoConfig* cfg, JacoHandle** out) {
   CREATECHK(hipMalloc(&h->flags, B * sizeof(unsigned)));
   CREATECHK(hipMalloc(&h->stats, B * 4 * sizeof(int)));
   CREATECHK(hipMalloc(&h->dbg, JDBG_SIZE * sizeof(float)));
+  CREATECHK(hipMalloc(&h->remaining, B * sizeof(int)));
+  CREATECHK(hipMalloc(&h->heavy_list, B * sizeof(int)));
+  CREATECHK(hipMalloc(&h->heavy_count, sizeof(int)));
+  CREATECHK(hipMemset(h->remaining, 0, B * sizeof(int)));
   CREATECHK(hipMemcpy(h->model_dev, &h->model_host, sizeof(JacoModelDev), hipMemcpyHostToDevice));
   CREATECHK(hipMemcpy(h->hull_dev, hull.data(), hull.size() * sizeof(float), hipMemcpyHostToDevice));
   CREATECHK(hipMemset(h->flags, 0, B * sizeof(unsigned)));
@@ -124,7 +129,7 @@ extern "C" int jaco_destroy(JacoHandle* h) {
   if (!h) return JACO_EINVAL;
   (void)hipSetDevice(h->device);
   for (auto& e : h->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-  void* ptrs[] = {h->model_dev, h->hull_dev, h->qpos, h->qvel, h->qacc_ws, h->sensordata, h->flags, h->stats, h->dbg, h->prof};
+  void* ptrs[] = {h->model_dev, h->hull_dev, h->qpos, h->qvel, h->qacc_ws, h->sensordata, h->flags, h->stats, h->dbg, h->prof, h->remaining, h->heavy_list, h->heavy_count};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   delete h;
   return JACO_OK;
@@ -186,6 +191,7 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
   A.model = h->model_dev; A.hull = h->hull_dev; A.qpos = h->qpos; A.qvel = h->qvel; A.qacc_ws = h->qacc_ws; A.ctrl = ctrl;
   A.sensordata = h->sensordata; A.flags = h->flags; A.stats = h->stats; A.nenv = h->num_envs; A.nsub = nsub;
   A.disable_contact = h->disable_contact; A.dbg = dbg; A.dbg_env = dbg_env; A.prof = h->prof;
+  A.remaining = h->remaining; A.heavy_list = h->heavy_list; A.heavy_count = h->heavy_count;
   std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
   if (h->timing) {
     if (h->events_used == h->events.size()) {
@@ -197,7 +203,12 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
     ev = &h->events[h->events_used++];
     HIPCHK(h, hipEventRecord(ev->first, st));
   }
+  // light tier for every env, then the heavy tier for the envs that overflowed the light capacities
+  HIPCHK(h, hipMemsetAsync(h->heavy_count, 0, sizeof(int), st));
   hipLaunchKernelGGL(jaco_physics_kernel, dim3((unsigned)h->num_envs), dim3(64), 0, st, A);
+  HIPCHK(h, hipGetLastError());
+  unsigned hg = (unsigned)(h->num_envs < 1024 ? h->num_envs : 1024);
+  hipLaunchKernelGGL(jaco_physics_kernel_heavy, dim3(hg), dim3(64), 0, st, A);
   HIPCHK(h, hipGetLastError());
   if (ev) HIPCHK(h, hipEventRecord(ev->second, st));
   return JACO_OK;

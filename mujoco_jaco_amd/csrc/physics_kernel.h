@@ -17,17 +17,28 @@
 #include <jaco/model_dev.h>
 #include <jaco/wave_ops.h>
 
-#define JMAXCON 64    // contacts kept per env (overflow sets JFLAG_CON_OVERFLOW)
-#define JMAXEFC 256   // constraint rows per env (JNR row slots per lane)
-#define JNR (JMAXEFC / 64)
-#define JMAXCAND 128  // bounding-sphere survivors per env
+// Two capacity tiers of the same kernel (DESIGN.md "Two tiers"):
+//   light: <= 64 rows / 32 contacts / 64 candidates -> 1 constraint row per lane, ~17 KB LDS, the common case;
+//   heavy: <= 256 rows / 64 contacts / 128 candidates -> 4 rows per lane, ~39 KB LDS, for envs that overflow light.
+// A light wave that meets an overflow hands its env (state untouched for that substep) to the heavy launch.
+template <int MAXEFC_, int MAXCON_, int MAXCAND_>
+struct JacoCaps {
+  static constexpr int MAXEFC = MAXEFC_, MAXCON = MAXCON_, MAXCAND = MAXCAND_, NR = MAXEFC_ / 64;
+};
+typedef JacoCaps<64, 32, 64> JacoLight;
+typedef JacoCaps<256, 64, 128> JacoHeavy;
+#define JDBG_MAXCON 64
+#define JDBG_MAXEFC 256
 #define JLD (JNV)     // row stride of per-row dof vectors in LDS (21: odd, conflict-free for lane-per-row access)
+#define JB0 9         // dof blocks of the mass matrix: [0,JB0) arm + fingers, [JB0,JB1) object, [JB1,JNV) pedestal
+#define JB1 15
 
 #define JFLAG_CON_OVERFLOW 1u
 #define JFLAG_EFC_OVERFLOW 2u
 #define JFLAG_CAND_OVERFLOW 4u
 #define JFLAG_NAN 8u
 #define JFLAG_SOLVER_MAXITER 16u
+#define JFLAG_HEAVY_TIER 32u   // informational: env was stepped by the heavy tier at least once
 
 #define JMINVAL 1e-15f
 
@@ -57,6 +68,9 @@ struct JacoStepArgs {
   float* sensordata;   // [nenv][nsensor]
   unsigned* flags;     // [nenv] sticky error bits
   int* stats;          // [nenv][4]: ncon, nefc, newton iterations, candidates (last substep) or nullptr
+  int* remaining;      // [nenv] substeps left for the heavy tier (written by the light tier)
+  int* heavy_list;     // [nenv] env ids handed to the heavy tier
+  int* heavy_count;    // [1]
   int nenv, nsub, disable_contact;
   unsigned long long* prof;  // diagnostic build only: [nenv][JPROF_N] cycle sums, else nullptr
   float* dbg;          // optional stage dump of env dbg_env (see JDBG_* offsets), else nullptr
@@ -73,14 +87,16 @@ struct JacoStepArgs {
 #define JDBG_QACC (JDBG_QACC_SMOOTH + 24)
 #define JDBG_QFRC_CON (JDBG_QACC + 24)
 #define JDBG_NCON (JDBG_QFRC_CON + 24)    // ncon, nefc, iters, ncand
-#define JDBG_CONTACT (JDBG_NCON + 4)      // [JMAXCON][8]: dist, pos3, normal3, pair
-#define JDBG_EFC (JDBG_CONTACT + 8 * JMAXCON)  // [JMAXEFC][4]: aref, R, x(final jar), force
-#define JDBG_GPOS (JDBG_EFC + 4 * JMAXEFC)     // [JMAXGEOM][3]
+#define JDBG_CONTACT (JDBG_NCON + 4)      // [JDBG_MAXCON][8]: dist, pos3, normal3, pair
+#define JDBG_EFC (JDBG_CONTACT + 8 * JDBG_MAXCON)  // [JDBG_MAXEFC][4]: aref, R, x(final jar), force
+#define JDBG_GPOS (JDBG_EFC + 4 * JDBG_MAXEFC)     // [JMAXGEOM][3]
 #define JDBG_CFN (JDBG_GPOS + 3 * JMAXGEOM)      // [JMAXCON] per-contact normal force seen by the touch stage
-#define JDBG_SENS (JDBG_CFN + JMAXCON)         // [JNSENS] sensordata
+#define JDBG_SENS (JDBG_CFN + JDBG_MAXCON)         // [JNSENS] sensordata
 #define JDBG_SIZE (JDBG_SENS + JNSENS)
 
+template <class C>
 struct JacoLDS {
+  typedef C Caps;
   float qpos[24], qvel[24], qacc_ws[24], ctrl[12];
   float xpos[JNB][3], xmat[JNB][9], xipos[JNB][3];
   float cdof[JNV][6];
@@ -90,15 +106,15 @@ struct JacoLDS {
   float bias[24], smooth[24], qacc_smooth[24], qfrc_con[24];
   float gpos[JMAXGEOM][3], gmat[JMAXGEOM][9];
   // contacts
-  float c_dist[JMAXCON], c_pos[JMAXCON][3], c_frame[JMAXCON][9], c_fn[JMAXCON];
-  int c_pair[JMAXCON], c_efc[JMAXCON];
-  int cand[JMAXCAND];
+  float c_dist[C::MAXCON], c_pos[C::MAXCON][3], c_frame[C::MAXCON][9], c_fn[C::MAXCON];
+  int c_pair[C::MAXCON], c_efc[C::MAXCON];
+  unsigned c_m1[C::MAXCON], c_m2[C::MAXCON];   // dof chain masks of the two bodies
+  int cand[C::MAXCAND];
   // constraint rows
-  float J[JMAXEFC * JLD];
-  float e_aref[JMAXEFC], e_D[JMAXEFC], e_f[JMAXEFC];
-  int e_con[JMAXEFC];
+  float J[C::MAXEFC * JLD];
+  float e_aref[C::MAXEFC], e_D[C::MAXEFC], e_f[C::MAXEFC];
+  int e_con[C::MAXEFC];                         // contact | edge << 8 | block bits << 16
   int ncon, nefc, ncand, nlimit;
-  float scratch[64];
 };
 
 // ---------------------------------------------------------------- small vector helpers
@@ -175,16 +191,20 @@ JDEV sv inert_mul(const float* I, sv mv) {
 
 // ---------------------------------------------------------------- LDL^T solve, one matrix row per lane
 // h[j] = A[lane][j] (lanes >= n must hold identity rows), b = rhs[lane]; returns x[lane]. Registers only.
+// FULL = false: A is block diagonal over the dof blocks [0,JB0) [JB0,JB1) [JB1,JNV) (always true for the mass
+// matrix; true for the Newton Hessian unless an active row couples two blocks): 66 instead of 210 eliminations.
+template <bool FULL>
 JDEV float ldl_solve(float (&h)[JNV], float b, int lane) {
   float dinv = 1.f;
 #pragma unroll
   for (int k = 0; k < JNV; k++) {
+    const int jend = FULL ? JNV : (k < JB0 ? JB0 : (k < JB1 ? JB1 : JNV));
     float dk = wave_bcast(h[k], k);
     float inv = 1.f / dk;
     dinv = lane == k ? inv : dinv;
     float lik = lane > k ? h[k] * inv : 0.f;
 #pragma unroll
-    for (int j = k + 1; j < JNV; j++) h[j] -= lik * wave_bcast(h[j], k);
+    for (int j = k + 1; j < jend; j++) h[j] -= lik * wave_bcast(h[j], k);
     b -= lik * wave_bcast(b, k);
   }
   // now: b = y (L y = rhs); h[k>lane] = d_lane * L[k][lane]
@@ -197,13 +217,23 @@ JDEV float ldl_solve(float (&h)[JNV], float b, int lane) {
   }
   return x;
 }
+// inclusive prefix sum over lanes (6 ds_bpermute steps)
+JDEV int wave_scan_incl(int v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int t = wave_shfl_i(v, lane >= o ? lane - o : lane);
+    v += lane >= o ? t : 0;
+  }
+  return v;
+}
 JDEV void load_rows(float (&h)[JNV], const float* M, int nv, int lane) {
 #pragma unroll
   for (int j = 0; j < JNV; j++) h[j] = lane < nv ? M[lane * JNV + j] : (lane == j ? 1.f : 0.f);
 }
 
 // ---------------------------------------------------------------- stage K: tree walk
-JDEV void stage_walk(const JacoModelDev* m, JacoLDS& s, int lane) {
+template <class L>
+JDEV void stage_walk(const JacoModelDev* m, L& s, int lane) {
   int nleaf = m->nleaf;
   int leaf = lane < nleaf ? lane : nleaf - 1;
   bool pub = lane < nleaf;
@@ -271,7 +301,8 @@ JDEV void stage_walk(const JacoModelDev* m, JacoLDS& s, int lane) {
 }
 
 // ---------------------------------------------------------------- stage G: geom poses, body inertias, RNE body forces
-JDEV void stage_geoms_inertia(const JacoModelDev* m, JacoLDS& s, int lane) {
+template <class L>
+JDEV void stage_geoms_inertia(const JacoModelDev* m, L& s, int lane) {
   if (lane < m->ngeom) {
     int b = m->g_body[lane];
     if (b >= 0) {
@@ -310,7 +341,8 @@ JDEV void stage_geoms_inertia(const JacoModelDev* m, JacoLDS& s, int lane) {
 }
 
 // children -> parents: composite inertias (lanes 0..9) and RNE forces (lanes 16..21), component-parallel
-JDEV void stage_accumulate(const JacoModelDev* m, JacoLDS& s, int lane) {
+template <class L>
+JDEV void stage_accumulate(const JacoModelDev* m, L& s, int lane) {
   for (int b = m->nbody - 1; b > 0; b--) {
     int p = m->b_parent[b];
     if (p < 0) continue;
@@ -320,7 +352,8 @@ JDEV void stage_accumulate(const JacoModelDev* m, JacoLDS& s, int lane) {
 }
 
 // ---------------------------------------------------------------- stage M: mass matrix, bias, actuation
-JDEV void stage_mass_bias(const JacoModelDev* m, JacoLDS& s, int lane) {
+template <class L>
+JDEV void stage_mass_bias(const JacoModelDev* m, L& s, int lane) {
   if (lane < m->nv) {
     int d = lane, b = m->d_body[d];
     sv S = ldsv(s.cdof[d]);
@@ -335,7 +368,8 @@ JDEV void stage_mass_bias(const JacoModelDev* m, JacoLDS& s, int lane) {
     s.smooth[d] = -m->d_damping[d] * s.qvel[d] - bias;
   }
 }
-JDEV void stage_actuation(const JacoModelDev* m, JacoLDS& s, int lane) {
+template <class L>
+JDEV void stage_actuation(const JacoModelDev* m, L& s, int lane) {
   if (lane < m->nu) {
     int a = lane;
     float c = s.ctrl[a];
@@ -369,7 +403,8 @@ JDEV float row_params(const float* solref, const float* solimp, float pos, float
 }
 
 // joint limits: lane = body; one row per violated limit, compacted with a ballot
-JDEV void stage_limit_rows(const JacoModelDev* m, JacoLDS& s, int lane) {
+template <class L>
+JDEV void stage_limit_rows(const JacoModelDev* m, L& s, int lane) {
   bool act = false;
   float dist = 0.f, sgn = 1.f;
   int d = 0;
@@ -388,77 +423,98 @@ JDEV void stage_limit_rows(const JacoModelDev* m, JacoLDS& s, int lane) {
     float R;
     s.e_aref[r] = row_params(m->b_solref[lane], m->b_solimp[lane], dist, sgn * s.qvel[d], m->d_invweight[d], &R);
     s.e_D[r] = 1.f / R;
+    s.e_con[r] = (d < JB0 ? 1 : (d < JB1 ? 2 : 4)) << 16;
   }
   if (lane == 0) { s.nefc = popc64(mask); s.nlimit = s.nefc; }
 }
 
 // ---------------------------------------------------------------- stage S: primal Newton solver
-// Lane k < nv owns element k of every dof vector; lane r owns constraint rows r and r + 64.
+// Lane k < nv owns element k of every dof vector and row k of M / H; lane r owns constraint rows r + 64 q.
 struct NewtonOut { float qacc, qfrc_con; int iters; };
 
-// out[q] = sum_k J[row(q)][k] * v[k] for the lane's JNR rows; v distributed one element per lane
-JDEV void rows_dot(const JacoLDS& s, float vk, int lane, int ne, int nv, float (&out)[JNR]) {
-  const float* Jr[JNR];
+// out[q] = sum_k J[row(q)][k] * v[k] for the lane's NR rows; v distributed one element per lane.
+// NR == 1 keeps the lane's J row in registers (jrow) for the whole solve: no LDS traffic here.
+template <int NR>
+JDEV void rows_dot(const float* J, const float (&jrow)[JNV], float vk, int lane, int ne, int nv, float (&out)[NR]) {
+  if (NR == 1) {
+    float acc = 0.f;
 #pragma unroll
-  for (int q = 0; q < JNR; q++) { int r = lane + 64 * q; Jr[q] = s.J + (r < ne ? r : 0) * JLD; out[q] = 0.f; }
+    for (int k = 0; k < JNV; k++) acc += jrow[k] * wave_bcast(vk, k);
+    out[0] = acc;
+    return;
+  }
+  const float* Jr[NR];
+#pragma unroll
+  for (int q = 0; q < NR; q++) { int r = lane + 64 * q; Jr[q] = J + (r < ne ? r : 0) * JLD; out[q] = 0.f; }
 #pragma unroll
   for (int k = 0; k < JNV; k++) {
-    float vb = k < nv ? wave_bcast(vk, k) : 0.f;
+    float vb = wave_bcast(vk, k);
 #pragma unroll
-    for (int q = 0; q < JNR; q++) out[q] += Jr[q][k < nv ? k : 0] * vb;
+    for (int q = 0; q < NR; q++) out[q] += Jr[q][k] * vb;
   }
+  (void)nv;
 }
-JDEV float mat_vec(const float* M, float vk, int lane, int nv) {  // (M v)[lane]
+JDEV float mat_vec(const float (&mrow)[JNV], float vk) {  // (M v)[lane], mrow = M[lane][:] (zero for lanes >= nv)
   float acc = 0.f;
-  const float* row = M + (lane < nv ? lane : 0) * JNV;
 #pragma unroll
-  for (int k = 0; k < JNV; k++) acc += row[k] * wave_bcast(vk, k);
-  return lane < nv ? acc : 0.f;
+  for (int k = 0; k < JNV; k++) acc += mrow[k] * wave_bcast(vk, k);
+  return acc;
 }
-// sum_r J[r][lane] * f_r, f distributed over the row slots
-JDEV float jt_vec(const JacoLDS& s, const float (&f)[JNR], int ne, int lane, int nv) {
+// sum_r J[r][lane] * f_r, f distributed over the row slots; 4 rows in flight per step to cover LDS latency
+template <int NR>
+JDEV float jt_vec(const float* J, const float (&f)[NR], int ne, int lane, int nv) {
   float acc = 0.f;
   int kk = lane < nv ? lane : 0;
 #pragma unroll
-  for (int q = 0; q < JNR; q++) {
+  for (int q = 0; q < NR; q++) {
     int n = ne - 64 * q;
     n = n > 64 ? 64 : n;
-    for (int rl = 0; rl < n; rl++) {
-      float fr = wave_bcast(f[q], rl);
-      if (fr != 0.f) acc += s.J[(64 * q + rl) * JLD + kk] * fr;
+    const float* Jq = J + (64 * q) * JLD + kk;
+    int rl = 0;
+    for (; rl + 4 <= n; rl += 4) {
+      float j0 = Jq[(rl + 0) * JLD], j1 = Jq[(rl + 1) * JLD], j2 = Jq[(rl + 2) * JLD], j3 = Jq[(rl + 3) * JLD];
+      acc += j0 * wave_bcast(f[q], rl) + j1 * wave_bcast(f[q], rl + 1) + j2 * wave_bcast(f[q], rl + 2) + j3 * wave_bcast(f[q], rl + 3);
     }
+    for (; rl < n; rl++) acc += Jq[rl * JLD] * wave_bcast(f[q], rl);
   }
   return lane < nv ? acc : 0.f;
 }
 
-JDEV NewtonOut stage_newton(const JacoModelDev* m, JacoLDS& s, int lane) {
+template <class L>
+JDEV NewtonOut stage_newton(const JacoModelDev* m, L& s, const float (&mrow)[JNV], int lane) {
+  constexpr int NR = L::Caps::NR, MAXEFC = L::Caps::MAXEFC;
   NewtonOut out;
   int nv = m->nv, ne = s.nefc;
   float qas = lane < nv ? s.qacc_smooth[lane] : 0.f;
   out.qacc = qas; out.qfrc_con = 0.f; out.iters = 0;
   if (ne == 0) return out;
-  if (ne > JMAXEFC) ne = JMAXEFC;
-  bool valid[JNR];
-  float D[JNR], ar[JNR], x[JNR], xs[JNR], f[JNR], jp[JNR];
+  if (ne > MAXEFC) ne = MAXEFC;
+  bool valid[NR];
+  float D[NR], ar[NR], x[NR], xs[NR], f[NR], jp[NR];
+  int blk[NR];
+  float jrow[JNV];
 #pragma unroll
-  for (int q = 0; q < JNR; q++) {
+  for (int q = 0; q < NR; q++) {
     int r = lane + 64 * q;
     valid[q] = r < ne;
     D[q] = valid[q] ? s.e_D[r] : 0.f;
     ar[q] = valid[q] ? s.e_aref[r] : 0.f;
+    blk[q] = valid[q] ? (s.e_con[r] >> 16) & 7 : 0;
   }
+#pragma unroll
+  for (int k = 0; k < JNV; k++) jrow[k] = (NR == 1 && lane < ne) ? s.J[lane * JLD + k] : 0.f;
   float scale = 1.f / (m->meaninertia * (float)(nv > 1 ? nv : 1));
   float tol = m->tolerance;
 
   // starting point: cheaper of warm start and unconstrained acceleration
   // (cross-lane helpers are always called by all 64 lanes; validity is applied to their results)
   float a = lane < nv ? s.qacc_ws[lane] : 0.f;
-  float Ma = mat_vec(s.M, a - qas, lane, nv);
-  rows_dot(s, a, lane, ne, nv, x);
-  rows_dot(s, qas, lane, ne, nv, xs);
+  float Ma = mat_vec(mrow, a - qas);
+  rows_dot<NR>(s.J, jrow, a, lane, ne, nv, x);
+  rows_dot<NR>(s.J, jrow, qas, lane, ne, nv, xs);
   float cw = 0.5f * Ma * (a - qas), cs = 0.f;
 #pragma unroll
-  for (int q = 0; q < JNR; q++) {
+  for (int q = 0; q < NR; q++) {
     x[q] = valid[q] ? x[q] - ar[q] : 0.f;
     xs[q] = valid[q] ? xs[q] - ar[q] : 0.f;
     cw += x[q] < 0.f ? 0.5f * D[q] * x[q] * x[q] : 0.f;
@@ -469,22 +525,28 @@ JDEV NewtonOut stage_newton(const JacoModelDev* m, JacoLDS& s, int lane) {
   if (!(cw < cs)) {
     a = qas; Ma = 0.f;
 #pragma unroll
-    for (int q = 0; q < JNR; q++) x[q] = xs[q];
+    for (int q = 0; q < NR; q++) x[q] = xs[q];
   }
+
   int it = 0;
   for (; it < m->iterations; it++) {
+    bool coupled = false;
 #pragma unroll
-    for (int q = 0; q < JNR; q++) f[q] = x[q] < 0.f ? -D[q] * x[q] : 0.f;
-    float jtf = jt_vec(s, f, ne, lane, nv);
-    float grad = Ma - jtf;
+    for (int q = 0; q < NR; q++) {
+      f[q] = x[q] < 0.f ? -D[q] * x[q] : 0.f;
+      coupled = coupled || (x[q] < 0.f && (blk[q] & (blk[q] - 1)) != 0);   // active row touching two dof blocks
+    }
+    bool full = wave_ballot(coupled) != 0ull;
+    float grad = Ma - jt_vec<NR>(s.J, f, ne, lane, nv);
     float gn = sqrtf(wave_sum(grad * grad));
     if (gn * scale < tol) break;
-    // Hessian rows: M + sum_active D_r J_r^T J_r
+    // Hessian rows: M + sum_active D_r J_r^T J_r  (lane i accumulates row i; J_r[j] arrive as LDS broadcasts)
     float h[JNV];
-    load_rows(h, s.M, nv, lane);
+#pragma unroll
+    for (int j2 = 0; j2 < JNV; j2++) h[j2] = lane < nv ? mrow[j2] : (lane == j2 ? 1.f : 0.f);
     int kk = lane < nv ? lane : 0;
 #pragma unroll
-    for (int q = 0; q < JNR; q++) {
+    for (int q = 0; q < NR; q++) {
       float w = x[q] < 0.f ? D[q] : 0.f;
       int n = ne - 64 * q;
       n = n > 64 ? 64 : n;
@@ -494,22 +556,22 @@ JDEV NewtonOut stage_newton(const JacoModelDev* m, JacoLDS& s, int lane) {
         const float* Jr = s.J + (64 * q + rl) * JLD;
         float wj = lane < nv ? Dr * Jr[kk] : 0.f;
 #pragma unroll
-        for (int j = 0; j < JNV; j++) h[j] += wj * Jr[j];
+        for (int j2 = 0; j2 < JNV; j2++) h[j2] += wj * Jr[j2];
       }
     }
-    float p = ldl_solve(h, -grad, lane);
+    float p = full ? ldl_solve<true>(h, -grad, lane) : ldl_solve<false>(h, -grad, lane);
     p = lane < nv ? p : 0.f;
     // exact line search on phi(al) = cost(a + al p)
-    float Mp = mat_vec(s.M, p, lane, nv);
+    float Mp = mat_vec(mrow, p);
     float pMp = wave_sum(p * Mp), pMa = wave_sum(p * Ma);
-    rows_dot(s, p, lane, ne, nv, jp);
+    rows_dot<NR>(s.J, jrow, p, lane, ne, nv, jp);
 #pragma unroll
-    for (int q = 0; q < JNR; q++) jp[q] = valid[q] ? jp[q] : 0.f;
+    for (int q = 0; q < NR; q++) jp[q] = valid[q] ? jp[q] : 0.f;
     float al = 0.f, lo = 0.f, hi = 3.0e38f, d10 = 0.f;
     for (int ls = 0; ls < m->ls_iterations; ls++) {
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-      for (int q = 0; q < JNR; q++) {
+      for (int q = 0; q < NR; q++) {
         float xa = x[q] + al * jp[q];
         s1 += xa < 0.f ? D[q] * xa * jp[q] : 0.f;
         s2 += xa < 0.f ? D[q] * jp[q] * jp[q] : 0.f;
@@ -527,7 +589,7 @@ JDEV NewtonOut stage_newton(const JacoModelDev* m, JacoLDS& s, int lane) {
     // tolerance stays meaningful in fp32 (the 1280 kg pedestal's cost terms are ~1e3, the object's ~1e-3)
     float dc = 0.f;
 #pragma unroll
-    for (int q = 0; q < JNR; q++) {
+    for (int q = 0; q < NR; q++) {
       float dx = al * jp[q], xn = x[q] + dx;
       bool was = x[q] < 0.f, is = xn < 0.f;
       dc += (was && is) ? 0.5f * D[q] * dx * (2.f * x[q] + dx) : (is ? 0.5f * D[q] * xn * xn : (was ? -0.5f * D[q] * x[q] * x[q] : 0.f));
@@ -538,17 +600,18 @@ JDEV NewtonOut stage_newton(const JacoModelDev* m, JacoLDS& s, int lane) {
     if (improvement * scale < tol) { it++; break; }
   }
 #pragma unroll
-  for (int q = 0; q < JNR; q++) f[q] = x[q] < 0.f ? -D[q] * x[q] : 0.f;
+  for (int q = 0; q < NR; q++) f[q] = x[q] < 0.f ? -D[q] * x[q] : 0.f;
   out.qacc = a;
-  out.qfrc_con = jt_vec(s, f, ne, lane, nv);
+  out.qfrc_con = jt_vec<NR>(s.J, f, ne, lane, nv);
   out.iters = it;
 #pragma unroll
-  for (int q = 0; q < JNR; q++) if (valid[q]) s.e_f[lane + 64 * q] = f[q];
+  for (int q = 0; q < NR; q++) if (valid[q]) s.e_f[lane + 64 * q] = f[q];
   return out;
 }
 
 // ---------------------------------------------------------------- stage E: integration
-JDEV void stage_integrate_pos(const JacoModelDev* m, JacoLDS& s, int lane) {
+template <class L>
+JDEV void stage_integrate_pos(const JacoModelDev* m, L& s, int lane) {
   float h = m->timestep;
   if (lane < m->nbody) {
     int b = lane, qa = m->b_qadr[b], da = m->b_dadr[b];
@@ -578,22 +641,24 @@ JDEV void stage_integrate_pos(const JacoModelDev* m, JacoLDS& s, int lane) {
 
 #include "collision.h"
 
-// ---------------------------------------------------------------- the kernel
-__global__ __launch_bounds__(64) void jaco_physics_kernel(JacoStepArgs A) {
-  __shared__ JacoLDS s;
-  const int lane = lane_id(), env = env_id();
-  if (env >= A.nenv) return;
+#include "collision.h"
+
+// ---------------------------------------------------------------- the kernels
+// One substep loop for one env; returns the number of substeps NOT done (light tier bail-out) or 0.
+template <class C, bool LIGHT>
+JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int lane) {
   const JacoModelDev* m = A.model;
   const int nq = m->nq, nv = m->nv, nu = m->nu, ns = m->nsensor;
   if (lane < nq) s.qpos[lane] = A.qpos[(size_t)env * nq + lane];
   if (lane < nv) { s.qvel[lane] = A.qvel[(size_t)env * nv + lane]; s.qacc_ws[lane] = A.qacc_ws[(size_t)env * nv + lane]; }
   if (lane < nu) s.ctrl[lane] = A.ctrl[(size_t)env * nu + lane];
-  unsigned flags = 0;
+  unsigned flags = LIGHT ? 0u : JFLAG_HEAVY_TIER;
   float sens = 0.f;
-  int iters = 0;
+  int iters = 0, left = 0;
   wave_sync();
   JSTAMP_INIT
-  for (int sub = 0; sub < A.nsub; sub++) {
+  for (int sub = 0; sub < nsub; sub++) {
+    m = opaque_ptr(A.model);
     stage_walk(m, s, lane);
     for (int i = lane; i < JNV * JNV; i += 64) s.M[i] = 0.f;
     wave_sync();
@@ -608,27 +673,35 @@ __global__ __launch_bounds__(64) void jaco_physics_kernel(JacoStepArgs A) {
     stage_actuation(m, s, lane);
     wave_sync();
     JSTAMP(2);
-    float h[JNV];
-    load_rows(h, s.M, nv, lane);
-    float smooth = lane < nv ? s.smooth[lane] : 0.f;
-    float qas = ldl_solve(h, smooth, lane);
-    if (lane < nv) s.qacc_smooth[lane] = qas;
+    // constraint rows first: nothing below is live across the (register-hungry) collision code
     stage_limit_rows(m, s, lane);
     wave_sync();
     JSTAMP(3);
+    unsigned cflags = 0;
     if (!A.disable_contact) {
-      stage_collision(A, m, s, lane, flags);
+      stage_collision(A, m, s, lane, cflags);
       wave_sync();
       JSTAMP(4);
-      stage_contact_rows(m, s, lane, flags);
+      stage_contact_rows(m, s, lane, cflags);
       wave_sync();
       JSTAMP(5);
-    } else if (lane == 0) {
-      s.ncon = 0; s.ncand = 0;
+    } else {
+      if (lane == 0) { s.ncon = 0; s.ncand = 0; }
+      wave_sync();
     }
+    if (LIGHT && cflags) {   // capacity exceeded: leave this substep (and the rest) to the heavy tier; nothing was mutated
+      left = nsub - sub;
+      break;
+    }
+    float mrow[JNV], h[JNV];   // M[lane][:] stays in registers for the rest of the substep
+#pragma unroll
+    for (int j = 0; j < JNV; j++) { mrow[j] = lane < nv ? s.M[lane * JNV + j] : 0.f; h[j] = lane < nv ? mrow[j] : (lane == j ? 1.f : 0.f); }
+    float smooth = lane < nv ? s.smooth[lane] : 0.f;
+    float qas = ldl_solve<false>(h, smooth, lane);
+    if (lane < nv) s.qacc_smooth[lane] = qas;
     wave_sync();
-    if (s.nefc > JMAXEFC) flags |= JFLAG_EFC_OVERFLOW;
-    NewtonOut nw = stage_newton(m, s, lane);
+    flags |= cflags;
+    NewtonOut nw = stage_newton(m, s, mrow, lane);
     JSTAMP(6);
     iters = nw.iters;
     if (iters >= m->iterations) flags |= JFLAG_SOLVER_MAXITER;
@@ -638,13 +711,12 @@ __global__ __launch_bounds__(64) void jaco_physics_kernel(JacoStepArgs A) {
     // Euler with implicit joint damping
     float total = smooth + nw.qfrc_con, qacc_e = nw.qacc;
     if (m->has_damping) {
-      load_rows(h, s.M, nv, lane);
       float hd = lane < nv ? m->timestep * m->d_damping[lane] : 0.f;
 #pragma unroll
-      for (int j = 0; j < JNV; j++) h[j] += lane == j ? hd : 0.f;
-      qacc_e = ldl_solve(h, total, lane);
+      for (int j = 0; j < JNV; j++) h[j] = (lane < nv ? mrow[j] : 0.f) + (lane == j ? (lane < nv ? hd : 1.f) : 0.f);
+      qacc_e = ldl_solve<false>(h, total, lane);
     }
-    if (A.dbg && env == A.dbg_env && sub == A.nsub - 1) {
+    if (A.dbg && env == A.dbg_env && sub == nsub - 1) {
       float* D = A.dbg;
       if (lane < m->nbody) {
         for (int k = 0; k < 3; k++) D[JDBG_XPOS + 3 * lane + k] = s.xpos[lane][k];
@@ -656,12 +728,12 @@ __global__ __launch_bounds__(64) void jaco_physics_kernel(JacoStepArgs A) {
         D[JDBG_QACC + lane] = nw.qacc; D[JDBG_QFRC_CON + lane] = nw.qfrc_con;
       }
       if (lane == 0) { D[JDBG_NCON] = (float)s.ncon; D[JDBG_NCON + 1] = (float)s.nefc; D[JDBG_NCON + 2] = (float)iters; D[JDBG_NCON + 3] = (float)s.ncand; }
-      for (int c = lane; c < s.ncon && c < JMAXCON; c += 64) {
+      for (int c = lane; c < s.ncon && c < C::MAXCON; c += 64) {
         float* o = D + JDBG_CONTACT + 8 * c;
         o[0] = s.c_dist[c]; o[1] = s.c_pos[c][0]; o[2] = s.c_pos[c][1]; o[3] = s.c_pos[c][2];
         o[4] = s.c_frame[c][0]; o[5] = s.c_frame[c][1]; o[6] = s.c_frame[c][2]; o[7] = (float)s.c_pair[c];
       }
-      for (int r = lane; r < s.nefc && r < JMAXEFC; r += 64) {
+      for (int r = lane; r < s.nefc && r < C::MAXEFC; r += 64) {
         float* o = D + JDBG_EFC + 4 * r;
         o[0] = s.e_aref[r]; o[1] = 1.f / s.e_D[r]; o[2] = 0.f; o[3] = s.e_f[r];
       }
@@ -683,14 +755,39 @@ __global__ __launch_bounds__(64) void jaco_physics_kernel(JacoStepArgs A) {
   }
   if (lane < nq) A.qpos[(size_t)env * nq + lane] = s.qpos[lane];
   if (lane < nv) { A.qvel[(size_t)env * nv + lane] = s.qvel[lane]; A.qacc_ws[(size_t)env * nv + lane] = s.qacc_ws[lane]; }
-  if (lane < ns && A.sensordata) A.sensordata[(size_t)env * ns + lane] = sens;
+  if (left == 0 && lane < ns && A.sensordata) A.sensordata[(size_t)env * ns + lane] = sens;
   unsigned long long anyf = wave_ballot(flags != 0);
   if (anyf) {
     unsigned f = flags;
     for (int o = 1; o < 64; o <<= 1) f |= (unsigned)wave_shfl_i((int)f, lane ^ o);
     if (lane == 0 && A.flags) A.flags[env] |= f;
   }
-  if (lane == 0 && A.stats) {
+  if (left == 0 && lane == 0 && A.stats) {
     A.stats[4 * env] = s.ncon; A.stats[4 * env + 1] = s.nefc; A.stats[4 * env + 2] = iters; A.stats[4 * env + 3] = s.ncand;
+  }
+  wave_sync();
+  return left;
+}
+
+// light tier: one workgroup (= one wavefront) per env
+__global__ __launch_bounds__(64, 2) void jaco_physics_kernel(JacoStepArgs A) {
+  __shared__ JacoLDS<JacoLight> s;
+  const int lane = lane_id(), env = env_id();
+  if (env >= A.nenv) return;
+  int left = run_env<JacoLight, true>(A, s, env, A.nsub, lane);
+  if (left > 0 && lane == 0) {
+    A.remaining[env] = left;
+    int slot = jaco_atomic_inc(A.heavy_count);
+    A.heavy_list[slot] = env;
+  }
+}
+// heavy tier: workgroups stride over the envs the light tier handed over
+__global__ __launch_bounds__(64) void jaco_physics_kernel_heavy(JacoStepArgs A) {
+  __shared__ JacoLDS<JacoHeavy> s;
+  const int lane = lane_id();
+  const int count = *A.heavy_count;
+  for (int i = env_id(); i < count; i += grid_size()) {
+    int env = A.heavy_list[i];
+    run_env<JacoHeavy, false>(A, s, env, A.remaining[env], lane);
   }
 }

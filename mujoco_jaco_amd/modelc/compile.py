@@ -41,6 +41,80 @@ def collision_pairs(M):
     return np.array(pairs, dtype=np.int32).reshape(-1, 2)
 
 
+def _geom_points(M, g, xpos, xquat):
+    """World-frame extreme points of a convex geom at the pose given by its body frame (mesh: hull vertices)."""
+    b = M["geom_bodyid"][g]
+    R = rot.quat_to_mat(xquat[b]) @ rot.quat_to_mat(M["geom_quat"].reshape(-1, 4)[g])
+    p = xpos[b] + rot.quat_to_mat(xquat[b]) @ M["geom_pos"].reshape(-1, 3)[g]
+    t, sz = M["geom_type"][g], M["geom_size"].reshape(-1, 3)[g]
+    if t == mjcf.GEOM_MESH:
+        md = M["geom_dataid"][g]
+        v = M["mesh_vert"].reshape(-1, 3)[M["mesh_vertadr"][md]:M["mesh_vertadr"][md] + M["mesh_vertnum"][md]]
+        return p + v @ R.T, 0.0
+    if t == mjcf.GEOM_BOX:
+        c = np.array([[sx, sy, sz_] for sx in (-1, 1) for sy in (-1, 1) for sz_ in (-1, 1)]) * sz
+        return p + c @ R.T, 0.0
+    if t == mjcf.GEOM_SPHERE:
+        return p[None, :], float(sz[0])
+    return None, 0.0
+
+
+def prune_static_pairs(M, pairs):
+    """Drop pairs that provably can never touch: a geom whose body moves only by rotation about one fixed world
+    axis sweeps a solid of revolution; if that solid is separated from a *static* geom along the axis, or radially,
+    the pair is dead for every configuration.  Exact (collision results are unchanged); it removes the permanent
+    0.2 mm near-miss link0<->link1 hull pair and its siblings from the per-step narrowphase."""
+    xpos, xquat, xanchor, xaxis = kin.fk(M, M["qpos0"])
+    weld, parent = M["body_weldid"], M["body_parentid"]
+    keep, dropped = [], []
+    for g1, g2 in pairs:
+        b1, b2 = M["geom_bodyid"][g1], M["geom_bodyid"][g2]
+        w1, w2 = weld[b1], weld[b2]
+        if (w1 == 0) == (w2 == 0):
+            keep.append((g1, g2)); continue
+        gs, gm, wm = (g1, g2, w2) if w1 == 0 else (g2, g1, w1)
+        if M["body_mocapid"][M["geom_bodyid"][gs]] >= 0:
+            keep.append((g1, g2)); continue   # mocap geoms move at run time
+        # moving body must hang off the static world through exactly one hinge
+        if weld[parent[wm]] != 0 or M["body_jntnum"][wm] != 1 or M["jnt_type"][M["body_jntadr"][wm]] != mjcf.JNT_HINGE:
+            keep.append((g1, g2)); continue
+        j = M["body_jntadr"][wm]
+        a, c = xaxis[j], xanchor[j]
+        pm, rm = _geom_points(M, gm, xpos, xquat)
+        if pm is None:
+            keep.append((g1, g2)); continue
+        hm = (pm - c) @ a
+        radm = np.linalg.norm((pm - c) - np.outer(hm, a), axis=1).max() + rm
+        hm_lo, hm_hi = hm.min() - rm, hm.max() + rm
+        if M["geom_type"][gs] == mjcf.GEOM_PLANE:
+            b = M["geom_bodyid"][gs]
+            n = (rot.quat_to_mat(xquat[b]) @ rot.quat_to_mat(M["geom_quat"].reshape(-1, 4)[gs]))[:, 2]
+            p0 = xpos[b] + rot.quat_to_mat(xquat[b]) @ M["geom_pos"].reshape(-1, 3)[gs]
+            # lowest point of the swept solid above the plane, valid when the plane normal is the rotation axis
+            if abs(abs(n @ a) - 1) < 1e-9:
+                lo = ((pm - p0) @ n).min() - rm
+                if lo > 1e-6:
+                    dropped.append((g1, g2)); continue
+            keep.append((g1, g2)); continue
+        ps, rs = _geom_points(M, gs, xpos, xquat)
+        if ps is None:
+            keep.append((g1, g2)); continue
+        hs = (ps - c) @ a
+        if hs.min() - rs > hm_hi + 1e-6 or hs.max() + rs < hm_lo - 1e-6:
+            dropped.append((g1, g2)); continue
+        # radial: the swept solid lies inside the cylinder of radius radm about the axis; if some half-space
+        # {x : perp(x).u > radm} contains the whole static geom, the two are separated for every joint angle
+        perp = (ps - c) - np.outer(hs, a)
+        cen = perp.mean(0)
+        d = np.linalg.norm(cen)
+        if d > 1e-9:
+            u = cen / d
+            if (perp @ u).min() - rs > radm + 1e-6:   # a plane with normal u separates the static geom from the swept cylinder
+                dropped.append((g1, g2)); continue
+        keep.append((g1, g2))
+    return np.array(keep, dtype=np.int32).reshape(-1, 2), dropped
+
+
 def mix_pair(M, g1, g2, timestep):
     """condim / friction / solref / solimp of a geom pair (equal priority, equal solmix)."""
     condim = max(M["geom_condim"][g1], M["geom_condim"][g2])
@@ -208,7 +282,9 @@ def compile_model(xml_name, timestep=0.001):
     M["body_invweight0"] = np.ascontiguousarray(biw.reshape(-1))
     M["dof_invweight0"] = diw
     M["meaninertia"] = np.array([meaninertia])
-    pairs = collision_pairs(M)
+    pairs_all = collision_pairs(M)
+    pairs, dropped = prune_static_pairs(M, pairs_all)
+    M["pair_geom_unpruned"] = np.ascontiguousarray(pairs_all.reshape(-1))   # kept for the oracle-side equivalence test
     M["pair_geom"] = np.ascontiguousarray(pairs.reshape(-1))
     M["npair"] = np.array([len(pairs)], dtype=np.int32)
     M.update(fuse(M, names, pairs))

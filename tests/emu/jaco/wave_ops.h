@@ -75,3 +75,13 @@ JDEV int wave_argmax(float v, int idx, float* best) {
   *best = bv;
   return bi;
 }
+
+extern int emu_grid;
+JDEV int grid_size() { return emu_grid; }
+JDEV int jaco_atomic_inc(int* p) { return (*p)++; }
+
+template <class T>
+JDEV const T* opaque_ptr(const T* p) {
+  asm volatile("" : "+r"(p));
+  return p;
+}

@@ -10,6 +10,7 @@
 
 int emu_cur_lane = 0;
 int emu_block = 0;
+int emu_grid = 1;
 EmuWord emu_x[2][64];
 unsigned emu_cnt[64];
 

@@ -25,7 +25,7 @@ def lib():
         subprocess.check_call(["make", "-s", "-C", EMU_DIR])
         L = ctypes.CDLL(os.path.join(EMU_DIR, "libjaco_emu.so"))
         fp, ip, up = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint)
-        L.emu_physics_step.argtypes = [ctypes.c_char_p, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int, fp, fp, fp, fp, fp, up, ip, fp, ctypes.c_int]
+        L.emu_physics_step.argtypes = [ctypes.c_char_p, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int, fp, fp, fp, fp, fp, up, ip, fp, ctypes.c_int, ip]
         _lib = L
     return _lib
 
@@ -52,9 +52,11 @@ class EmuEnv:
     def step(self, ctrl, nsub=1, disable_contact=False, dbg_env=-1):
         ctrl = np.ascontiguousarray(np.broadcast_to(np.asarray(ctrl, np.float32), (self.nenv, self.nu)))
         fp = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+        hv = ctypes.c_int(0)
         rc = self.L.emu_physics_step(self.blob, len(self.blob), self.nenv, nsub, int(disable_contact), fp(self.qpos), fp(self.qvel),
                                      fp(self.qacc_ws), fp(ctrl), fp(self.sensordata),
                                      self.flags.ctypes.data_as(ctypes.POINTER(ctypes.c_uint)),
                                      self.stats.ctypes.data_as(ctypes.POINTER(ctypes.c_int)),
-                                     fp(self.dbg) if dbg_env >= 0 else None, dbg_env)
+                                     fp(self.dbg) if dbg_env >= 0 else None, dbg_env, ctypes.byref(hv))
+        self.heavy_envs = hv.value
         assert rc == 0

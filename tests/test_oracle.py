@@ -177,3 +177,27 @@ def test_touch_sensor_uses_the_normal_ray(names, model_arrays):
                 assert s[k] >= fn * (1 - 1e-9)          # counted
                 checked += int(not inside)               # ... although the point is outside the site box
     assert checked >= 1 and np.all(s[14:20] == 0)        # inner pads fire, outer pads do not
+
+
+def test_static_pair_pruning_is_exact(model_arrays, tmp_path):
+    """The compiler drops pairs it proves can never touch (link1 sweeps a solid of revolution about joint0).
+    Re-running collision with the unpruned whitelist must give the same contacts in every state."""
+    import os
+    from mujoco_jaco_amd.modelc import blob
+    from oracle_binding import ASSETS
+    M = dict(model_arrays)
+    assert len(M["pair_geom_unpruned"]) > len(M["pair_geom"])
+    M["pair_geom"] = M["pair_geom_unpruned"]; M["npair"] = np.array([len(M["pair_geom"]) // 2], dtype=np.int32)
+    path = os.path.join(ASSETS, "_unpruned_tmp.jacomdl")
+    blob.save(path, M)
+    try:
+        a, b = Oracle(), Oracle("_unpruned_tmp")
+        rng = np.random.default_rng(5)
+        for _ in range(20):
+            q, v = _rand_state(model_arrays, rng)
+            q[0] = rng.uniform(-7, 7); q[9:12] = [rng.uniform(-.1, .1), .65, .2]
+            for o in (a, b):
+                o.set("qpos", q); o.set("qvel", v); o.forward()
+            assert a.ncon == b.ncon and np.array_equal(a.get("contact")[:], b.get("contact")[:])
+    finally:
+        os.remove(path)
