@@ -1,0 +1,78 @@
+"""CPU tier: oracle/glue.py against golden vectors captured from the reference's own Python
+(tests/golden/make_glue_vectors.py ran env_script/env_mujoco_util.py behind third-party stand-ins)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import glue  # noqa: E402
+
+G = np.load(os.path.join(ROOT, "tests", "golden", "glue_vectors.npz"))
+BASE = np.array([0.0, 0.0, 0.157])
+
+
+def test_get_rotation():
+    for r, inv, out in zip(G["rot_in"], G["rot_inv"], G["rot_out"]):
+        assert np.allclose(glue.get_rotation(r[0], r[1], r[2], r[3:6], bool(inv)), out, atol=1e-14)
+
+
+def test_touch_class_bit_exact():
+    got = np.array([glue.touch_class(s) for s in G["touch_sens"]])
+    assert np.array_equal(got, G["touch_class"])
+    assert set(G["touch_class"].tolist()) == {0, 1, 2, 3}
+
+
+def test_reward_picking():
+    for k in range(len(G["s_ee"])):
+        r = glue.reward_picking(G["s_ee"][k], G["s_eeq"][k], G["s_obj"][k], G["s_touch"][k])
+        assert abs(r - G["s_reward"][k]) < 1e-12
+
+
+@pytest.mark.parametrize("task,key", [("picking", "s_term_pick"), ("placing", "s_term_place")])
+def test_terminal_flags_bit_exact(task, key):
+    seen = set()
+    for k in range(len(G["s_ee"])):
+        done, bonus, wb, succ = glue.terminal(task, G["s_q2"][k], G["s_ee"][k], G["s_obj"][k], G["s_dest_goal"][k], int(G["s_touch"][k]),
+                                              int(G["s_nsteps"][k]), BASE)
+        e = G[key][k]
+        assert (bool(e[0]), int(e[3])) == (done, succ)                 # done / success: exact
+        assert abs(e[1] - bonus) < 1e-12 and abs(e[2] - wb) < 1e-12
+        seen.add((done, succ, bonus < 0))
+    assert len(seen) >= 3   # the fixture exercises continue / success / failure branches
+
+
+def test_env_timeout():
+    for n in G["timeout_steps"]:
+        done, bonus, wb, succ = glue.env_terminal("picking", int(n) - 1, 1.2, [0, .4, .3], [0, .65, .2], [.4, .3, .35], 0, 5, BASE)
+        assert done == (n >= G["timeout_expect_done_at"][0])
+        if done:
+            assert (bonus, wb, succ) == (-10.0, 0.0, 0)
+
+
+def test_subgoal_and_observation():
+    for k in range(len(G["s_ee"])):
+        nz = G["s_noise"][k]
+        pos, ori = glue.rulebased_subgoal("picking", G["s_ee"][k], G["s_obj_goal"][k], G["s_obj"][k][1], G["s_dest_goal"][k], nz[:6])
+        assert np.allclose(pos, G["s_sub_pos"][k], atol=1e-12) and np.allclose(ori, G["s_sub_ori"][k], atol=1e-10)
+        touch = glue.touch_class(nz[6:])
+        obs = glue.observation("picking", touch, G["s_ee"][k], G["s_eeq"][k], G["s_grip"][k], G["s_obj"][k], G["s_dest_goal"][k],
+                               G["s_obj_goal"][k], nz[:6])
+        assert obs.dtype == np.float32 and obs.shape == (26,)
+        assert np.allclose(obs, G["s_obs"][k], atol=2e-7)
+
+
+def test_take_action():
+    for k in range(len(G["s_ee"])):
+        a, g0 = G["s_act"][k][:7], G["s_act"][k][7]
+        target, grip, ramp = glue.take_action(G["s_ee"][k], G["s_eeq"][k], a, g0)
+        assert np.allclose(target, G["s_target"][k], atol=1e-12)
+        assert abs(grip - G["s_grip_after"][k]) < 1e-15 and np.allclose(ramp, G["s_ramp"][k], atol=1e-15)
+        assert np.allclose(G["s_mocap_hand_pos"][k], target[:3], atol=1e-12)
+        q = glue.quat_from_euler(*target[3:6]); e = G["s_mocap_hand_quat"][k]
+        assert min(np.abs(q - e).max(), np.abs(q + e).max()) < 1e-12
+        # the marker placement consumes the 6 draws of the first _get_rulebased_subgoal call of the step
+        pos, ori = glue.rulebased_subgoal("picking", G["s_ee"][k], G["s_obj_goal"][k], G["s_obj"][k][1], G["s_dest_goal"][k], G["s_noise_act"][k])
+        assert np.allclose(pos, G["s_mocap_sub_pos"][k], atol=1e-12)
