@@ -4,10 +4,11 @@
   python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
 
 Workload: 65 536 environments per GPU, full Jaco + 3-finger gripper +
-table/object contacts, states drawn from the reference's `picking` reset distribution, random motor
-torques (ctrl-level entry jaco_physics_step), inputs resident in HBM.  One "step" = one env step =
-`--frame-skip` physics substeps for every env of the batch (default 1 = the ctrl-level number; the
-reference's drop-in value is 50, env_mujoco.py:24 -- pass --frame-skip 50 for that).
+table/object contacts, states drawn from the reference's `picking` reset distribution, inputs resident in HBM.
+Default `--level env`: one "step" = one JacoMujocoEnv.step (env_mujoco.py:116-139) for every env of the batch:
+random actions U(-1,1)^7 -> _take_action, `--frame-skip` (default 50 = the reference, env_mujoco.py:24) substeps of
+operational-space control + physics, observation, reward, termination (jaco_step).  `--level ctrl` times the ctrl-level
+entry jaco_physics_step (random motor torques, `--frame-skip` substeps per step, default 1) used for oracle parity.
 Environments are independent, so ranks shard them with no data-path collective; the only collective is
 the per-step all_gather of the observation rows, as the north star prescribes.
 Also reports: roofline of the physics kernel (algorithmic bytes / HIP-event kernel time vs 8 TB/s) and,
@@ -56,7 +57,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=65536, help="environments per GPU")
-    ap.add_argument("--frame-skip", type=int, default=1)
+    ap.add_argument("--frame-skip", type=int, default=None)
+    ap.add_argument("--level", choices=["env", "ctrl"], default="env")
     ap.add_argument("--model", default="jaco2_curtain_torque")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -79,19 +81,35 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
 
-    B, fs = args.batch, args.frame_skip
+    B = args.batch
+    fs = args.frame_skip if args.frame_skip is not None else (50 if args.level == "env" else 1)
     M = blob.load(os.path.join(ROOT, "mujoco_jaco_amd", "assets", args.model + ".jacomdl"))
-    env = BatchedMujoco(B, robot_file=args.model, device=local_rank, frame_skip=fs, seed=rank)
-    q = torch.tensor(workload.reset_states(M["qpos0"], B, seed=1000 + rank), dtype=torch.float32, device=dev)
-    ctrl = torch.tensor(workload.random_ctrl(B, seed=2000 + rank, scale=0.2)[:, :env.nu].copy(), dtype=torch.float32, device=dev)
-    env.set_state(q, None, None)
-    gathered = torch.empty(world * B, env.nq, device=dev) if world > 1 else None
+    if args.level == "env":
+        from mujoco_jaco_amd.env import JacoBatchedEnv
+        genv = JacoBatchedEnv(num_envs=B, device=local_rank, frame_skip=fs, seed=1000 + rank, task="picking", robot_file=args.model)
+        env = genv.sim
+        obs = genv.reset()
+        gen = torch.Generator(device=dev); gen.manual_seed(2000 + rank)
+        actions = [torch.rand(B, 7, device=dev, generator=gen) * 2 - 1 for _ in range(4)]
+        gathered = torch.empty(world * B, 26, device=dev) if world > 1 else None
+        it = [0]
 
-    def step():
-        env.send_forces(ctrl, nsub=fs)
-        if world > 1:  # one collective per rollout step: concatenate the observation rows of all shards
-            qpos, _, _ = env.state_views()
-            dist.all_gather_into_tensor(gathered, qpos)
+        def step():
+            o, r, d, _ = genv.step(actions[it[0] % 4]); it[0] += 1
+            if world > 1:  # one collective per rollout step: concatenate the observation rows of all shards
+                dist.all_gather_into_tensor(gathered, o)
+    else:
+        env = BatchedMujoco(B, robot_file=args.model, device=local_rank, frame_skip=fs, seed=rank)
+        q = torch.tensor(workload.reset_states(M["qpos0"], B, seed=1000 + rank), dtype=torch.float32, device=dev)
+        ctrl = torch.tensor(workload.random_ctrl(B, seed=2000 + rank, scale=0.2)[:, :env.nu].copy(), dtype=torch.float32, device=dev)
+        env.set_state(q, None, None)
+        gathered = torch.empty(world * B, env.nq, device=dev) if world > 1 else None
+
+        def step():
+            env.send_forces(ctrl, nsub=fs)
+            if world > 1:
+                qpos, _, _ = env.state_views()
+                dist.all_gather_into_tensor(gathered, qpos)
 
     for _ in range(args.warmup):
         step()
@@ -119,22 +137,26 @@ def main():
         # algorithmic HBM bytes of one launch of jaco_physics_kernel per env (DESIGN.md "Measurement"):
         # reads qpos, qvel, qacc_warmstart, ctrl; writes qpos, qvel, qacc_warmstart, sensordata.
         bytes_per_env = 4 * (2 * env.nq + 4 * env.nv + env.nu + env.nsensor)
+        if args.level == "env":  # + action in, obs / reward / done out, task and controller-cache rows in and out
+            bytes_per_env = 4 * (2 * env.nq + 4 * env.nv + env.nsensor + 7 + 26 + 1 + 2 * 32 + 2 * 96) + 1
         achieved = bytes_per_env * B / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
         out = {
-            "metric": "env-steps/sec at batch 65 536 (physics step, full Jaco + gripper + contacts)",
+            "metric": "env-steps/sec at batch 65 536 (full Jaco + gripper + contacts)",
             "value": world * B * args.steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "config3: %d envs/GPU, %s, picking reset distribution, random motor ctrl, ctrl-level jaco_physics_step"
-                                   % (B, args.model),
+            "config": {"workload": "config3: %d envs/GPU, %s, picking reset distribution, %s"
+                                   % (B, args.model, "random actions, env-level jaco_step (OSC + %d substeps + obs/reward/done)" % fs
+                                      if args.level == "env" else "random motor ctrl, ctrl-level jaco_physics_step"),
+                       "level": args.level,
                        "envs_per_gpu": B, "frame_skip": fs, "substeps_per_s": world * B * args.steps * fs / dt,
-                       "sharding": "independent env shards per rank" + ("; one all_gather of [B,%d] f32 rows per step" % env.nq if world > 1 else ""),
+                       "sharding": "independent env shards per rank" + ("; one all_gather of [B,%d] f32 rows per step" % (26 if args.level == "env" else env.nq) if world > 1 else ""),
                        "mean_contacts": float(stats[0]), "mean_rows": float(stats[1]), "mean_newton_iters": float(stats[2]), "flags_or": flags,
                        "heavy_tier_fraction": float(((env.flags() & 32) != 0).float().mean().item())},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "kernel": "jaco_physics_kernel", "kernel_ms": kern_ms, "launches": launches,
                          "algorithmic_bytes_per_env_launch": bytes_per_env,
-                         "note": "latency/occupancy-bound by design (SURVEY 8d): algorithmic traffic is ~0.6 KB per env per launch"},
+                         "note": "latency/occupancy-bound by design (SURVEY 8d): algorithmic traffic is ~1 KB per env per launch"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.model, fs)

@@ -37,6 +37,7 @@ extern "C" {
 #define JACO_FLAG_NAN 8u            /* non-finite velocity: env should be reset */
 #define JACO_FLAG_SOLVER_MAXITER 16u
 #define JACO_FLAG_HEAVY_TIER 32u     /* informational: stepped by the 256-row tier at least once (not an error) */
+#define JACO_FLAG_OSC_SINGULAR 64u   /* |det(J M^-1 J^T)| < 1e-3: abr_control would switch to the SVD pseudo-inverse (not implemented) */
 
 /* task ids (env_script/env_mujoco.py:18-23; only picking/placing return the 4-tuple step() unpacks) */
 #define JACO_TASK_PICKING 0
@@ -88,6 +89,28 @@ int jaco_get_sensordata(JacoHandle* h, float* out_dev, void* stream);
 int jaco_get_flags(JacoHandle* h, uint32_t* out_dev, void* stream);
 int jaco_clear_flags(JacoHandle* h, void* stream);
 int jaco_get_stats(JacoHandle* h, int32_t* out_dev, void* stream);
+
+/* ---- env level: JacoMujocoEnv.reset / step (env_script/env_mujoco.py:99-139), batched -------------------------
+ * jaco_reset: _reset (env_mujoco_util.py:92-174) for the envs whose mask byte is non-zero (NULL = all): counter-based
+ *   RNG draws of the per-task initial state (Appendix A of SURVEY.md), sim.forward(), then _get_observation for every
+ *   env into obs_dev [num_envs][26].  Task `placing` (object in hand + 150 held substeps) is not implemented yet.
+ * jaco_step: clip is the caller's job (env_mujoco.py:117 np.clip); then _take_action, frame_skip x (OSC torque +
+ *   sim.step()), make_observation, _get_reward, terminal_inspection.  action_dev [num_envs][7] (6 for reaching),
+ *   obs_dev [num_envs][26] f32, reward_dev [num_envs] f32, done_dev [num_envs] u8.  An env that returned done stays
+ *   frozen (done = 1, reward 0, obs row untouched) until it is reset: there is no auto-reset inside the library.
+ * jaco_forward: sim.forward() + _get_observation from the current state (after jaco_set_state / jaco_set_task_state).
+ * jaco_set_noise: optional [num_envs][12] uniform draws replacing the internal RNG for the rule-based sub-goal noise
+ *   (6 for the marker placed in _take_action, 6 for the observation; env_mujoco_util.py:279,295); NULL restores the RNG.
+ * Task rows ([num_envs][jaco_task_row_floats()], layout JT_* in csrc/env_logic.h) expose gripper command, step
+ *   counters, goals and the success flag (get_wb / accum_succ bookkeeping stay on the host side). */
+int jaco_reset(JacoHandle* h, const uint8_t* mask_dev, float* obs_dev, void* stream);
+int jaco_step(JacoHandle* h, const float* action_dev, float* obs_dev, float* reward_dev, uint8_t* done_dev, void* stream);
+int jaco_forward(JacoHandle* h, float* obs_dev, void* stream);
+int jaco_set_noise(JacoHandle* h, const float* noise_dev);
+int jaco_get_task_state(JacoHandle* h, float* out_dev, void* stream);
+int jaco_set_task_state(JacoHandle* h, const float* in_dev, void* stream);
+int jaco_task_row_floats(void);
+int jaco_set_frame_skip(JacoHandle* h, int frame_skip);
 
 /* Solver / collision options, MuJoCo <option> names: "iterations", "tolerance", "ls_iterations",
  * "disable_contact" (contact flag), "mpr_iterations", "mpr_tolerance". */

@@ -34,6 +34,14 @@ SYMBOLS = {
     "jaco_clear_flags": (_ci, [_vp, _vp]),
     "jaco_get_stats": (_ci, [_vp, _vp, _vp]),
     "jaco_set_option": (_ci, [_vp, _cp, _cd]),
+    "jaco_reset": (_ci, [_vp, _vp, _vp, _vp]),
+    "jaco_step": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "jaco_forward": (_ci, [_vp, _vp, _vp]),
+    "jaco_set_noise": (_ci, [_vp, _vp]),
+    "jaco_get_task_state": (_ci, [_vp, _vp, _vp]),
+    "jaco_set_task_state": (_ci, [_vp, _vp, _vp]),
+    "jaco_task_row_floats": (_ci, []),
+    "jaco_set_frame_skip": (_ci, [_vp, _ci]),
     "jaco_physics_step_debug": (_ci, [_vp, _vp, _ci, _ci, ctypes.POINTER(ctypes.c_float), _ci]),
     "jaco_debug_dump_floats": (_ci, []),
     "jaco_kernel_time_ms": (_ci, [_vp, ctypes.POINTER(_cd), _ip]),

@@ -1,0 +1,283 @@
+// Env-level task logic executed inside the physics kernels.
+// Included by physics_kernel.h.  Everything here mirrors /root/reference/env_script/env_mujoco_util.py and
+// env_mujoco.py; the operational-space controller mirrors abr_control's OSC.generate [EXT, SURVEY App. D.2].
+//
+// Staleness: the reference's controller reads qpos/qvel of the current substep but J, M, qfrc_bias and the
+// EE pose from mjData, i.e. from the forward pass of the *previous* substep; likewise the observation reads body poses
+// and sensordata computed at the start of the last substep.  In this kernel those quantities are simply still in LDS
+// from the previous substep when the controller runs (and are carried across launches in the per-env cache row).
+#pragma once
+
+// per-env task row (floats)
+#define JT_GRIP 0        // gripper command angle (env_mujoco_util.py:96,629-630)
+#define JT_STEPS 1       // JacoMujocoEnv.current_steps
+#define JT_EPISODES 2    // JacoMujocoEnvUtil.num_episodes
+#define JT_DONE 3        // 1 after a terminal step until the env is reset (frozen)
+#define JT_OBJGOAL 4     // [3]
+#define JT_DESTGOAL 7    // [3]
+#define JT_TARGET 10     // [6] EE target pose (xyz + euler rxyz)
+#define JT_GRIP_PREV 16
+#define JT_SUB 17        // substep index inside the current env step (tier hand-off)
+#define JT_RNG 18        // draw counter (bit pattern of an unsigned)
+#define JT_PENDING 19    // 1: JT_CTRL holds the ctrl of the interrupted substep
+#define JT_CTRL 20       // [9]
+#define JT_SUCC 29       // success flag of the last terminal step
+#define JT_WB 30         // last |EE - base| (get_wb)
+#define JTASK_N 32
+// per-env cache row: what the controller reads one substep late
+#define JC_M 0           // [6][6] arm block of the mass matrix
+#define JC_BIAS 36       // [6]
+#define JC_CDOF 42       // [6][6] motion subspaces of the arm dofs
+#define JC_EEPOS 78      // [3] frame of the body carrying the EE
+#define JC_EEMAT 81      // [9]
+#define JC_OBJPOS 90     // [3] object body position
+#define JCACHE_N 96
+
+#define JFLAG_OSC_SINGULAR 64u
+
+#define JOSC_KP 50.f
+#define JOSC_KO 180.f
+#define JOSC_KV 20.f
+#define JOSC_VMAX_XYZ 0.4f
+#define JOSC_VMAX_ABG 1.0472f
+
+// ---------------------------------------------------------------- small rotation helpers
+JDEV void mat_to_euler_rxyz(const m3& M, float* e) {   // Gohlke euler_from_matrix(..., 'rxyz'): R = Rx(a) Ry(b) Rz(c)
+  float cy = sqrtf(M.m[8] * M.m[8] + M.m[5] * M.m[5]);
+  if (cy > 8.8e-16f) { e[0] = atan2f(-M.m[5], M.m[8]); e[1] = atan2f(M.m[2], cy); e[2] = atan2f(-M.m[1], M.m[0]); }
+  else { e[0] = 0.f; e[1] = atan2f(M.m[2], cy); e[2] = atan2f(M.m[3], M.m[4]); }
+}
+JDEV void euler_rxyz_to_quat(float a, float b, float c, float* q) {
+  float ca = cosf(0.5f * a), sa = sinf(0.5f * a), cb = cosf(0.5f * b), sb = sinf(0.5f * b), cc = cosf(0.5f * c), sc = sinf(0.5f * c);
+  // qx(a) * qy(b) * qz(c)
+  float w1 = ca * cb, x1 = sa * cb, y1 = ca * sb, z1 = sa * sb;
+  q[0] = w1 * cc - z1 * sc; q[1] = x1 * cc + y1 * sc; q[2] = y1 * cc - x1 * sc; q[3] = w1 * sc + z1 * cc;
+}
+JDEV void mat_to_quat(const m3& R, float* q) {
+  float t = R.m[0] + R.m[4] + R.m[8];
+  if (t > 0.f) {
+    float s = sqrtf(t + 1.f) * 2.f;
+    q[0] = 0.25f * s; q[1] = (R.m[7] - R.m[5]) / s; q[2] = (R.m[2] - R.m[6]) / s; q[3] = (R.m[3] - R.m[1]) / s;
+  } else if (R.m[0] > R.m[4] && R.m[0] > R.m[8]) {
+    float s = sqrtf(1.f + R.m[0] - R.m[4] - R.m[8]) * 2.f;
+    q[0] = (R.m[7] - R.m[5]) / s; q[1] = 0.25f * s; q[2] = (R.m[1] + R.m[3]) / s; q[3] = (R.m[2] + R.m[6]) / s;
+  } else if (R.m[4] > R.m[8]) {
+    float s = sqrtf(1.f + R.m[4] - R.m[0] - R.m[8]) * 2.f;
+    q[0] = (R.m[2] - R.m[6]) / s; q[1] = (R.m[1] + R.m[3]) / s; q[2] = 0.25f * s; q[3] = (R.m[5] + R.m[7]) / s;
+  } else {
+    float s = sqrtf(1.f + R.m[8] - R.m[0] - R.m[4]) * 2.f;
+    q[0] = (R.m[3] - R.m[1]) / s; q[1] = (R.m[2] + R.m[6]) / s; q[2] = (R.m[5] + R.m[7]) / s; q[3] = 0.25f * s;
+  }
+}
+JDEV void quat_to_euler_rxyz(const float* q, float* e) {
+  float n = rsqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  m3 M = quat2mat(q[0] * n, q[1] * n, q[2] * n, q[3] * n);
+  mat_to_euler_rxyz(M, e);
+}
+
+// counter-based uniform [0,1) (the reference draws from the global, unseeded numpy RNG: not reproducible by design)
+JDEV float rng_uniform(unsigned long long seed, unsigned env, unsigned counter) {
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * ((unsigned long long)env * 0x100000001ull + counter + 1ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+// EE frame from the (stale) frame of the body that carries it
+template <class L>
+JDEV void ee_frame(const JacoModelDev* m, const L& s, v3* pos, m3* R) {
+  int eb = m->ee_body;
+  m3 Rb = ldm(s.xmat[eb]);
+  *pos = ld3(s.xpos[eb]) + mul(Rb, ld3(m->ee_pos));
+  *R = mul(Rb, ldm(m->ee_mat));
+}
+
+// ---------------------------------------------------------------- a8: rule-based subgoal (env_mujoco_util.py:273-300)
+JDEV void rulebased_subgoal(int task, v3 ee, v3 obj_goal, float obj_y, v3 dest_goal, const float* nz, float* pos, float* ori) {
+  v3 D = ee - obj_goal;
+  float dn = norm(D);
+  v3 p = D * (0.12f / dn) + obj_goal + mk3((nz[0] - 0.5f) / 25.f, (nz[1] - 0.5f) / 25.f, (nz[2] - 0.5f) / 25.f);
+  if (p.z < 0.1898f + 0.1f) p.z = 0.1898f + 0.1f;
+  if (p.y > obj_y - 0.15f) p.y = obj_y - 0.15f;
+  v3 x = D * (-1.f / dn);
+  const float s2 = 0.70710678118654752f, s3 = 0.86602540378443865f;
+  float qv[4] = {s2, s2 * x.x, s2 * x.y, s2 * x.z}, qd[4] = {s3, 0.5f * x.x, 0.5f * x.y, 0.5f * x.z}, rv[3], rd[3];
+  quat_to_euler_rxyz(qv, rv);
+  quat_to_euler_rxyz(qd, rd);
+  v3 c = cross(mk3(rv[0], rv[1], rv[2]), mk3(rd[0], rd[1], rd[2]));
+  ori[0] = c.x - 1.57079632679489662f + (nz[3] - 0.5f) / 10.f;
+  ori[1] = c.y + (nz[4] - 0.5f) / 10.f;
+  ori[2] = c.z + (nz[5] - 0.5f) / 10.f;
+  pos[0] = p.x; pos[1] = p.y; pos[2] = p.z;
+  if (task == 1) {  // placing (:297-298)
+    pos[0] = dest_goal.x; pos[1] = dest_goal.y; pos[2] = dest_goal.z;
+    ori[0] = 0.f; ori[1] = 1.57079632679489662f; ori[2] = 0.f;
+  }
+}
+
+// ---------------------------------------------------------------- a9: touch class (env_mujoco_util.py:470-490); sens in XML order
+JDEV int touch_class(float sens, int lane) {
+  // touch_array[i] = "i_touch" = sensordata[1 + i] (i = 0..18), touch_array[19] = EE_touch = sensordata[0]
+  bool hit = sens > 0.001f;
+  unsigned long long m = wave_ballot(hit && lane < JNSENS);
+  unsigned long long arr = ((m >> 1) & 0x7FFFFull) | ((m & 1ull) << 19);
+  bool thumb = (arr & 0x1Eull) != 0, index = (arr & 0x1E0ull) != 0, pinky = (arr & 0x1E00ull) != 0;
+  if ((thumb && index) || (thumb && pinky)) return 3;
+  if (arr & 0x1FFFull) return 1;
+  if (arr & 0xFE000ull) return 2;
+  return 0;
+}
+
+// ---------------------------------------------------------------- a10: picking reward (env_mujoco_util.py:392-431)
+JDEV float reward_picking(v3 ee, const float* eul, v3 obj, int touch) {
+  float cr = cosf(eul[0]), sr = sinf(eul[0]), cp = cosf(eul[1]), sp = sinf(eul[1]);
+  // Rx(r) Ry(p) Rz(y) applied to (0,0,-1): third column negated
+  v3 ee_vec = mk3(-sp, sr * cp, -cr * cp);
+  v3 d = obj - ee;
+  float dn = norm(d);
+  v3 u = d * (1.f / dn);
+  float pitch = -acosf(u.z), yaw = -acosf(-u.x / sqrtf(1.f - u.z * u.z));
+  // rot_ee^T (0,0,1) with roll = 0: third row of Ry(pitch) Rz(yaw)
+  float cpi = cosf(pitch), spi = sinf(pitch), cya = cosf(yaw), sya = sinf(yaw);
+  v3 tv = mk3(-spi * cya, spi * sya, -cpi);   // (z already negated: target_vec[2] *= -1)
+  float ang = norm(ee_vec - tv);
+  float r = 2.5f * expf(-dn / 0.2f) + expf(-ang / 0.52359877559829887f) / (dn * 15.f + 1.f);
+  r += touch == 1 ? 0.75f : (touch == 2 ? -0.75f : (touch == 3 ? 2.5f : 0.f));
+  r += 100.f * (obj.z - 0.1898f);
+  return r * 0.01f;
+}
+
+// ---------------------------------------------------------------- a11: termination (env_mujoco.py:144-150, env_mujoco_util.py:492-582)
+// returns done; *bonus, *succ; updates steps / episodes counters in the task row
+JDEV bool terminal_inspection(int task, float* trow, float q2, v3 ee, v3 base, v3 obj, v3 dest_goal, int touch, float* bonus, int* succ, float* wb) {
+  float steps = trow[JT_STEPS] + 1.f;
+  trow[JT_STEPS] = steps;
+  const float task_max = 700.f;   // picking / placing (env_mujoco.py:20-21)
+  *succ = 0; *wb = 0.f;
+  if (!(steps < task_max)) { *bonus = -10.f; return true; }
+  float n = trow[JT_EPISODES] + 1.f;
+  trow[JT_EPISODES] = n;
+  *wb = norm(ee - base);
+  const float PI = 3.14159265358979323846f;
+  if (PI - 0.1f < q2 && q2 < PI + 0.1f) { *bonus = -1.f; return true; }
+  if (task == 0) {
+    if (obj.z > 0.1898f + 0.07f && (touch == 1 || touch == 3)) { *bonus = 200.f - n * 0.1f; *succ = 1; return true; }
+    if (obj.z < 0.1f) { *bonus = -20.f; return true; }
+    *bonus = 0.f;
+    return false;
+  }
+  float dx = dest_goal.x - obj.x, dy = dest_goal.y - obj.y, dd = sqrtf(dx * dx + dy * dy);
+  if (obj.z < 0.1f) { *bonus = -20.f; return true; }
+  if (dd < 0.02f && touch == 0 && obj.z < 0.35f) { *bonus = 200.f - n * 0.1f; *succ = 1; return true; }
+  if (dd > 0.02f && touch == 0 && obj.z < 0.20f) { *bonus = -20.f; return true; }
+  *bonus = 0.f;
+  return false;
+}
+
+// ---------------------------------------------------------------- a4/a5: operational-space controller on the wave
+// 6x6 Gauss-Jordan, one matrix row per lane (lanes 0..5), no pivoting (SPD input). B in: identity row; out: inverse row.
+JDEV float gj_inverse6(float (&A)[6], float (&B)[6], int lane) {
+  float det = 1.f;
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    float piv = wave_bcast(A[k], k);
+    det *= piv;
+    float inv = 1.f / piv, sc = lane == k ? inv : 1.f;
+#pragma unroll
+    for (int j = 0; j < 6; j++) { A[j] *= sc; B[j] *= sc; }
+    float f = lane == k ? 0.f : A[k];
+#pragma unroll
+    for (int j = 0; j < 6; j++) { A[j] -= f * wave_bcast(A[j], k); B[j] -= f * wave_bcast(B[j], k); }
+  }
+  return det;
+}
+
+// Writes the six arm torques into s.ctrl[0..5].  Scratch: the (not yet built) constraint-row area s.J.
+template <class L>
+JDEV void stage_osc(const JacoModelDev* m, L& s, int lane, unsigned& flags) {
+  float* Jm = s.J;            // [6][6] J[r][c], rows: 3 translational, 3 rotational; columns: arm dofs
+  float* Mi = s.J + 36;       // M^-1
+  float* T = s.J + 72;        // M^-1 J^T
+  float* X = s.J + 108;       // J M^-1 J^T, then its (pseudo-)inverse Mx
+  float* w = s.J + 144;       // Mx u_task
+  v3 pe; m3 Re;
+  ee_frame(m, s, &pe, &Re);
+  const int r = lane / 6, c = lane - 6 * r;   // lanes 0..35 = matrix entry (r, c)
+  if (lane < 6) {
+    sv S = ldsv(s.cdof[lane]);
+    v3 jp = S.b + cross(S.a, pe);
+    Jm[0 * 6 + lane] = jp.x; Jm[1 * 6 + lane] = jp.y; Jm[2 * 6 + lane] = jp.z;
+    Jm[3 * 6 + lane] = S.a.x; Jm[4 * 6 + lane] = S.a.y; Jm[5 * 6 + lane] = S.a.z;
+  }
+  // M^-1 (lanes 0..5 own rows)
+  float A[6], B[6];
+  int i = lane < 6 ? lane : 0;
+#pragma unroll
+  for (int j = 0; j < 6; j++) { A[j] = s.M[i * JNV + j]; B[j] = (lane == j) ? 1.f : 0.f; }
+  gj_inverse6(A, B, lane);
+  if (lane < 6) for (int j = 0; j < 6; j++) Mi[lane * 6 + j] = B[j];
+  wave_sync();
+  if (lane < 36) { float a = 0.f; for (int k = 0; k < 6; k++) a += Mi[r * 6 + k] * Jm[c * 6 + k]; T[lane] = a; }
+  wave_sync();
+  if (lane < 36) { float a = 0.f; for (int k = 0; k < 6; k++) a += Jm[r * 6 + k] * T[k * 6 + c]; X[lane] = a; }
+  wave_sync();
+#pragma unroll
+  for (int j = 0; j < 6; j++) { A[j] = X[i * 6 + j]; B[j] = (lane == j) ? 1.f : 0.f; }
+  float det = gj_inverse6(A, B, lane);
+  // abr_control: plain inverse when |det| >= 1e-3, else SVD pseudo-inverse dropping singular values < 0.005.
+  // The pseudo-inverse branch is not implemented yet: flagged, plain inverse used (DESIGN.md "Next").
+  if (fabsf(det) < 1e-3f) flags |= JFLAG_OSC_SINGULAR;
+  // task-space error (uniform across lanes)
+  const float* tg = s.task + JT_TARGET;
+  float ut[6];
+  ut[0] = pe.x - tg[0]; ut[1] = pe.y - tg[1]; ut[2] = pe.z - tg[2];
+  float qd[4], qe[4];
+  euler_rxyz_to_quat(tg[3], tg[4], tg[5], qd);
+  float qn = rsqrtf(qd[0] * qd[0] + qd[1] * qd[1] + qd[2] * qd[2] + qd[3] * qd[3]);
+  for (int k = 0; k < 4; k++) qd[k] *= qn;
+  mat_to_quat(Re, qe);
+  // q_e = q_d * conj(q_EE)
+  float cw = qe[0], cx = -qe[1], cy = -qe[2], cz = -qe[3];
+  float ew = qd[0] * cw - qd[1] * cx - qd[2] * cy - qd[3] * cz;
+  float ex = qd[0] * cx + qd[1] * cw + qd[2] * cz - qd[3] * cy;
+  float ey = qd[0] * cy - qd[1] * cz + qd[2] * cw + qd[3] * cx;
+  float ez = qd[0] * cz + qd[1] * cy - qd[2] * cx + qd[3] * cw;
+  float sg = ew > 0.f ? 1.f : (ew < 0.f ? -1.f : 0.f);
+  ut[3] = -ex * sg; ut[4] = -ey * sg; ut[5] = -ez * sg;
+  // velocity limiting (vmax = [0.4, 1.0472]) then gains: u_task <- kv * scale * lambda * u_task
+  float nx = sqrtf(ut[0] * ut[0] + ut[1] * ut[1] + ut[2] * ut[2]), na = sqrtf(ut[3] * ut[3] + ut[4] * ut[4] + ut[5] * ut[5]);
+  const float sat_xyz = JOSC_VMAX_XYZ / JOSC_KP * JOSC_KV, sat_abg = JOSC_VMAX_ABG / JOSC_KO * JOSC_KV;
+  float sx = nx > sat_xyz ? sat_xyz / nx : 1.f, sa = na > sat_abg ? sat_abg / na : 1.f;
+  for (int k = 0; k < 3; k++) { ut[k] *= JOSC_KP * sx; ut[3 + k] *= JOSC_KO * sa; }
+  if (lane < 6) { float a = 0.f; for (int k = 0; k < 6; k++) a += B[k] * ut[k]; w[lane] = a; }   // row `lane` of Mx
+  wave_sync();
+  if (lane < 6) {
+    float u = s.bias[lane];
+    for (int k = 0; k < 6; k++) u -= JOSC_KV * s.M[lane * JNV + k] * s.qvel[k] + Jm[k * 6 + lane] * w[k];
+    s.ctrl[lane] = u;
+  }
+  wave_sync();
+}
+
+// ---------------------------------------------------------------- a2: action -> target / gripper ramp (env_mujoco_util.py:602-646)
+template <class L>
+JDEV void take_action(const JacoModelDev* m, L& s, const float* act, int nact, int lane) {
+  v3 pe; m3 Re;
+  ee_frame(m, s, &pe, &Re);
+  float eul[3];
+  mat_to_euler_rxyz(Re, eul);
+  if (lane == 0) {
+    float* t = s.task;
+    t[JT_TARGET + 0] = pe.x + act[0] / 25.f; t[JT_TARGET + 1] = pe.y + act[1] / 25.f; t[JT_TARGET + 2] = pe.z + act[2] / 25.f;
+    t[JT_TARGET + 3] = eul[0] + act[3] / 5.f; t[JT_TARGET + 4] = eul[1] + act[4] / 5.f;
+    float yaw = eul[2] + act[5] / 5.f;
+    const float PI = 3.14159265358979323846f;
+    if (fabsf(yaw) > PI) yaw += (yaw > 0.f ? -1.f : 1.f) * 2.f * PI;
+    t[JT_TARGET + 5] = yaw;
+    float prev = t[JT_GRIP], g = 0.6f;
+    if (nact == 7) g = fminf(1.f, fmaxf(0.6f, prev + act[6] / 10.f));
+    t[JT_GRIP_PREV] = nact == 7 ? prev : 0.6f;
+    t[JT_GRIP] = g;
+  }
+}

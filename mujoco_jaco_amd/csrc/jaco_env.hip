@@ -25,6 +25,8 @@ struct JacoHandle {
   unsigned* flags = nullptr;
   int* stats = nullptr;
   int *remaining = nullptr, *heavy_list = nullptr, *heavy_count = nullptr;
+  float *task_rows = nullptr, *cache = nullptr;
+  const float* noise = nullptr;
   unsigned long long* prof = nullptr;
   std::vector<float> qpos0;
   int num_envs = 0, device = 0, frame_skip = 50, task = 0, disable_contact = 0;
@@ -95,6 +97,10 @@ extern "C" int jaco_create(const JacoConfig* cfg, JacoHandle** out) {
   CREATECHK(hipMalloc(&h->heavy_list, B * sizeof(int)));
   CREATECHK(hipMalloc(&h->heavy_count, sizeof(int)));
   CREATECHK(hipMemset(h->remaining, 0, B * sizeof(int)));
+  CREATECHK(hipMalloc(&h->task_rows, B * JTASK_N * sizeof(float)));
+  CREATECHK(hipMalloc(&h->cache, B * JCACHE_N * sizeof(float)));
+  CREATECHK(hipMemset(h->task_rows, 0, B * JTASK_N * sizeof(float)));
+  CREATECHK(hipMemset(h->cache, 0, B * JCACHE_N * sizeof(float)));
   CREATECHK(hipMemcpy(h->model_dev, &h->model_host, sizeof(JacoModelDev), hipMemcpyHostToDevice));
   CREATECHK(hipMemcpy(h->hull_dev, hull.data(), hull.size() * sizeof(float), hipMemcpyHostToDevice));
   CREATECHK(hipMemset(h->flags, 0, B * sizeof(unsigned)));
@@ -129,7 +135,7 @@ extern "C" int jaco_destroy(JacoHandle* h) {
   if (!h) return JACO_EINVAL;
   (void)hipSetDevice(h->device);
   for (auto& e : h->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-  void* ptrs[] = {h->model_dev, h->hull_dev, h->qpos, h->qvel, h->qacc_ws, h->sensordata, h->flags, h->stats, h->dbg, h->prof, h->remaining, h->heavy_list, h->heavy_count};
+  void* ptrs[] = {h->model_dev, h->hull_dev, h->qpos, h->qvel, h->qacc_ws, h->sensordata, h->flags, h->stats, h->dbg, h->prof, h->remaining, h->heavy_list, h->heavy_count, h->task_rows, h->cache};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   delete h;
   return JACO_OK;
@@ -185,13 +191,18 @@ extern "C" int jaco_reset_state(JacoHandle* h, void* stream) {
   return JACO_OK;
 }
 
-static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t st, float* dbg, int dbg_env) {
-  if (!ctrl || nsub <= 0) { h->err = "jaco_physics_step: bad arguments"; return JACO_EINVAL; }
+struct EnvIO { int mode = 0; const float* action = nullptr; float* obs = nullptr; float* reward = nullptr; unsigned char* done = nullptr; };
+
+static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t st, float* dbg, int dbg_env, const EnvIO& io = EnvIO()) {
+  if ((!ctrl && io.mode == 0) || nsub <= 0) { h->err = "jaco_physics_step: bad arguments"; return JACO_EINVAL; }
   JacoStepArgs A{};
-  A.model = h->model_dev; A.hull = h->hull_dev; A.qpos = h->qpos; A.qvel = h->qvel; A.qacc_ws = h->qacc_ws; A.ctrl = ctrl;
+  A.model = h->model_dev; A.hull = h->hull_dev; A.qpos = h->qpos; A.qvel = h->qvel; A.qacc_ws = h->qacc_ws;
+  A.ctrl = ctrl ? ctrl : h->qvel;   // env modes compute ctrl in-kernel; the pointer only has to be readable
   A.sensordata = h->sensordata; A.flags = h->flags; A.stats = h->stats; A.nenv = h->num_envs; A.nsub = nsub;
   A.disable_contact = h->disable_contact; A.dbg = dbg; A.dbg_env = dbg_env; A.prof = h->prof;
   A.remaining = h->remaining; A.heavy_list = h->heavy_list; A.heavy_count = h->heavy_count;
+  A.env_mode = io.mode; A.task_id = h->task; A.nact = h->task == JACO_TASK_REACHING ? 6 : 7; A.seed = h->seed;
+  A.task = h->task_rows; A.cache = h->cache; A.action = io.action; A.noise = h->noise; A.obs = io.obs; A.reward = io.reward; A.done = io.done;
   std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
   if (h->timing) {
     if (h->events_used == h->events.size()) {
@@ -218,6 +229,84 @@ extern "C" int jaco_physics_step(JacoHandle* h, const float* ctrl_dev, int nsub,
   if (!h) return JACO_EINVAL;
   return launch_step(h, ctrl_dev, nsub, (hipStream_t)stream, nullptr, -1);
 }
+// ---- env level: reset / step with the reference's Gym-style semantics, batched -------------------------
+struct JacoResetArgs {
+  const float* qpos0; float* qpos; float* qvel; float* qacc_ws; float* task; const unsigned char* mask;
+  int nenv, nq, nv, task_id, has_free; unsigned long long seed;
+};
+__global__ void jaco_reset_kernel(JacoResetArgs R) {
+  int e = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (e >= R.nenv || (R.mask && !R.mask[e])) return;
+  float* t = R.task + (size_t)e * JTASK_N;
+  unsigned c = __float_as_uint(t[JT_RNG]);
+  auto U = [&](float lo, float hi) { float u = rng_uniform(R.seed, (unsigned)e, c++); return lo + (hi - lo) * u; };
+  float* q = R.qpos + (size_t)e * R.nq;
+  for (int k = 0; k < R.nq; k++) q[k] = R.qpos0[k];
+  for (int k = 0; k < R.nv; k++) { R.qvel[(size_t)e * R.nv + k] = 0.f; R.qacc_ws[(size_t)e * R.nv + k] = 0.f; }
+  // _create_init_angle (env_mujoco_util.py:176-185); fingers stay at qpos0 (mujoco.py:342-343)
+  if (R.task_id == JACO_TASK_PLACING) {
+    const float PI = 3.14159265358979323846f;
+    float a0 = U(0.f, 1.f) < 0.5f ? U(3.f * PI / 8.f, PI / 2.f) : U(PI / 2.f, 5.f * PI / 8.f);
+    q[0] = a0; q[1] = 3.85f; q[2] = U(1.f, 1.1f); q[3] = U(2.f, 2.1f); q[4] = U(0.8f, 2.3f); q[5] = U(-1.2f, -1.1f);
+  } else {
+    q[0] = U(0.7f, 2.5f); q[1] = U(3.8f, 4.f); q[2] = U(1.f, 1.7f); q[3] = U(1.8f, 2.5f); q[4] = U(1.f, 2.5f); q[5] = U(0.8f, 2.3f);
+  }
+  for (int k = 0; k < JTASK_N; k++) if (k != JT_RNG) t[k] = 0.f;
+  t[JT_GRIP] = 0.6f; t[JT_GRIP_PREV] = 0.6f;
+  if (R.has_free) {   // __sample_goal (:215-219), set_dest_xyz (mujoco.py:229-237), set_obj_xyz with the zero quaternion (:119-121)
+    float ox = U(-0.1f, 0.1f), oy = 0.65f + U(-0.08f, 0.02f), dx = 0.4f + U(-0.05f, 0.05f), dy = 0.3f + U(-0.05f, 0.05f);
+    q[9] = ox; q[10] = oy; q[11] = 0.1898f; q[12] = 1.f; q[13] = 0.f; q[14] = 0.f; q[15] = 0.f;
+    q[16] = dx; q[17] = dy;
+    t[JT_OBJGOAL] = ox; t[JT_OBJGOAL + 1] = oy; t[JT_OBJGOAL + 2] = 0.1898f;
+    t[JT_DESTGOAL] = dx; t[JT_DESTGOAL + 1] = dy; t[JT_DESTGOAL + 2] = 0.3468f;
+  }
+  t[JT_RNG] = __uint_as_float(c);
+}
+
+extern "C" int jaco_forward(JacoHandle* h, float* obs_dev, void* stream) {
+  if (!h || !obs_dev) return JACO_EINVAL;
+  EnvIO io; io.mode = 2; io.obs = obs_dev;
+  return launch_step(h, nullptr, 1, (hipStream_t)stream, nullptr, -1, io);
+}
+extern "C" int jaco_reset(JacoHandle* h, const uint8_t* mask_dev, float* obs_dev, void* stream) {
+  if (!h || !obs_dev) return JACO_EINVAL;
+  if (h->task == JACO_TASK_PLACING) { h->err = "jaco_reset: the placing reset (object in hand + 150 held substeps, env_mujoco_util.py:106-117) is not implemented yet"; return JACO_EINVAL; }
+  hipStream_t st = (hipStream_t)stream;
+  const JacoModelDev& m = h->model_host;
+  HIPCHK(h, hipMemcpyAsync(h->dbg, h->qpos0.data(), m.nq * sizeof(float), hipMemcpyHostToDevice, st));
+  JacoResetArgs R{h->dbg, h->qpos, h->qvel, h->qacc_ws, h->task_rows, mask_dev, h->num_envs, m.nq, m.nv, h->task, m.nq >= 23, h->seed};
+  hipLaunchKernelGGL(jaco_reset_kernel, dim3((unsigned)((h->num_envs + 255) / 256)), dim3(256), 0, st, R);
+  HIPCHK(h, hipGetLastError());
+  // sim.forward() + _get_observation for every env (unmasked envs recompute the same cache and observation)
+  return jaco_forward(h, obs_dev, stream);
+}
+extern "C" int jaco_step(JacoHandle* h, const float* action_dev, float* obs_dev, float* reward_dev, uint8_t* done_dev, void* stream) {
+  if (!h || !action_dev || !obs_dev || !reward_dev || !done_dev) return JACO_EINVAL;
+  EnvIO io; io.mode = 1; io.action = action_dev; io.obs = obs_dev; io.reward = reward_dev; io.done = done_dev;
+  return launch_step(h, nullptr, h->frame_skip, (hipStream_t)stream, nullptr, -1, io);
+}
+extern "C" int jaco_set_noise(JacoHandle* h, const float* noise_dev) {
+  if (!h) return JACO_EINVAL;
+  h->noise = noise_dev;
+  return JACO_OK;
+}
+extern "C" int jaco_get_task_state(JacoHandle* h, float* out_dev, void* stream) {
+  if (!h || !out_dev) return JACO_EINVAL;
+  HIPCHK(h, hipMemcpyAsync(out_dev, h->task_rows, (size_t)h->num_envs * JTASK_N * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return JACO_OK;
+}
+extern "C" int jaco_set_task_state(JacoHandle* h, const float* in_dev, void* stream) {
+  if (!h || !in_dev) return JACO_EINVAL;
+  HIPCHK(h, hipMemcpyAsync(h->task_rows, in_dev, (size_t)h->num_envs * JTASK_N * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return JACO_OK;
+}
+extern "C" int jaco_task_row_floats(void) { return JTASK_N; }
+extern "C" int jaco_set_frame_skip(JacoHandle* h, int frame_skip) {
+  if (!h || frame_skip <= 0) return JACO_EINVAL;
+  h->frame_skip = frame_skip;
+  return JACO_OK;
+}
+
 extern "C" int jaco_debug_dump_floats(void) { return JDBG_SIZE; }
 extern "C" int jaco_physics_step_debug(JacoHandle* h, const float* ctrl_dev, int nsub, int env, float* dump_host, int dump_floats) {
   if (!h || !dump_host || dump_floats < JDBG_SIZE || env < 0 || env >= h->num_envs) return JACO_EINVAL;

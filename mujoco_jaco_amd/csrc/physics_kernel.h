@@ -72,6 +72,17 @@ struct JacoStepArgs {
   int* heavy_list;     // [nenv] env ids handed to the heavy tier
   int* heavy_count;    // [1]
   int nenv, nsub, disable_contact;
+  // env-level mode (jaco_step / jaco_reset): nsub = frame_skip
+  int env_mode;              // 0 ctrl-level, 1 env step, 2 forward only (reset: fill cache + observation)
+  int task_id, nact;
+  unsigned long long seed;
+  float* task;               // [nenv][JTASK_N]
+  float* cache;              // [nenv][JCACHE_N]
+  const float* action;       // [nenv][nact]
+  const float* noise;        // optional [nenv][12] sub-goal noise draws (6 for the marker, 6 for the observation), else RNG
+  float* obs;                // [nenv][26]
+  float* reward;             // [nenv]
+  unsigned char* done;       // [nenv]
   unsigned long long* prof;  // diagnostic build only: [nenv][JPROF_N] cycle sums, else nullptr
   float* dbg;          // optional stage dump of env dbg_env (see JDBG_* offsets), else nullptr
   int dbg_env;
@@ -115,6 +126,7 @@ struct JacoLDS {
   float e_aref[C::MAXEFC], e_D[C::MAXEFC], e_f[C::MAXEFC];
   int e_con[C::MAXEFC];                         // contact | edge << 8 | block bits << 16
   int ncon, nefc, ncand, nlimit;
+  float task[32];
 };
 
 // ---------------------------------------------------------------- small vector helpers
@@ -640,8 +652,10 @@ JDEV void stage_integrate_pos(const JacoModelDev* m, L& s, int lane) {
 }
 
 #include "collision.h"
+#include "env_logic.h"
 
 #include "collision.h"
+#include "env_logic.h"
 
 // ---------------------------------------------------------------- the kernels
 // One substep loop for one env; returns the number of substeps NOT done (light tier bail-out) or 0.
@@ -654,11 +668,47 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
   if (lane < nu) s.ctrl[lane] = A.ctrl[(size_t)env * nu + lane];
   unsigned flags = LIGHT ? 0u : JFLAG_HEAVY_TIER;
   float sens = 0.f;
-  int iters = 0, left = 0;
+  int iters = 0, left = 0, sub0 = 0;
+  const int emode = A.env_mode;
+  if (emode) {   // task row + the one-substep-stale quantities the controller reads (env_logic.h)
+    if (lane < JTASK_N) s.task[lane] = A.task[(size_t)env * JTASK_N + lane];
+    const float* CR = A.cache + (size_t)env * JCACHE_N;
+    if (lane < 36) { s.M[(lane / 6) * JNV + lane % 6] = CR[JC_M + lane]; s.cdof[lane / 6][lane % 6] = CR[JC_CDOF + lane]; }
+    if (lane < 6) s.bias[lane] = CR[JC_BIAS + lane];
+    if (lane < 3) { s.xpos[m->ee_body][lane] = CR[JC_EEPOS + lane]; s.xpos[m->obj_body >= 0 ? m->obj_body : 0][lane] = CR[JC_OBJPOS + lane]; }
+    if (lane < 9) s.xmat[m->ee_body][lane] = CR[JC_EEMAT + lane];
+  }
   wave_sync();
+  if (emode == 1) {
+    if (s.task[JT_DONE] != 0.f) {   // finished and not yet reset: frozen (no auto-reset)
+      if (lane == 0) { A.reward[env] = 0.f; A.done[env] = 1; }
+      return 0;
+    }
+    sub0 = (int)s.task[JT_SUB];
+    if (sub0 == 0) {
+      // _take_action: the marker placement consumes 6 draws (a8), then the EE target and the gripper ramp
+      take_action(m, s, A.action + (size_t)env * A.nact, A.nact, lane);
+      if (lane == 0) { unsigned c = __float_as_uint(s.task[JT_RNG]); s.task[JT_RNG] = __uint_as_float(c + 6u); }
+      wave_sync();
+    }
+  }
   JSTAMP_INIT
-  for (int sub = 0; sub < nsub; sub++) {
+  for (int sub = sub0; sub < nsub; sub++) {
     m = opaque_ptr(A.model);
+    if (emode == 1) {
+      if (s.task[JT_PENDING] != 0.f) {   // resume of a substep interrupted by the light tier: its ctrl was saved
+        if (lane < nu) s.ctrl[lane] = s.task[JT_CTRL + lane];
+        wave_sync();
+        if (lane == 0) s.task[JT_PENDING] = 0.f;
+      } else {
+        stage_osc(m, s, lane, flags);   // _step_simulation: feedback -> OSC torque (env_mujoco_util.py:73-90)
+        if (lane >= 6 && lane < nu) {   // gripper ramp np.linspace(prev, new, skip_frames)[gripper_iter] (:631,:78)
+          float g0 = s.task[JT_GRIP_PREV], g1 = s.task[JT_GRIP];
+          s.ctrl[lane] = nsub > 1 ? g0 + (g1 - g0) * ((float)sub / (float)(nsub - 1)) : g1;
+        }
+        wave_sync();
+      }
+    }
     stage_walk(m, s, lane);
     for (int i = lane; i < JNV * JNV; i += 64) s.M[i] = 0.f;
     wave_sync();
@@ -691,6 +741,11 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
     }
     if (LIGHT && cflags) {   // capacity exceeded: leave this substep (and the rest) to the heavy tier; nothing was mutated
       left = nsub - sub;
+      if (emode == 1) {
+        if (lane < nu) s.task[JT_CTRL + lane] = s.ctrl[lane];
+        if (lane == 0) { s.task[JT_PENDING] = 1.f; s.task[JT_SUB] = (float)sub; }
+        wave_sync();
+      }
       break;
     }
     float mrow[JNV], h[JNV];   // M[lane][:] stays in registers for the rest of the substep
@@ -742,6 +797,7 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
       if (lane < m->nsensor) D[JDBG_SENS + lane] = sens;
     }
     wave_sync();
+    if (emode == 2) break;   // sim.forward(): derived quantities only, no integration
     if (lane < nv) {
       float v = s.qvel[lane] + m->timestep * qacc_e;
       s.qvel[lane] = v;
@@ -753,9 +809,68 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
     wave_sync();
     JSTAMP(8);
   }
-  if (lane < nq) A.qpos[(size_t)env * nq + lane] = s.qpos[lane];
-  if (lane < nv) { A.qvel[(size_t)env * nv + lane] = s.qvel[lane]; A.qacc_ws[(size_t)env * nv + lane] = s.qacc_ws[lane]; }
+  if (emode != 2) {
+    if (lane < nq) A.qpos[(size_t)env * nq + lane] = s.qpos[lane];
+    if (lane < nv) { A.qvel[(size_t)env * nv + lane] = s.qvel[lane]; A.qacc_ws[(size_t)env * nv + lane] = s.qacc_ws[lane]; }
+  }
   if (left == 0 && lane < ns && A.sensordata) A.sensordata[(size_t)env * ns + lane] = sens;
+  if (emode) {
+    if (left == 0) {
+      // observation, reward, termination from the poses / sensors of the last forward pass (one substep stale, as in
+      // the reference) -- make_observation, _get_reward, terminal_inspection (env_mujoco.py:122-126)
+      float* CW = A.cache + (size_t)env * JCACHE_N;
+      if (lane < 36) { CW[JC_M + lane] = s.M[(lane / 6) * JNV + lane % 6]; CW[JC_CDOF + lane] = s.cdof[lane / 6][lane % 6]; }
+      if (lane < 6) CW[JC_BIAS + lane] = s.bias[lane];
+      int ob = m->obj_body >= 0 ? m->obj_body : 0;
+      if (lane < 3) { CW[JC_EEPOS + lane] = s.xpos[m->ee_body][lane]; CW[JC_OBJPOS + lane] = s.xpos[ob][lane]; }
+      if (lane < 9) CW[JC_EEMAT + lane] = s.xmat[m->ee_body][lane];
+      v3 pe; m3 Re;
+      ee_frame(m, s, &pe, &Re);
+      float eul[3];
+      mat_to_euler_rxyz(Re, eul);
+      v3 obj = ld3(s.xpos[ob]);
+      v3 objgoal = ld3(s.task + JT_OBJGOAL), destgoal = ld3(s.task + JT_DESTGOAL);
+      int touch = touch_class(sens, lane);
+      float nz[6];
+      unsigned cnt = __float_as_uint(s.task[JT_RNG]);
+      for (int k = 0; k < 6; k++) nz[k] = A.noise ? A.noise[(size_t)env * 12 + 6 + k] : rng_uniform(A.seed, (unsigned)env, cnt + k);
+      float spos[3], sori[3];
+      rulebased_subgoal(A.task_id, pe, objgoal, obj.y, destgoal, nz, spos, sori);
+      float rew = 0.f, bonus = 0.f, wb = 0.f;
+      int succ = 0;
+      bool done = false;
+      const float PI = 3.14159265358979323846f;
+      if (emode == 1) {
+        rew = A.task_id == 0 ? reward_picking(pe, eul, obj, touch) : 0.f;
+        float trow[4] = {0.f, s.task[JT_STEPS], s.task[JT_EPISODES], 0.f};
+        done = terminal_inspection(A.task_id, trow, s.qpos[2], pe, ld3(m->base_pos), obj, destgoal, touch, &bonus, &succ, &wb);
+        wave_sync();
+        if (lane == 0) {
+          s.task[JT_STEPS] = trow[JT_STEPS]; s.task[JT_EPISODES] = trow[JT_EPISODES]; s.task[JT_DONE] = done ? 1.f : 0.f;
+          s.task[JT_SUCC] = (float)succ; s.task[JT_WB] = wb; s.task[JT_SUB] = 0.f; s.task[JT_PENDING] = 0.f;
+          A.reward[env] = rew + bonus;
+          A.done[env] = done ? 1 : 0;
+        }
+      }
+      if (lane == 0) s.task[JT_RNG] = __uint_as_float(cnt + 6u);
+      if (lane < 26) {
+        float o;
+        if (lane == 0) o = (float)touch;
+        else if (lane < 4) o = lane == 1 ? pe.x : (lane == 2 ? pe.y : pe.z);
+        else if (lane < 7) o = eul[lane - 4] / PI;
+        else if (lane == 7) o = (s.task[JT_GRIP] - 0.8f) / 0.2f;
+        else if (lane < 11) o = lane == 8 ? obj.x : (lane == 9 ? obj.y : obj.z);
+        else if (lane < 14) o = 0.f;
+        else if (lane < 17) o = s.task[JT_DESTGOAL + lane - 14];
+        else if (lane < 20) o = spos[lane - 17];
+        else if (lane < 23) o = sori[lane - 20] / PI;
+        else o = lane == 24 ? PI / 2.f : 0.f;
+        A.obs[(size_t)env * 26 + lane] = o;
+      }
+    }
+    wave_sync();
+    if (lane < JTASK_N) A.task[(size_t)env * JTASK_N + lane] = s.task[lane];
+  }
   unsigned long long anyf = wave_ballot(flags != 0);
   if (anyf) {
     unsigned f = flags;
@@ -788,6 +903,6 @@ __global__ __launch_bounds__(64) void jaco_physics_kernel_heavy(JacoStepArgs A) 
   const int count = *A.heavy_count;
   for (int i = env_id(); i < count; i += grid_size()) {
     int env = A.heavy_list[i];
-    run_env<JacoHeavy, false>(A, s, env, A.remaining[env], lane);
+    run_env<JacoHeavy, false>(A, s, env, A.env_mode == 1 ? A.nsub : A.remaining[env], lane);
   }
 }

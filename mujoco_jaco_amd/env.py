@@ -1,0 +1,151 @@
+"""Gym-style batched Jaco environment: drop-in for the env path of the reference.
+
+Mirrors /root/reference/env_script/env_mujoco.py `JacoMujocoEnv` (not a gym.Env subclass there either):
+same attribute names (`observation_space`, `action_space`, `metadata`, `max_steps`, `task_max_steps`, `skip_frames`,
+`state_shape`), same methods (`reset`, `step(action, weight=None, subgoal=None, id=None)`, `get_state_shape`,
+`get_num_observation`, `get_num_action`, `get_action_bound`, `get_wb`, `seed`, `close`), same kwargs
+(`task`, `robot_file`, `n_robots`, `seed`, `visualize`, ...), plus `num_envs`, `device`, `frame_skip`.
+`num_envs == 1` returns the reference's unbatched types (float32[26] ndarray, float, bool, {0: 0}) so the evaluation
+loop at main.py:254-260 runs unchanged; otherwise observations/rewards/dones are torch tensors on the GPU.
+All arithmetic happens in libjaco_env.so (jaco_reset / jaco_step); there is no CPU path.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from .physics import BatchedMujoco, JacoError
+
+TASK_IDS = {"picking": 0, "placing": 1, "reaching": 2}
+
+
+class Box:
+    """Minimal stand-in for gym.spaces.Box (gym is not a dependency of this package)."""
+
+    def __init__(self, low, high, dtype=np.float32):
+        self.low, self.high = np.asarray(low, dtype=dtype), np.asarray(high, dtype=dtype)
+        self.shape, self.dtype = self.low.shape, np.dtype(dtype)
+
+    def sample(self):
+        return np.random.uniform(self.low, self.high).astype(self.dtype)
+
+    def contains(self, x):
+        x = np.asarray(x)
+        return x.shape == self.shape and bool(np.all(x >= self.low) and np.all(x <= self.high))
+
+
+class JacoBatchedEnv:
+    def __init__(self, num_envs=1, device=0, frame_skip=50, seed=0, **kwargs):
+        self.task = kwargs.get("task", "picking")
+        if self.task not in TASK_IDS:
+            # the reference's other task branches return 3-tuples that env_mujoco.py:125 cannot unpack
+            raise NotImplementedError("task %r: only the reference's live tasks picking / placing are supported" % self.task)
+        self.n_robots = kwargs.get("n_robots", 1)
+        if self.n_robots != 1:
+            raise NotImplementedError("n_robots != 1")
+        robot_file = kwargs.get("robot_file", "jaco2_curtain_torque") or "jaco2_curtain_torque"
+        self.num_envs = int(num_envs)
+        self.sim = BatchedMujoco(self.num_envs, robot_file=robot_file, device=device, frame_skip=frame_skip,
+                                 task=TASK_IDS[self.task], seed=int(seed))
+        self.L, self.h, self.device = self.sim.L, self.sim.h, self.sim.device
+        # ---- RL setup (env_mujoco.py:15-93)
+        self.current_steps = 0
+        self.max_steps = 2500
+        self.task_max_steps = 700 if self.task in ("picking", "placing") else 500
+        self.skip_frames = int(frame_skip)
+        obs_max = np.hstack([[3], [1] * 25]).astype(np.float32)
+        self.observation_space = Box(-obs_max, obs_max, dtype=np.float32)
+        self.state_shape = self.observation_space.shape[0]
+        self.pose_action_space_max = 1
+        nact = 6 if self.task == "reaching" else 7
+        self.act_max = np.ones(nact)
+        self.act_min = -np.ones(nact)
+        self.action_space = Box(self.act_min, self.act_max, dtype=np.float32)
+        self.wb = 0
+        self.metadata = None
+        self._obs = torch.zeros(self.num_envs, 26, device=self.device)
+        self._rew = torch.zeros(self.num_envs, device=self.device)
+        self._done = torch.zeros(self.num_envs, dtype=torch.uint8, device=self.device)
+        self._noise = None
+        self._amin = torch.tensor(self.act_min, dtype=torch.float32, device=self.device)
+        self._amax = torch.tensor(self.act_max, dtype=torch.float32, device=self.device)
+
+    # ---- helpers
+    def _p(self, t):
+        return ctypes.c_void_p(t.data_ptr())
+
+    def _out(self, obs=None, rew=None, done=None):
+        if self.num_envs != 1:
+            return obs, rew, done
+        o = obs[0].cpu().numpy().astype(np.float32) if obs is not None else None
+        return o, (float(rew[0].item()) if rew is not None else None), (bool(done[0].item()) if done is not None else None)
+
+    def set_noise(self, noise):
+        """Inject the 12 uniform draws per env that the rule-based sub-goal consumes each step (tests); None = internal RNG."""
+        if noise is None:
+            self._noise = None
+            self.sim._chk(self.L.jaco_set_noise(self.h, None))
+        else:
+            self._noise = noise.to(self.device, torch.float32).contiguous()
+            assert self._noise.shape == (self.num_envs, 12)
+            self.sim._chk(self.L.jaco_set_noise(self.h, self._p(self._noise)))
+
+    # ---- reference surface
+    def reset(self, mask=None):
+        self.current_steps = 0
+        m = None
+        if mask is not None:
+            m = mask.to(self.device).to(torch.uint8).contiguous()
+        self.sim._chk(self.L.jaco_reset(self.h, self._p(m) if m is not None else None, self._p(self._obs), self.sim._stream()))
+        return self._out(self._obs)[0]
+
+    def step(self, action, weight=None, subgoal=None, id=None):
+        a = torch.as_tensor(action, dtype=torch.float32, device=self.device).reshape(self.num_envs, -1)
+        a = torch.max(torch.min(a, self._amax), self._amin).contiguous()          # np.clip (env_mujoco.py:117)
+        self.sim._chk(self.L.jaco_step(self.h, self._p(a), self._p(self._obs), self._p(self._rew), self._p(self._done), self.sim._stream()))
+        self.current_steps += 1
+        obs, rew, done = self._out(self._obs, self._rew, self._done)
+        if self.num_envs != 1:
+            done = done.bool()
+        return obs, rew, done, {0: 0}
+
+    def make_observation(self):
+        self.sim._chk(self.L.jaco_forward(self.h, self._p(self._obs), self.sim._stream()))
+        return self._out(self._obs)[0]
+
+    def task_state(self):
+        n = self.L.jaco_task_row_floats()
+        t = torch.empty(self.num_envs, n, device=self.device)
+        self.sim._chk(self.L.jaco_get_task_state(self.h, self._p(t), self.sim._stream()))
+        return t
+
+    def set_task_state(self, t):
+        t = t.to(self.device, torch.float32).contiguous()
+        self.sim._chk(self.L.jaco_set_task_state(self.h, self._p(t), self.sim._stream()))
+
+    def get_state_shape(self):
+        return self.state_shape
+
+    def get_num_observation(self):
+        return self.observation_space.shape[0]
+
+    def get_num_action(self):
+        return self.action_space.shape[0]
+
+    def get_action_bound(self):
+        return self.pose_action_space_max
+
+    def get_wb(self):
+        wb = self.task_state()[:, 30]
+        return float(wb[0].item()) if self.num_envs == 1 else wb
+
+    def successes(self):
+        return self.task_state()[:, 29] > 0.5
+
+    def seed(self, seed):
+        pass  # the reference's seed() is a no-op too (env_mujoco.py:163-164); pass `seed=` to the constructor instead
+
+    def close(self):
+        self.sim.close()
+        return None

@@ -13,6 +13,34 @@ extern "C" int emu_dbg_size() { return JDBG_SIZE; }
 extern "C" int emu_lds_bytes() { return (int)sizeof(JacoLDS<JacoLight>); }
 extern "C" int emu_lds_bytes_heavy() { return (int)sizeof(JacoLDS<JacoHeavy>); }
 
+static JacoModelDev g_model;
+static std::vector<float> g_hull;
+static int emu_launch(JacoStepArgs A, int* heavy_envs) {
+  std::vector<int> remaining(A.nenv, 0), list(A.nenv, 0);
+  int count = 0;
+  A.remaining = remaining.data(); A.heavy_list = list.data(); A.heavy_count = &count;
+  emu_grid = A.nenv;
+  for (int e = 0; e < A.nenv; e++) emu_run_wave(e, [&]() { jaco_physics_kernel(A); });
+  emu_grid = 1;
+  if (count > 0) emu_run_wave(0, [&]() { jaco_physics_kernel_heavy(A); });
+  if (heavy_envs) *heavy_envs = count;
+  return 0;
+}
+// env-level call: mode 1 = step (nsub = frame_skip), mode 2 = forward only
+extern "C" int emu_env_call(const void* blob, long blob_size, int nenv, int mode, int frame_skip, int task_id, int nact, unsigned long long seed,
+                            float* qpos, float* qvel, float* qacc_ws, float* sensordata, unsigned* flags, int* stats, float* task, float* cache,
+                            const float* action, const float* noise, float* obs, float* reward, unsigned char* done, int* heavy_envs) {
+  std::string err;
+  if (jaco_model_from_blob(blob, (size_t)blob_size, &g_model, &g_hull, &err)) { fprintf(stderr, "emu: %s\n", err.c_str()); return -1; }
+  JacoStepArgs A{};
+  A.model = &g_model; A.hull = g_hull.data(); A.qpos = qpos; A.qvel = qvel; A.qacc_ws = qacc_ws; A.ctrl = qvel; A.sensordata = sensordata;
+  A.flags = flags; A.stats = stats; A.nenv = nenv; A.nsub = mode == 2 ? 1 : frame_skip; A.env_mode = mode; A.task_id = task_id; A.nact = nact;
+  A.seed = seed; A.task = task; A.cache = cache; A.action = action; A.noise = noise; A.obs = obs; A.reward = reward; A.done = done; A.dbg_env = -1;
+  return emu_launch(A, heavy_envs);
+}
+extern "C" int emu_task_floats() { return JTASK_N; }
+extern "C" int emu_cache_floats() { return JCACHE_N; }
+
 extern "C" int emu_physics_step(const void* blob, long blob_size, int nenv, int nsub, int disable_contact, float* qpos, float* qvel,
                                 float* qacc_ws, const float* ctrl, float* sensordata, unsigned* flags, int* stats, float* dbg, int dbg_env, int* heavy_envs) {
   static JacoModelDev model;

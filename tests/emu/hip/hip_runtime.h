@@ -26,3 +26,6 @@ void emu_collective();
 static inline void __syncthreads() { emu_collective(); }
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline float __frcp_rn(float x) { return 1.0f / x; }
+
+static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }

@@ -26,6 +26,8 @@ def lib():
         L = ctypes.CDLL(os.path.join(EMU_DIR, "libjaco_emu.so"))
         fp, ip, up = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint)
         L.emu_physics_step.argtypes = [ctypes.c_char_p, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int, fp, fp, fp, fp, fp, up, ip, fp, ctypes.c_int, ip]
+        L.emu_env_call.argtypes = [ctypes.c_char_p, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_ulonglong,
+                                   fp, fp, fp, fp, up, ip, fp, fp, fp, fp, fp, fp, ctypes.POINTER(ctypes.c_ubyte), ip]
         _lib = L
     return _lib
 
@@ -60,3 +62,37 @@ class EmuEnv:
                                      fp(self.dbg) if dbg_env >= 0 else None, dbg_env, ctypes.byref(hv))
         self.heavy_envs = hv.value
         assert rc == 0
+
+
+class EmuJacoEnv(EmuEnv):
+    """Env-level calls (jaco_step / jaco_forward semantics) on the emulated kernels."""
+
+    def __init__(self, model="jaco2_curtain_torque", nenv=1, task_id=0, frame_skip=50, seed=0):
+        super().__init__(model, nenv)
+        self.task_id, self.frame_skip, self.seed = task_id, frame_skip, seed
+        self.task = np.zeros((nenv, self.L.emu_task_floats()), np.float32)
+        self.cache = np.zeros((nenv, self.L.emu_cache_floats()), np.float32)
+        self.obs = np.zeros((nenv, 26), np.float32)
+        self.reward = np.zeros(nenv, np.float32)
+        self.done = np.zeros(nenv, np.uint8)
+        self.task[:, 0] = 0.6; self.task[:, 16] = 0.6
+
+    def _call(self, mode, action=None, noise=None):
+        fp = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_float)) if a is not None else None
+        hv = ctypes.c_int(0)
+        rc = self.L.emu_env_call(self.blob, len(self.blob), self.nenv, mode, self.frame_skip, self.task_id, 7, self.seed,
+                                 fp(self.qpos), fp(self.qvel), fp(self.qacc_ws), fp(self.sensordata),
+                                 self.flags.ctypes.data_as(ctypes.POINTER(ctypes.c_uint)), self.stats.ctypes.data_as(ctypes.POINTER(ctypes.c_int)),
+                                 fp(self.task), fp(self.cache), fp(action), fp(noise), fp(self.obs), fp(self.reward),
+                                 self.done.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)), ctypes.byref(hv))
+        assert rc == 0
+        self.heavy_envs = hv.value
+
+    def forward(self, noise=None):
+        self._call(2, None, None if noise is None else np.ascontiguousarray(noise, np.float32))
+        return self.obs.copy()
+
+    def env_step(self, action, noise=None):
+        a = np.ascontiguousarray(np.broadcast_to(np.asarray(action, np.float32), (self.nenv, 7)))
+        self._call(1, a, None if noise is None else np.ascontiguousarray(noise, np.float32))
+        return self.obs.copy(), self.reward.copy(), self.done.copy()

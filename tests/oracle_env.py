@@ -1,0 +1,62 @@
+"""TEST INFRASTRUCTURE: fp64 single-env restatement of JacoMujocoEnv.step (env_script/env_mujoco.py:116-139) on top of
+the physics oracle and oracle/glue.py, including the one-substep staleness of everything the controller and the
+observation read from mjData."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import glue  # noqa: E402
+from oracle_binding import Oracle  # noqa: E402
+
+
+class OracleEnv:
+    def __init__(self, names, task="picking", frame_skip=50):
+        self.o = Oracle()
+        self.task, self.frame_skip = task, frame_skip
+        self.ee = names["body"].index("EE")
+        self.obj = names["body"].index("object_body")
+        self.base = np.array([0.0, 0.0, 0.157])
+        self.grip, self.steps, self.episodes = 0.6, 0, 0
+        self.obj_goal, self.dest_goal = np.zeros(3), np.zeros(3)
+
+    def set_state(self, qpos, qvel=None, qacc_ws=None):
+        o = self.o
+        o.set("qpos", qpos); o.set("qvel", np.zeros(o.nv) if qvel is None else qvel)
+        o.set("qacc_warmstart", np.zeros(o.nv) if qacc_ws is None else qacc_ws)
+        o.forward()   # sim.forward(): derived quantities of the current state
+
+    def _ee(self):
+        o = self.o
+        return o.get("xpos").reshape(-1, 3)[self.ee].copy(), o.get("xquat").reshape(-1, 4)[self.ee].copy()
+
+    def observe(self, noise6):
+        o = self.o
+        pe, qe = self._ee()
+        obj = o.get("xpos").reshape(-1, 3)[self.obj]
+        touch = glue.touch_class(o.get("sensordata"))
+        return glue.observation(self.task, touch, pe, qe, self.grip, obj, self.dest_goal, self.obj_goal, noise6), touch, pe, qe, obj
+
+    def step(self, action, noise12):
+        o = self.o
+        pe, qe = self._ee()
+        target, grip, ramp = glue.take_action(pe, qe, action, self.grip, self.frame_skip)
+        self.grip = grip
+        for k in range(self.frame_skip):
+            q_dq = o.get("qvel")[:6]
+            jp, jr = o.jac_body_com(self.ee)                       # stale: last forward pass
+            J = np.vstack([jp[:, :6], jr[:, :6]])
+            M = o.get("qM").reshape(o.nv, o.nv)[:6, :6]
+            bias = o.get("qfrc_bias")[:6]
+            pe, qe = self._ee()
+            u = glue.osc_generate(q_dq, target, J, M, bias, pe, qe)
+            o.step(np.concatenate([u, [ramp[k]] * 3]))
+        obs, touch, pe, qe, obj = self.observe(noise12[6:12])
+        rew = glue.reward_picking(pe, qe, obj, touch) if self.task == "picking" else 0.0
+        done, bonus, wb, succ = glue.env_terminal(self.task, self.steps, o.get("qpos")[2], pe, obj, self.dest_goal, touch, self.episodes, self.base)
+        self.steps += 1
+        if self.steps < 700:
+            self.episodes += 1
+        return obs, rew + bonus, done, succ

@@ -1,0 +1,56 @@
+"""CPU tier: env-level step of the emulated HIP kernels (OSC + substeps + obs/reward/done) against the fp64 oracle
+env (tests/oracle_env.py = physics oracle + oracle/glue.py, the latter pinned by the reference's golden vectors)."""
+import numpy as np
+
+from emu_binding import EmuJacoEnv
+from mujoco_jaco_amd import workload
+from oracle_env import OracleEnv
+
+
+def _pair(names, M, seed, fs):
+    e = EmuJacoEnv(frame_skip=fs)
+    oe = OracleEnv(names, frame_skip=fs)
+    q = workload.reset_states(M["qpos0"], 1, seed=seed)[0]
+    oe.obj_goal = q[9:12].copy(); oe.dest_goal = np.array([q[16], q[17], 0.3468])
+    oe.set_state(q.astype(np.float32).astype(np.float64))
+    e.qpos[0] = q; e.task[0, 4:7] = oe.obj_goal; e.task[0, 7:10] = oe.dest_goal
+    return e, oe
+
+
+def test_env_step_matches_oracle_env(names, model_arrays):
+    e, oe = _pair(names, model_arrays, 3, 10)
+    rng = np.random.default_rng(3)
+    nz = rng.uniform(size=(1, 12)).astype(np.float32)
+    obs0 = e.forward(nz)
+    assert np.abs(obs0[0] - oe.observe(nz[0, 6:].astype(np.float64))[0]).max() < 2e-6
+    for step in range(6):
+        a = rng.uniform(-1, 1, 7).astype(np.float32); nz = rng.uniform(size=(1, 12)).astype(np.float32)
+        obs, rew, done = e.env_step(a, nz)
+        oo, orew, odone, _ = oe.step(a.astype(np.float64), nz[0].astype(np.float64))
+        assert obs[0, 0] == oo[0] and bool(done[0]) == odone              # touch class and done: exact
+        assert np.abs(obs[0] - oo).max() < 5e-5 and abs(rew[0] - orew) < 1e-4
+    assert e.task[0, 1] == 6 and e.task[0, 2] == 6                         # current_steps, num_episodes
+
+
+def test_gripper_ramp_and_target(names, model_arrays):
+    e, oe = _pair(names, model_arrays, 4, 5)
+    e.forward()
+    a = np.array([0.5, -0.2, 0.1, 0.3, -0.4, 0.9, 1.0], np.float32)
+    e.env_step(a, np.full((1, 12), 0.5, np.float32))
+    assert abs(e.task[0, 0] - 0.7) < 1e-6 and abs(e.task[0, 16] - 0.6) < 1e-6   # gripper += a6/10, clipped to [0.6, 1]
+    import glue
+    pe, qe = oe._ee()
+    target, _, _ = glue.take_action(pe, qe, a.astype(np.float64), 0.6, 5)
+    assert np.abs(e.task[0, 10:16] - target).max() < 1e-5
+
+
+def test_timeout_and_freeze(names, model_arrays):
+    e, _ = _pair(names, model_arrays, 5, 1)
+    e.forward()
+    e.task[0, 1] = 698                                                   # current_steps
+    z = np.zeros(7, np.float32)
+    _, _, d = e.env_step(z); assert d[0] == 0
+    _, r, d = e.env_step(z); assert d[0] == 1 and abs(r[0] - (-10.0)) < 0.2   # time out: -10 (+ small shaping reward)
+    q = e.qpos.copy()
+    _, r, d = e.env_step(z)                                              # frozen until reset
+    assert d[0] == 1 and r[0] == 0 and np.array_equal(q, e.qpos)

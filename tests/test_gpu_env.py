@@ -1,0 +1,108 @@
+"""GPU tier, env level: JacoBatchedEnv (libjaco_env.so jaco_reset / jaco_step) against the fp64 oracle env, plus the
+drop-in surface of the reference's JacoMujocoEnv (env_script/env_mujoco.py)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def test_env_step_parity_vs_oracle_env(model_arrays, names):
+    from mujoco_jaco_amd import workload
+    from mujoco_jaco_amd.env import JacoBatchedEnv
+    from oracle_env import OracleEnv
+    B, nstep = 12, 3
+    q = workload.reset_states(model_arrays["qpos0"], B, seed=71)
+    env = JacoBatchedEnv(num_envs=B, task="picking")
+    dev = env.device
+    env.sim.set_state(torch.tensor(q, dtype=torch.float32, device=dev), torch.zeros(B, 21, device=dev), torch.zeros(B, 21, device=dev))
+    t = env.task_state(); t[:] = 0; t[:, 0] = 0.6; t[:, 16] = 0.6
+    t[:, 4:7] = torch.tensor(q[:, 9:12], dtype=torch.float32); t[:, 7:9] = torch.tensor(q[:, 16:18], dtype=torch.float32); t[:, 9] = 0.3468
+    env.set_task_state(t)
+    rng = np.random.default_rng(7)
+    oes = []
+    for k in range(B):
+        oe = OracleEnv(names); oe.obj_goal = q[k, 9:12].astype(np.float32).astype(np.float64)
+        oe.dest_goal = np.array([q[k, 16], q[k, 17], 0.3468]).astype(np.float32).astype(np.float64)
+        oe.set_state(q[k].astype(np.float32).astype(np.float64)); oes.append(oe)
+    nz = rng.uniform(size=(B, 12)).astype(np.float32)
+    env.set_noise(torch.tensor(nz)); obs = env.make_observation().cpu().numpy()
+    for k in range(B):
+        assert np.abs(obs[k] - oes[k].observe(nz[k, 6:].astype(np.float64))[0]).max() < 2e-6
+    errs = []
+    for s in range(nstep):
+        a = rng.uniform(-1, 1, (B, 7)).astype(np.float32); nz = rng.uniform(size=(B, 12)).astype(np.float32)
+        env.set_noise(torch.tensor(nz))
+        obs, rew, done, info = env.step(torch.tensor(a))
+        obs, rew, done = obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()
+        assert info == {0: 0}
+        for k in range(B):
+            oo, orew, odone, _ = oes[k].step(a[k].astype(np.float64), nz[k].astype(np.float64))
+            errs.append(np.abs(obs[k] - oo).max())
+            assert bool(done[k]) == odone                                   # termination flag: bit-exact
+            if errs[-1] < 1e-3:
+                assert obs[k, 0] == oo[0] and abs(rew[k] - orew) < 1e-3
+    errs = np.array(errs)
+    print("env-level obs error after up to %d steps x 50 substeps: median %.2e p90 %.2e max %.2e" % (nstep, np.median(errs), np.percentile(errs, 90), errs.max()))
+    assert np.median(errs) < 2e-5 and np.percentile(errs, 80) < 1e-3
+
+
+def test_drop_in_surface_single_env():
+    """The caller pattern of main.py:250-263 with num_envs = 1: unbatched numpy / python types like the reference."""
+    from mujoco_jaco_amd.env import JacoBatchedEnv
+    env = JacoBatchedEnv(task="picking", robot_file="jaco2_curtain_torque", n_robots=1, seed=3, visualize=False)
+    assert env.observation_space.shape == (26,) and env.action_space.shape == (7,) and env.observation_space.dtype == np.float32
+    assert float(env.observation_space.high[0]) == 3.0 and env.metadata is None and env.skip_frames == 50 and env.task_max_steps == 700
+    assert env.get_num_observation() == 26 and env.get_num_action() == 7 and env.get_action_bound() == 1 and env.get_state_shape() == 26
+    obs = env.reset()
+    assert isinstance(obs, np.ndarray) and obs.dtype == np.float32 and obs.shape == (26,)
+    assert abs(obs[7] - (-1.0)) < 1e-6 and abs(obs[10] - 0.1898) < 1e-6 and abs(obs[24] - np.pi / 2) < 1e-6   # gripper 0.6, object z
+    done, n = False, 0
+    while not done and n < 5:
+        obs, reward, done, info = env.step(env.action_space.sample() * 1.5)      # clipped like np.clip (env_mujoco.py:117)
+        assert isinstance(reward, float) and isinstance(done, bool) and info == {0: 0} and obs.shape == (26,)
+        n += 1
+    assert np.isfinite(obs).all() and isinstance(env.get_wb(), float)
+    env.seed(0)
+    assert env.close() is None
+
+
+def test_reset_distribution_and_mask(model_arrays):
+    from mujoco_jaco_amd.env import JacoBatchedEnv
+    B = 4096
+    env = JacoBatchedEnv(num_envs=B, task="picking", seed=11)
+    obs = env.reset()
+    q = env.sim.get_state()[0].cpu().numpy()
+    lo = np.array([0.7, 3.8, 1.0, 1.8, 1.0, 0.8]); hi = np.array([2.5, 4.0, 1.7, 2.5, 2.5, 2.3])       # env_mujoco_util.py:178-179
+    assert (q[:, :6] >= lo - 1e-6).all() and (q[:, :6] <= hi + 1e-6).all()
+    assert np.abs(q[:, :6].mean(0) - (lo + hi) / 2).max() < 0.05 * (hi - lo).max()                      # roughly uniform
+    assert np.allclose(q[:, 6:9], 1.1) and np.allclose(q[:, 11], 0.1898) and np.allclose(q[:, 12:16], [1, 0, 0, 0])
+    assert (np.abs(q[:, 9]) <= 0.1).all() and (q[:, 10] >= 0.57 - 1e-6).all() and (q[:, 10] <= 0.67 + 1e-6).all()
+    assert (np.abs(q[:, 16] - 0.4) <= 0.05 + 1e-6).all() and (np.abs(q[:, 17] - 0.3) <= 0.05 + 1e-6).all()
+    assert torch.isfinite(obs).all() and (obs[:, 7] + 1).abs().max() < 1e-6
+    # step a little, then reset only the odd envs
+    env.step(torch.zeros(B, 7))
+    q1 = env.sim.get_state()[0].clone()
+    mask = torch.zeros(B, dtype=torch.uint8); mask[1::2] = 1
+    env.reset(mask)
+    q2 = env.sim.get_state()[0]
+    assert torch.equal(q1[0::2], q2[0::2]) and not torch.equal(q1[1::2], q2[1::2])
+    assert not np.allclose(q2[1::2, :6].cpu().numpy(), q[1::2, :6])                                     # fresh draws
+
+
+def test_done_envs_freeze_until_reset():
+    from mujoco_jaco_amd.env import JacoBatchedEnv
+    B = 8
+    env = JacoBatchedEnv(num_envs=B, task="picking", frame_skip=2, seed=5)
+    env.reset()
+    t = env.task_state(); t[:4, 1] = 698; env.set_task_state(t)         # four envs one step before the 700-step time-out
+    z = torch.zeros(B, 7)
+    _, _, d, _ = env.step(z); assert not d.any()
+    _, r, d, _ = env.step(z); assert d[:4].all() and not d[4:].any() and (r[:4] < -9).all()
+    q = env.sim.get_state()[0].clone()
+    _, r, d, _ = env.step(z)
+    q2 = env.sim.get_state()[0]
+    assert d[:4].all() and (r[:4] == 0).all() and torch.equal(q[:4], q2[:4]) and not torch.equal(q[4:], q2[4:])
+    m = torch.zeros(B, dtype=torch.uint8); m[:4] = 1
+    env.reset(m)
+    _, _, d, _ = env.step(z); assert not d.any()

@@ -65,7 +65,7 @@ def test_in_hand_grasp_with_hull_contacts(model_arrays, names):
         errs.append(eq)
         if (e.stats[0, 0], e.stats[0, 1]) == (o.ncon, o.nefc):
             sens.append(np.abs(o.get("sensordata") - e.sensordata[0]).max() / max(1.0, o.get("sensordata").max()))
-    assert max(o.ncon, 0) >= 0 and e.flags[0] == 0
+    assert (e.flags[0] & 31) == 0   # bit 32 only says the 256-row tier was used
     assert np.median(errs) < 1e-6 and max(errs) < 2e-4      # a grazing contact may flip for one step
     assert np.median(sens) < 1e-3
 
