@@ -73,10 +73,10 @@ JDEV v3 support_geom(const JacoStepArgs& A, const JacoModelDev* m, const L& s, i
   GeomPose P = geom_pose(s, g);
   v3 l = mulT(P.R, dir), sp;
   if (type == JG_BOX) {
-    sp = mk3(l.x > 0.f ? m->g_size[g][0] : -m->g_size[g][0], l.y > 0.f ? m->g_size[g][1] : -m->g_size[g][1], l.z > 0.f ? m->g_size[g][2] : -m->g_size[g][2]);
+    sp = mk3(l.x > 0.f ? s.mc.g_size[g][0] : -s.mc.g_size[g][0], l.y > 0.f ? s.mc.g_size[g][1] : -s.mc.g_size[g][1], l.z > 0.f ? s.mc.g_size[g][2] : -s.mc.g_size[g][2]);
   } else if (type == JG_SPHERE) {
     float n = norm(l);
-    sp = l * (n > JMINVAL ? m->g_size[g][0] / n : 0.f);
+    sp = l * (n > JMINVAL ? s.mc.g_size[g][0] / n : 0.f);
   } else {  // hull mesh: 64-lane scan + argmax (lowest vertex index wins ties, like a serial first-max scan)
     int adr = m->g_vertadr[g], nvert = m->g_vertnum[g];
     float best = -3.0e38f;
@@ -100,7 +100,7 @@ JDEV void collide_plane_box(const JacoModelDev* m, L& s, int g1, int g2, int pai
   GeomPose P = geom_pose(s, g1), B = geom_pose(s, g2);
   v3 n = col(P.R, 2);
   int i = lane & 7;
-  v3 l = mk3((i & 1) ? m->g_size[g2][0] : -m->g_size[g2][0], (i & 2) ? m->g_size[g2][1] : -m->g_size[g2][1], (i & 4) ? m->g_size[g2][2] : -m->g_size[g2][2]);
+  v3 l = mk3((i & 1) ? s.mc.g_size[g2][0] : -s.mc.g_size[g2][0], (i & 2) ? s.mc.g_size[g2][1] : -s.mc.g_size[g2][1], (i & 4) ? s.mc.g_size[g2][2] : -s.mc.g_size[g2][2]);
   v3 c = B.p + mul(B.R, l);
   float dist = dot(c - P.p, n);
   push_contacts(s, lane < 8 && !(dist > 0.f), dist, c - n * (0.5f * dist), n, pair, ncon, flags, 4);
@@ -109,7 +109,7 @@ template <class L>
 JDEV void collide_plane_sphere(const JacoModelDev* m, L& s, int g1, int g2, int pair, int lane, int& ncon, unsigned& flags) {
   GeomPose P = geom_pose(s, g1);
   v3 n = col(P.R, 2), c = ld3(s.gpos[g2]);
-  float r = m->g_size[g2][0], dist = dot(c - P.p, n) - r;
+  float r = s.mc.g_size[g2][0], dist = dot(c - P.p, n) - r;
   push_contacts(s, lane == 0 && !(dist > 0.f), dist, c - n * (r + 0.5f * dist), n, pair, ncon, flags, 1);
 }
 template <class L>
@@ -125,7 +125,7 @@ JDEV void collide_plane_convex(const JacoStepArgs& A, const JacoModelDev* m, L& 
 template <class L>
 JDEV void collide_box_box(const JacoModelDev* m, L& s, int g1, int g2, int pair, int lane, int& ncon, unsigned& flags) {
   GeomPose P1 = geom_pose(s, g1), P2 = geom_pose(s, g2);
-  float s1[3] = {m->g_size[g1][0], m->g_size[g1][1], m->g_size[g1][2]}, s2[3] = {m->g_size[g2][0], m->g_size[g2][1], m->g_size[g2][2]};
+  float s1[3] = {s.mc.g_size[g1][0], s.mc.g_size[g1][1], s.mc.g_size[g1][2]}, s2[3] = {s.mc.g_size[g2][0], s.mc.g_size[g2][1], s.mc.g_size[g2][2]};
   v3 Aa[3] = {col(P1.R, 0), col(P1.R, 1), col(P1.R, 2)}, Ba[3] = {col(P2.R, 0), col(P2.R, 1), col(P2.R, 2)};
   v3 pp = P2.p - P1.p;
   // lane a < 6: face axis; 6 <= a < 15: edge axis A[i] x B[j]
@@ -355,24 +355,31 @@ JDEV bool mpr_penetration(const JacoStepArgs& A, const JacoModelDev* m, const L&
 
 // ---------------------------------------------------------------- stage C
 template <class L>
-JDEV void stage_collision(const JacoStepArgs& A, const JacoModelDev* m, L& s, int lane, unsigned& flags) {
-  // phase 1: bounding spheres, lane = pair
+JDEV void stage_collision(const JacoStepArgs& A, const JacoModelDev* m, L& s, int lane, unsigned& flags, JProfCtx& pc) {
+  (void)pc;
+  // phase 1: bounding spheres, lane = pair; the pair codes of all chunks are fetched up front (independent loads)
   int n1 = 0;
-  for (int base = 0; base < m->npair; base += 64) {
-    int k = base + lane;
+  int codes[JMAXPAIR / 64];
+#pragma unroll
+  for (int ch = 0; ch < JMAXPAIR / 64; ch++) codes[ch] = (ch * 64 < m->npair) ? m->pair_code[(ch * 64 + lane < m->npair) ? ch * 64 + lane : 0] : 0;
+#pragma unroll
+  for (int ch = 0; ch < JMAXPAIR / 64; ch++) {
+    if (ch * 64 >= m->npair) break;
+    int k = ch * 64 + lane;
     bool valid = k < m->npair;
-    int code = m->pair_code[valid ? k : 0];
+    int code = codes[ch];
     int g1 = code & 255, g2 = (code >> 8) & 255, t1 = (code >> 16) & 15;
     v3 df = ld3(s.gpos[g2]) - ld3(s.gpos[g1]);
     bool pass;
-    if (t1 == JG_PLANE) pass = !(dot(df, col(ldm(s.gmat[g1]), 2)) > m->g_rbound[g2]);
-    else { float r = m->g_rbound[g1] + m->g_rbound[g2]; pass = !(dot(df, df) > r * r); }
+    if (t1 == JG_PLANE) pass = !(dot(df, col(ldm(s.gmat[g1]), 2)) > s.mc.g_rbound[g2]);
+    else { float r = s.mc.g_rbound[g1] + s.mc.g_rbound[g2]; pass = !(dot(df, df) > r * r); }
     pass = pass && valid;
     unsigned long long mask = wave_ballot(pass);
     int idx = n1 + wave_prefix_count(mask);
     if (pass && idx < L::Caps::MAXCAND) s.cand[idx] = k;
     n1 += popc64(mask);
   }
+  JSTAMP(9);
   if (n1 > L::Caps::MAXCAND) { flags |= JFLAG_CAND_OVERFLOW; n1 = L::Caps::MAXCAND; }
   wave_sync();
   // phase 2: oriented-box cull of the survivors, lane = survivor; compacted in place (order preserved)
@@ -385,8 +392,8 @@ JDEV void stage_collision(const JacoStepArgs& A, const JacoModelDev* m, L& s, in
       int code = m->pair_code[k];
       int g1 = code & 255, g2 = (code >> 8) & 255, t1 = (code >> 16) & 15, t2 = (code >> 20) & 15;
       if (t1 != JG_PLANE) {
-        v3 sa = t1 == JG_SPHERE ? mk3(m->g_size[g1][0], m->g_size[g1][0], m->g_size[g1][0]) : ld3(m->g_size[g1]);
-        v3 sb = t2 == JG_SPHERE ? mk3(m->g_size[g2][0], m->g_size[g2][0], m->g_size[g2][0]) : ld3(m->g_size[g2]);
+        v3 sa = t1 == JG_SPHERE ? mk3(s.mc.g_size[g1][0], s.mc.g_size[g1][0], s.mc.g_size[g1][0]) : ld3(s.mc.g_size[g1]);
+        v3 sb = t2 == JG_SPHERE ? mk3(s.mc.g_size[g2][0], s.mc.g_size[g2][0], s.mc.g_size[g2][0]) : ld3(s.mc.g_size[g2]);
         keep = !obb_separated(geom_pose(s, g1), sa, geom_pose(s, g2), sb);
       }
     }
@@ -396,6 +403,7 @@ JDEV void stage_collision(const JacoStepArgs& A, const JacoModelDev* m, L& s, in
     ncand += popc64(mask);
     wave_sync();
   }
+  JSTAMP(10);
   // phase 3: narrowphase, whole wave per candidate
   int ncon = 0;
   for (int c = 0; c < ncand; c++) {
@@ -419,7 +427,7 @@ JDEV void stage_collision(const JacoStepArgs& A, const JacoModelDev* m, L& s, in
       int b1 = m->g_body[g1], b2 = m->g_body[g2];
       unsigned m1 = b1 >= 0 ? m->b_chainmask[b1] : 0u, m2 = b2 >= 0 ? m->b_chainmask[b2] : 0u;
       int c = before + lane;
-      if (c < ncon) { s.c_m1[c] = m1; s.c_m2[c] = m2; }
+      if (c < ncon) { s.c_m1[c] = m1; s.c_m2[c] = m2; s.c_ob[c] = m->g_origbody[g1] | (m->g_origbody[g2] << 16); s.c_dim[c] = m->pair[pk].condim; }
     }
   }
   if (lane == 0) { s.ncon = ncon; s.ncand = ncand; }
@@ -436,7 +444,7 @@ JDEV void stage_contact_rows(const JacoModelDev* m, L& s, int lane, unsigned& fl
   unsigned cm1 = 0, cm2 = 0;
   if (lane < ncon) {
     const JacoPairParam& P = m->pair[s.c_pair[lane]];
-    dim = P.condim; nrow = dim == 1 ? 1 : 2 * (dim - 1);
+    dim = s.c_dim[lane]; nrow = dim == 1 ? 1 : 2 * (dim - 1);
     mu0 = P.mu[0]; mu1 = P.mu[2]; mu2 = P.mu[3];
     cm1 = s.c_m1[lane]; cm2 = s.c_m2[lane];
   }
@@ -498,11 +506,10 @@ JDEV void stage_contact_rows(const JacoModelDev* m, L& s, int lane, unsigned& fl
     int kf = pd == 1 ? 0 : 1 + (e >> 1);
     float mu = pd == 1 ? 0.f : P.mu[kf - 1];
     float da = pd == 1 ? tran : tran + mu * mu * (kf < 3 ? tran : rot);
-    float R;
-    float aref = row_params(P.solref, P.solimp, pos, vel, da, &R);
+    float R, imp;
+    float aref = row_params(P.solref, P.solimp, pos, vel, da, &R, &imp);
     if (pd > 1) {  // pyramidal: every edge uses 2 mu^2 R of the contact's first row (impratio = 1)
-      float R0;
-      row_params(P.solref, P.solimp, pos, 0.f, tran + P.mu[0] * P.mu[0] * tran, &R0);
+      float R0 = fmaxf(JMINVAL, (1.f - imp) * (tran + P.mu[0] * P.mu[0] * tran) / imp);
       R = fmaxf(JMINVAL, 2.f * P.mu[0] * P.mu[0] * R0);
     }
     s.e_aref[rr] = aref;
@@ -558,8 +565,8 @@ template <class L>
 JDEV void stage_touch(const JacoModelDev* m, L& s, int lane, float* sens) {
   int ncon = s.ncon;
   if (lane < ncon) {
-    const JacoPairParam& P = m->pair[s.c_pair[lane]];
-    int nrow = P.condim == 1 ? 1 : 2 * (P.condim - 1), r0 = s.c_efc[lane];
+    int cd = s.c_dim[lane];
+    int nrow = cd == 1 ? 1 : 2 * (cd - 1), r0 = s.c_efc[lane];
     float fn = 0.f;
     for (int e = 0; e < nrow; e++) fn += s.e_f[r0 + e];
     s.c_fn[lane] = fn;
@@ -574,8 +581,8 @@ JDEV void stage_touch(const JacoModelDev* m, L& s, int lane, float* sens) {
     int ob = m->s_origbody[lane], type = m->s_type[lane];
     float sx = m->s_size[lane][0], sy = m->s_size[lane][1], sz = m->s_size[lane][2];
     for (int c = 0; c < ncon; c++) {
-      const JacoPairParam& P = m->pair[s.c_pair[c]];
-      bool on1 = m->g_origbody[P.g1] == ob, on2 = m->g_origbody[P.g2] == ob;
+      int obs = s.c_ob[c];
+      bool on1 = (obs & 0xFFFF) == ob, on2 = (obs >> 16) == ob;
       if (!on1 && !on2) continue;
       float fn = s.c_fn[c];
       if (!(fn > JMINVAL)) continue;

@@ -92,3 +92,14 @@ JDEV const T* opaque_ptr(const T* p) {
   asm volatile("" : "+s"(p));
   return p;
 }
+
+// 32x32 f32 accumulator tile of v_mfma_f32_32x32x2_f32: element (row, col) lives in lane (col + 32 * ((row >> 2) & 1)),
+// register (row & 3) + 4 * (row >> 3).  One call adds the rank-2 product A[32x2] * B[2x32]:
+// lane l supplies a = A[l & 31][l >> 5] and b = B[l >> 5][l & 31].  Exact f32 fmaf chain (no reduced precision).
+typedef float jaco_f32x16 __attribute__((ext_vector_type(16)));
+struct acc32x32 { jaco_f32x16 v; };
+JDEV void acc_zero(acc32x32& c) {
+#pragma unroll
+  for (int i = 0; i < 16; i++) c.v[i] = 0.f;
+}
+JDEV void wave_mfma_32x32x2(float a, float b, acc32x32& c) { c.v = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c.v, 0, 0, 0); }

@@ -1,6 +1,8 @@
 // Host-side: JACOMDL1 blob (fused view, f_* arrays) -> JacoModelDev + hull vertex table.
 // No HIP dependency so the same loader serves the product library and the CPU-side kernel checks.
 #include "model_blob.h"
+#define JB0 9
+#define JB1 15
 
 #include <cmath>
 #include <cstdint>
@@ -111,6 +113,14 @@ int jaco_model_from_blob(const void* buf, size_t size, JacoModelDev* m, std::vec
   for (int d = 0; d < nv; d++) {
     m->d_parent[d] = dpar[d]; m->d_damping[d] = (float)ddamp[d]; m->d_invweight[d] = (float)diw[d];
     if (ddamp[d] > 0) m->has_damping = 1;
+    if (ddamp[d] > 0 && d >= JB0) FAIL("joint damping outside the arm/finger dof block is not supported by the kernels");
+  }
+  for (int b = 0; b < nb; b++) {   // the kernels' block-diagonal solves assume this dof layout (one block per kinematic tree)
+    int blk = da[b] < JB0 ? 0 : (da[b] < JB1 ? 1 : 2), root = b;
+    while (par[root] >= 0) root = par[root];
+    int rblk = da[root] < JB0 ? 0 : (da[root] < JB1 ? 1 : 2);
+    int n = jt[b] == JJ_FREE ? 6 : 1;
+    if (blk != rblk || (da[b] + n > JB0 && da[b] < JB0) || (da[b] + n > JB1 && da[b] < JB1)) FAIL("dof layout does not match the kernels' blocks [0,9) [9,15) [15,21)");
   }
   for (int b = 0; b < nb; b++) {
     unsigned mask = par[b] >= 0 ? m->b_chainmask[par[b]] : 0u;

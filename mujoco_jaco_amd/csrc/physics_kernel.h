@@ -44,18 +44,20 @@ typedef JacoCaps<256, 64, 128> JacoHeavy;
 
 // Diagnostic build only (-DJACO_PROFILE_STAGES): lane 0 accumulates shader-clock cycles per stage into
 // JacoStepArgs::prof[env][JPROF_N]. The shipped library is built without it (no stamp executes).
-#define JPROF_N 12
+#define JPROF_N 16
+struct JProfCtx {
+  unsigned long long tprev;
+  unsigned long long* row;   // [JPROF_N] of this env, or nullptr
+};
 #ifdef JACO_PROFILE_STAGES
-#define JSTAMP(i)                                                             \
-  do {                                                                        \
-    unsigned long long t_ = __builtin_amdgcn_s_memtime();                     \
-    if (lane == 0 && A.prof) A.prof[(size_t)env * JPROF_N + (i)] += t_ - tprev_; \
-    tprev_ = __builtin_amdgcn_s_memtime();                                    \
-  } while (0)
-#define JSTAMP_INIT unsigned long long tprev_ = __builtin_amdgcn_s_memtime();
+JDEV void jprof_stamp(JProfCtx& pc, int i, int lane) {
+  unsigned long long t = __builtin_amdgcn_s_memtime();
+  if (lane == 0 && pc.row) pc.row[i] += t - pc.tprev;
+  pc.tprev = __builtin_amdgcn_s_memtime();
+}
+#define JSTAMP(i) jprof_stamp(pc, (i), lane)
 #else
 #define JSTAMP(i)
-#define JSTAMP_INIT
 #endif
 
 struct JacoStepArgs {
@@ -120,6 +122,8 @@ struct JacoLDS {
   float c_dist[C::MAXCON], c_pos[C::MAXCON][3], c_frame[C::MAXCON][9], c_fn[C::MAXCON];
   int c_pair[C::MAXCON], c_efc[C::MAXCON];
   unsigned c_m1[C::MAXCON], c_m2[C::MAXCON];   // dof chain masks of the two bodies
+  int c_ob[C::MAXCON];                          // original (unfused) body ids of the two geoms: ob1 | ob2 << 16 (touch sensors)
+  int c_dim[C::MAXCON];
   int cand[C::MAXCAND];
   // constraint rows
   float J[C::MAXEFC * JLD];
@@ -127,7 +131,36 @@ struct JacoLDS {
   int e_con[C::MAXEFC];                         // contact | edge << 8 | block bits << 16
   int ncon, nefc, ncand, nlimit;
   float task[32];
+  // per-launch copy of the small, hot model tables (per-lane gathers from LDS instead of dependent global loads)
+  struct {
+    float b_pos[JNB][3], b_mat[JNB][9], b_axis[JNB][3], b_com[JNB][3], b_qpos0[JNB];
+    int b_jtype[JNB], b_qadr[JNB], b_dadr[JNB], b_writer[JNB], b_parent[JNB];
+    int leaf_depth[JMAXLEAF], leaf_path[JMAXLEAF][JMAXDEPTH];
+    int d_body[JNV], d_parent[JNV];
+    float g_size[JMAXGEOM][3], g_rbound[JMAXGEOM];
+  } mc;
 };
+
+template <class L>
+JDEV void stage_model(const JacoModelDev* m, L& s, int lane) {
+  if (lane < JNB) {
+    int b = lane;
+    for (int k = 0; k < 3; k++) { s.mc.b_pos[b][k] = m->b_pos[b][k]; s.mc.b_axis[b][k] = m->b_axis[b][k]; s.mc.b_com[b][k] = m->b_com[b][k]; }
+    for (int k = 0; k < 9; k++) s.mc.b_mat[b][k] = m->b_mat[b][k];
+    s.mc.b_qpos0[b] = m->b_qpos0[b]; s.mc.b_jtype[b] = m->b_jtype[b]; s.mc.b_qadr[b] = m->b_qadr[b]; s.mc.b_dadr[b] = m->b_dadr[b];
+    s.mc.b_writer[b] = m->b_writer[b]; s.mc.b_parent[b] = m->b_parent[b];
+  }
+  if (lane < JMAXLEAF) {
+    s.mc.leaf_depth[lane] = m->leaf_depth[lane];
+    for (int k = 0; k < JMAXDEPTH; k++) s.mc.leaf_path[lane][k] = m->leaf_path[lane][k];
+  }
+  if (lane < JNV) { s.mc.d_body[lane] = m->d_body[lane]; s.mc.d_parent[lane] = m->d_parent[lane]; }
+  {
+    int g = lane;
+    for (int k = 0; k < 3; k++) s.mc.g_size[g][k] = m->g_size[g][k];
+    s.mc.g_rbound[g] = m->g_rbound[g];
+  }
+}
 
 // ---------------------------------------------------------------- small vector helpers
 struct v3 { float x, y, z; };
@@ -174,7 +207,9 @@ JDEV m3 quat2mat(float w, float x, float y, float z) {
 }
 // rotation by angle about unit axis (Rodrigues)
 JDEV m3 axis_rot(v3 a, float ang) {
-  float s = sinf(ang), c = cosf(ang), t = 1.f - c;
+  float s, c;
+  sincosf(ang, &s, &c);   // one shared range reduction
+  float t = 1.f - c;
   m3 r;
   r.m[0] = c + t * a.x * a.x; r.m[1] = t * a.x * a.y - s * a.z; r.m[2] = t * a.x * a.z + s * a.y;
   r.m[3] = t * a.x * a.y + s * a.z; r.m[4] = c + t * a.y * a.y; r.m[5] = t * a.y * a.z - s * a.x;
@@ -229,6 +264,37 @@ JDEV float ldl_solve(float (&h)[JNV], float b, int lane) {
   }
   return x;
 }
+// Block-diagonal variant that factors only the dof blocks named in `mask` (bit 0: [0,JB0), bit 1: [JB0,JB1), bit 2: [JB1,JNV));
+// lanes of skipped blocks get x = 0.
+template <int LO, int HI>
+JDEV float ldl_block(float (&h)[JNV], float b, int lane) {
+  float dinv = 1.f;
+#pragma unroll
+  for (int k = LO; k < HI; k++) {
+    float dk = wave_bcast(h[k], k);
+    float inv = 1.f / dk;
+    dinv = lane == k ? inv : dinv;
+    float lik = (lane > k && lane < HI) ? h[k] * inv : 0.f;
+#pragma unroll
+    for (int j = k + 1; j < HI; j++) h[j] -= lik * wave_bcast(h[j], k);
+    b -= lik * wave_bcast(b, k);
+  }
+  float z = b * dinv, acc = 0.f, x = 0.f;
+#pragma unroll
+  for (int k = HI - 1; k >= LO; k--) {
+    x = lane == k ? z - dinv * acc : x;
+    float xk = wave_bcast(x, k);
+    acc += (lane < k && lane >= LO) ? h[k] * xk : 0.f;
+  }
+  return (lane >= LO && lane < HI) ? x : 0.f;
+}
+JDEV float ldl_solve_blocks(float (&h)[JNV], float b, int lane, int mask) {
+  float x = 0.f;
+  if (mask & 1) x += ldl_block<0, JB0>(h, b, lane);
+  if (mask & 2) x += ldl_block<JB0, JB1>(h, b, lane);
+  if (mask & 4) x += ldl_block<JB1, JNV>(h, b, lane);
+  return x;
+}
 // inclusive prefix sum over lanes (6 ds_bpermute steps)
 JDEV int wave_scan_incl(int v, int lane) {
 #pragma unroll
@@ -249,7 +315,7 @@ JDEV void stage_walk(const JacoModelDev* m, L& s, int lane) {
   int nleaf = m->nleaf;
   int leaf = lane < nleaf ? lane : nleaf - 1;
   bool pub = lane < nleaf;
-  int depth = m->leaf_depth[leaf];
+  int depth = s.mc.leaf_depth[leaf];
   v3 pos = mk3(0, 0, 0);
   m3 R;
   for (int i = 0; i < 9; i++) R.m[i] = (i % 4 == 0) ? 1.f : 0.f;
@@ -258,14 +324,14 @@ JDEV void stage_walk(const JacoModelDev* m, L& s, int lane) {
   cacc.b = mk3(-m->gravity[0], -m->gravity[1], -m->gravity[2]);
   for (int k = 0; k < JMAXDEPTH; k++) {
     if (k >= depth) break;
-    int b = m->leaf_path[leaf][k];
-    bool wr = pub && m->b_writer[b] == leaf;
-    int da = m->b_dadr[b], qa = m->b_qadr[b];
-    if (m->b_jtype[b] == JJ_HINGE) {
-      v3 ax = ld3(m->b_axis[b]);
-      pos = pos + mul(R, ld3(m->b_pos[b]));
-      m3 Rb = mul(R, ldm(m->b_mat[b]));
-      R = mul(Rb, axis_rot(ax, s.qpos[qa] - m->b_qpos0[b]));
+    int b = s.mc.leaf_path[leaf][k];
+    bool wr = pub && s.mc.b_writer[b] == leaf;
+    int da = s.mc.b_dadr[b], qa = s.mc.b_qadr[b];
+    if (s.mc.b_jtype[b] == JJ_HINGE) {
+      v3 ax = ld3(s.mc.b_axis[b]);
+      pos = pos + mul(R, ld3(s.mc.b_pos[b]));
+      m3 Rb = mul(R, ldm(s.mc.b_mat[b]));
+      R = mul(Rb, axis_rot(ax, s.qpos[qa] - s.mc.b_qpos0[b]));
       sv S;
       S.a = mul(Rb, ax);
       S.b = cross(pos, S.a);
@@ -305,7 +371,7 @@ JDEV void stage_walk(const JacoModelDev* m, L& s, int lane) {
     if (wr) {
       st3(s.xpos[b], pos);
       stm(s.xmat[b], R);
-      st3(s.xipos[b], pos + mul(R, ld3(m->b_com[b])));
+      st3(s.xipos[b], pos + mul(R, ld3(s.mc.b_com[b])));
       stsv(s.cvel[b], cvel);
       stsv(s.cacc[b], cacc);
     }
@@ -356,7 +422,7 @@ JDEV void stage_geoms_inertia(const JacoModelDev* m, L& s, int lane) {
 template <class L>
 JDEV void stage_accumulate(const JacoModelDev* m, L& s, int lane) {
   for (int b = m->nbody - 1; b > 0; b--) {
-    int p = m->b_parent[b];
+    int p = s.mc.b_parent[b];
     if (p < 0) continue;
     if (lane < 10) s.crb[p][lane] += s.crb[b][lane];
     else if (lane >= 16 && lane < 22) s.cfrc[p][lane - 16] += s.cfrc[b][lane - 16];
@@ -367,10 +433,10 @@ JDEV void stage_accumulate(const JacoModelDev* m, L& s, int lane) {
 template <class L>
 JDEV void stage_mass_bias(const JacoModelDev* m, L& s, int lane) {
   if (lane < m->nv) {
-    int d = lane, b = m->d_body[d];
+    int d = lane, b = s.mc.d_body[d];
     sv S = ldsv(s.cdof[d]);
     sv F = inert_mul(s.crb[b], S);
-    for (int j = d; j >= 0; j = m->d_parent[j]) {
+    for (int j = d; j >= 0; j = s.mc.d_parent[j]) {
       float v = dot(ldsv(s.cdof[j]), F);
       s.M[d * JNV + j] = v;
       s.M[j * JNV + d] = v;
@@ -396,21 +462,24 @@ JDEV void stage_actuation(const JacoModelDev* m, L& s, int lane) {
 // impedance d(r) and reference acceleration of MuJoCo's soft constraints
 JDEV float impedance(const float* solimp, float pos) {
   float dmin = fminf(0.9999f, fmaxf(0.0001f, solimp[0])), dmax = fminf(0.9999f, fmaxf(0.0001f, solimp[1]));
+  if (dmin == dmax) return dmax;   // flat impedance curve (every contact pair of this model that involves the object or a finger)
   float width = fmaxf(JMINVAL, solimp[2]), mid = fminf(0.9999f, fmaxf(0.0001f, solimp[3])), power = fmaxf(1.f, solimp[4]);
   float x = fabsf(pos) / width, y;
   if (x >= 1.f) return dmax;
   if (power == 1.f) y = x;
+  else if (power == 2.f) y = x <= mid ? x * x / mid : 1.f - (1.f - x) * (1.f - x) / (1.f - mid);
   else if (x <= mid) y = powf(x, power) / powf(mid, power - 1.f);
   else y = 1.f - powf(1.f - x, power) / powf(1.f - mid, power - 1.f);
   return dmin + y * (dmax - dmin);
 }
-// returns aref; *D = 1/R
-JDEV float row_params(const float* solref, const float* solimp, float pos, float vel, float diagApprox, float* Rout) {
+// returns aref; *Rout = regulariser R for the given diagApprox; *imp_out = impedance (reused by the caller)
+JDEV float row_params(const float* solref, const float* solimp, float pos, float vel, float diagApprox, float* Rout, float* imp_out = nullptr) {
   float imp = impedance(solimp, pos);
   float dmax = fminf(0.9999f, fmaxf(0.0001f, solimp[1]));
   float K = 1.f / fmaxf(JMINVAL, dmax * dmax * solref[0] * solref[0] * solref[1] * solref[1]);
   float B = 2.f / fmaxf(JMINVAL, dmax * solref[0]);
   *Rout = fmaxf(JMINVAL, (1.f - imp) * diagApprox / imp);
+  if (imp_out) *imp_out = imp;
   return -B * vel - K * imp * pos;
 }
 
@@ -443,6 +512,7 @@ JDEV void stage_limit_rows(const JacoModelDev* m, L& s, int lane) {
 // ---------------------------------------------------------------- stage S: primal Newton solver
 // Lane k < nv owns element k of every dof vector and row k of M / H; lane r owns constraint rows r + 64 q.
 struct NewtonOut { float qacc, qfrc_con; int iters; };
+#define JDAMPED_BLOCKS 1   // implicit joint damping only exists on the finger dofs (block 0); checked by the host loader
 
 // out[q] = sum_k J[row(q)][k] * v[k] for the lane's NR rows; v distributed one element per lane.
 // NR == 1 keeps the lane's J row in registers (jrow) for the whole solve: no LDS traffic here.
@@ -493,7 +563,8 @@ JDEV float jt_vec(const float* J, const float (&f)[NR], int ne, int lane, int nv
 }
 
 template <class L>
-JDEV NewtonOut stage_newton(const JacoModelDev* m, L& s, const float (&mrow)[JNV], int lane) {
+JDEV NewtonOut stage_newton(const JacoModelDev* m, L& s, const float (&mrow)[JNV], int lane, JProfCtx& pc) {
+  (void)pc;
   constexpr int NR = L::Caps::NR, MAXEFC = L::Caps::MAXEFC;
   NewtonOut out;
   int nv = m->nv, ne = s.nefc;
@@ -518,9 +589,15 @@ JDEV NewtonOut stage_newton(const JacoModelDev* m, L& s, const float (&mrow)[JNV
   float scale = 1.f / (m->meaninertia * (float)(nv > 1 ? nv : 1));
   float tol = m->tolerance;
 
+  // dof blocks that carry any constraint row; for the others the optimum is exactly qacc_smooth and stays there
+  int rowblk = 0;
+#pragma unroll
+  for (int q = 0; q < NR; q++) rowblk |= blk[q];
+  const int rowblocks = (wave_ballot(rowblk & 1) ? 1 : 0) | (wave_ballot(rowblk & 2) ? 2 : 0) | (wave_ballot(rowblk & 4) ? 4 : 0);
+  const bool mine = ((lane < JB0 ? 1 : (lane < JB1 ? 2 : 4)) & rowblocks) != 0;
   // starting point: cheaper of warm start and unconstrained acceleration
   // (cross-lane helpers are always called by all 64 lanes; validity is applied to their results)
-  float a = lane < nv ? s.qacc_ws[lane] : 0.f;
+  float a = (lane < nv && mine) ? s.qacc_ws[lane] : qas;
   float Ma = mat_vec(mrow, a - qas);
   rows_dot<NR>(s.J, jrow, a, lane, ne, nv, x);
   rows_dot<NR>(s.J, jrow, qas, lane, ne, nv, xs);
@@ -549,30 +626,42 @@ JDEV NewtonOut stage_newton(const JacoModelDev* m, L& s, const float (&mrow)[JNV
       coupled = coupled || (x[q] < 0.f && (blk[q] & (blk[q] - 1)) != 0);   // active row touching two dof blocks
     }
     bool full = wave_ballot(coupled) != 0ull;
-    float grad = Ma - jt_vec<NR>(s.J, f, ne, lane, nv);
-    float gn = sqrtf(wave_sum(grad * grad));
-    if (gn * scale < tol) break;
-    // Hessian rows: M + sum_active D_r J_r^T J_r  (lane i accumulates row i; J_r[j] arrive as LDS broadcasts)
-    float h[JNV];
-#pragma unroll
-    for (int j2 = 0; j2 < JNV; j2++) h[j2] = lane < nv ? mrow[j2] : (lane == j2 ? 1.f : 0.f);
-    int kk = lane < nv ? lane : 0;
+    // One matrix-core pass builds both the Hessian term and J^T f:  C = Jh^T diag(D*active) Jh  with Jh = [J | -x]
+    // (32 columns: 21 dofs, column 21 = -x, rest zero), two constraint rows per v_mfma_f32_32x32x2_f32.
+    // C[0..20][0..20] = sum_active D_r J_r^T J_r,  C[21][0..20] = J^T f  (f_r = -D_r x_r on active rows).
+    acc32x32 C;
+    acc_zero(C);
+    const int uh = lane >> 5, col = lane & 31;
 #pragma unroll
     for (int q = 0; q < NR; q++) {
       float w = x[q] < 0.f ? D[q] : 0.f;
       int n = ne - 64 * q;
       n = n > 64 ? 64 : n;
-      for (int rl = 0; rl < n; rl++) {
-        float Dr = wave_bcast(w, rl);
-        if (Dr == 0.f) continue;
-        const float* Jr = s.J + (64 * q + rl) * JLD;
-        float wj = lane < nv ? Dr * Jr[kk] : 0.f;
-#pragma unroll
-        for (int j2 = 0; j2 < JNV; j2++) h[j2] += wj * Jr[j2];
+      for (int rl = 0; rl < n; rl += 2) {
+        float x0 = wave_bcast(x[q], rl), x1 = wave_bcast(x[q], rl + 1), w0 = wave_bcast(w, rl), w1 = wave_bcast(w, rl + 1);
+        bool ok = rl + uh < n;
+        float xr = uh ? x1 : x0, wr = ok ? (uh ? w1 : w0) : 0.f;
+        float jv = (ok && col < JNV) ? s.J[(64 * q + rl + uh) * JLD + col] : 0.f;
+        float av = col == JNV ? (ok ? -xr : 0.f) : jv;
+        wave_mfma_32x32x2(av, wr * av, C);
       }
     }
-    float p = full ? ldl_solve<true>(h, -grad, lane) : ldl_solve<false>(h, -grad, lane);
+    JSTAMP(12);
+    // C is symmetric: row j of the tile, column `lane`, is where lane `lane` finds H[lane][j]
+    float h[JNV];
+#pragma unroll
+    for (int j2 = 0; j2 < JNV; j2++) {
+      const int reg = (j2 & 3) + 4 * (j2 >> 3);
+      float cv = ((j2 >> 2) & 1) ? wave_shfl(C.v[reg], (lane + 32) & 63) : C.v[reg];
+      h[j2] = lane < nv ? mrow[j2] + cv : (lane == j2 ? 1.f : 0.f);
+    }
+    float jtf = wave_shfl(C.v[(JNV & 3) + 4 * (JNV >> 3)], (lane + 32) & 63);   // row 21 sits in the upper lane half
+    float grad = Ma - (lane < nv ? jtf : 0.f);
+    float gn = sqrtf(wave_sum(grad * grad));
+    if (gn * scale < tol) break;
+    float p = full ? ldl_solve<true>(h, -grad, lane) : ldl_solve_blocks(h, -grad, lane, rowblocks);
     p = lane < nv ? p : 0.f;
+    JSTAMP(13);
     // exact line search on phi(al) = cost(a + al p)
     float Mp = mat_vec(mrow, p);
     float pMp = wave_sum(p * Mp), pMa = wave_sum(p * Ma);
@@ -608,6 +697,7 @@ JDEV NewtonOut stage_newton(const JacoModelDev* m, L& s, const float (&mrow)[JNV
       x[q] = xn;
     }
     float improvement = -(al * pMa + 0.5f * al * al * pMp + wave_sum(dc));
+    JSTAMP(14);
     a += al * p; Ma += al * Mp;
     if (improvement * scale < tol) { it++; break; }
   }
@@ -636,7 +726,8 @@ JDEV void stage_integrate_pos(const JacoModelDev* m, L& s, int lane) {
       float q0 = s.qpos[qa + 3], q1 = s.qpos[qa + 4], q2 = s.qpos[qa + 5], q3 = s.qpos[qa + 6];
       if (ang > 0.f) {
         v3 ax = w * (1.f / wn);
-        float sn = sinf(0.5f * ang), c = cosf(0.5f * ang);
+        float sn, c;
+        sincosf(0.5f * ang, &sn, &c);
         float d1 = ax.x * sn, d2 = ax.y * sn, d3 = ax.z * sn;
         float n0 = q0 * c - q1 * d1 - q2 * d2 - q3 * d3;
         float n1 = q0 * d1 + q1 * c + q2 * d3 - q3 * d2;
@@ -666,6 +757,7 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
   if (lane < nq) s.qpos[lane] = A.qpos[(size_t)env * nq + lane];
   if (lane < nv) { s.qvel[lane] = A.qvel[(size_t)env * nv + lane]; s.qacc_ws[lane] = A.qacc_ws[(size_t)env * nv + lane]; }
   if (lane < nu) s.ctrl[lane] = A.ctrl[(size_t)env * nu + lane];
+  stage_model(m, s, lane);
   unsigned flags = LIGHT ? 0u : JFLAG_HEAVY_TIER;
   float sens = 0.f;
   int iters = 0, left = 0, sub0 = 0;
@@ -692,7 +784,13 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
       wave_sync();
     }
   }
-  JSTAMP_INIT
+  JProfCtx pc;
+  pc.row = nullptr;
+  pc.tprev = 0;
+#ifdef JACO_PROFILE_STAGES
+  pc.row = A.prof ? A.prof + (size_t)env * JPROF_N : nullptr;
+  pc.tprev = __builtin_amdgcn_s_memtime();
+#endif
   for (int sub = sub0; sub < nsub; sub++) {
     m = opaque_ptr(A.model);
     if (emode == 1) {
@@ -729,7 +827,7 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
     JSTAMP(3);
     unsigned cflags = 0;
     if (!A.disable_contact) {
-      stage_collision(A, m, s, lane, cflags);
+      stage_collision(A, m, s, lane, cflags, pc);
       wave_sync();
       JSTAMP(4);
       stage_contact_rows(m, s, lane, cflags);
@@ -756,7 +854,7 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
     if (lane < nv) s.qacc_smooth[lane] = qas;
     wave_sync();
     flags |= cflags;
-    NewtonOut nw = stage_newton(m, s, mrow, lane);
+    NewtonOut nw = stage_newton(m, s, mrow, lane, pc);
     JSTAMP(6);
     iters = nw.iters;
     if (iters >= m->iterations) flags |= JFLAG_SOLVER_MAXITER;
@@ -765,11 +863,12 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
     JSTAMP(7);
     // Euler with implicit joint damping
     float total = smooth + nw.qfrc_con, qacc_e = nw.qacc;
-    if (m->has_damping) {
+    if (m->has_damping) {   // (M + h D) qacc = total; blocks without damping keep the solver's qacc (M qacc = total there)
       float hd = lane < nv ? m->timestep * m->d_damping[lane] : 0.f;
 #pragma unroll
       for (int j = 0; j < JNV; j++) h[j] = (lane < nv ? mrow[j] : 0.f) + (lane == j ? (lane < nv ? hd : 1.f) : 0.f);
-      qacc_e = ldl_solve<false>(h, total, lane);
+      float qd = ldl_solve_blocks(h, total, lane, JDAMPED_BLOCKS);
+      qacc_e = lane < JB0 ? qd : nw.qacc;
     }
     if (A.dbg && env == A.dbg_env && sub == nsub - 1) {
       float* D = A.dbg;

@@ -85,3 +85,21 @@ JDEV const T* opaque_ptr(const T* p) {
   asm volatile("" : "+r"(p));
   return p;
 }
+
+struct acc32x32 { float v[16]; };
+JDEV void acc_zero(acc32x32& c) { for (int i = 0; i < 16; i++) c.v[i] = 0.f; }
+JDEV void wave_mfma_32x32x2(float a, float b, acc32x32& c) {
+  int p = emu_post_f(a);
+  emu_collective();
+  float as[64];
+  for (int l = 0; l < 64; l++) as[l] = emu_x[p][l].f;
+  int q = emu_post_f(b);
+  emu_collective();
+  int lane = emu_cur_lane, col = lane & 31;
+  for (int reg = 0; reg < 16; reg++) {
+    int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+    float acc = c.v[reg];
+    for (int k = 0; k < 2; k++) acc = fmaf(as[row + 32 * k], emu_x[q][col + 32 * k].f, acc);
+    c.v[reg] = acc;
+  }
+}

@@ -15,16 +15,18 @@ q = torch.tensor(workload.reset_states(M["qpos0"], B), dtype=torch.float32, devi
 c = torch.tensor(workload.random_ctrl(B, scale=0.2), dtype=torch.float32, device=env.device)
 env.set_state(q, None, None)
 env.send_forces(c, nsub=100); torch.cuda.synchronize()   # settle initial interpenetration
-prof = np.zeros((B, 12), np.uint64)
+prof = np.zeros((B, 16), np.uint64)
 env._chk(env.L.jaco_stage_profile(env.h, prof.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), 1))
 t = time.time(); env.send_forces(c, nsub=nsub); torch.cuda.synchronize(); dt = time.time() - t
 env._chk(env.L.jaco_stage_profile(env.h, prof.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), 1))
-names = ["walk", "geoms+inertia", "accum+mass+act", "qacc_smooth+limits", "collision", "contact rows", "newton", "touch", "euler+integrate"]
-per = prof[:, :9].astype(np.float64) / nsub
+names = ["walk", "geoms+inertia", "accum+mass+act", "limit rows", "collision: narrowphase", "contact rows", "newton: rest (start, qacc_smooth, final)", "touch",
+         "euler+integrate", "collision: spheres", "collision: OBB cull", "-", "newton: MFMA H build", "newton: H fetch+LDL", "newton: line search", "-"]
+per = prof[:, :16].astype(np.float64) / nsub
 print("B", B, "nsub", nsub, "substeps/s %.3g" % (B * nsub / dt), "flags", int(env.flags().max()))
 st = env.stats().cpu().numpy()
 print("stats mean", st.mean(0), "max", st.max(0))
 tot = per.sum(1)
 for i, n in enumerate(names):
-    print("%-20s mean %9.0f cyc  (%4.1f%%)  p99 %9.0f" % (n, per[:, i].mean(), 100 * per[:, i].mean() / tot.mean(), np.percentile(per[:, i], 99)))
+    if n == '-': continue
+    print("%-42s mean %9.0f cyc  (%4.1f%%)  p99 %9.0f" % (n, per[:, i].mean(), 100 * per[:, i].mean() / tot.mean(), np.percentile(per[:, i], 99)))
 print("total per substep: mean %.0f cycles, p50 %.0f, p99 %.0f, max %.0f" % (tot.mean(), np.median(tot), np.percentile(tot, 99), tot.max()))
