@@ -309,72 +309,102 @@ JDEV void load_rows(float (&h)[JNV], const float* M, int nv, int lane) {
   for (int j = 0; j < JNV; j++) h[j] = lane < nv ? M[lane * JNV + j] : (lane == j ? 1.f : 0.f);
 }
 
-// ---------------------------------------------------------------- stage K: tree walk
+// ---------------------------------------------------------------- stage K: kinematic tree
+// K1 (lane = body): joint-local transform T_b = [R_b0 Rot(axis, q - q0) | pos_b] (free bodies: world pose from qpos).
+// K2 (lane = body): world frame = product of the ancestors' T (parent pointers, <= 7 levels), motion subspaces S_d,
+//                   and S_d * qvel_d per dof.
+// K3 (lane = body): body velocity = sum of S_d qvel_d over the dofs that move it;  K4 (lane = dof): S_d-dot * qvel_d with
+//                   the velocity "before" that dof;  K5 (lane = body): bias acceleration = -gravity + sum over the chain.
+// Scratch: s.cinert/s.crb (rebuilt right after) and the not-yet-built constraint-row area s.J.
 template <class L>
 JDEV void stage_walk(const JacoModelDev* m, L& s, int lane) {
-  int nleaf = m->nleaf;
-  int leaf = lane < nleaf ? lane : nleaf - 1;
-  bool pub = lane < nleaf;
-  int depth = s.mc.leaf_depth[leaf];
-  v3 pos = mk3(0, 0, 0);
-  m3 R;
-  for (int i = 0; i < 9; i++) R.m[i] = (i % 4 == 0) ? 1.f : 0.f;
-  sv cvel, cacc;
-  cvel.a = cvel.b = cacc.a = mk3(0, 0, 0);
-  cacc.b = mk3(-m->gravity[0], -m->gravity[1], -m->gravity[2]);
-  for (int k = 0; k < JMAXDEPTH; k++) {
-    if (k >= depth) break;
-    int b = s.mc.leaf_path[leaf][k];
-    bool wr = pub && s.mc.b_writer[b] == leaf;
-    int da = s.mc.b_dadr[b], qa = s.mc.b_qadr[b];
-    if (s.mc.b_jtype[b] == JJ_HINGE) {
-      v3 ax = ld3(s.mc.b_axis[b]);
-      pos = pos + mul(R, ld3(s.mc.b_pos[b]));
-      m3 Rb = mul(R, ldm(s.mc.b_mat[b]));
-      R = mul(Rb, axis_rot(ax, s.qpos[qa] - s.mc.b_qpos0[b]));
-      sv S;
-      S.a = mul(Rb, ax);
-      S.b = cross(pos, S.a);
-      float qd = s.qvel[da];
-      sv Sd = cross_motion(cvel, S);
-      cacc = cacc + Sd * qd;
-      cvel = cvel + S * qd;
-      if (wr) stsv(s.cdof[da], S);
+  const int nb = m->nbody, nv = m->nv;
+  float* T = &s.cinert[0][0];    // [JNB][12] local transforms (cinert+crb are contiguous: 2 * JNB * 10 floats)
+  float* Sq = s.J;               // [JNV][6] S_d * qvel_d      (the constraint-row area is free at this point)
+  float* Sq2 = s.J + JNV * 6;    // [JNV][6] S_d-dot * qvel_d
+  const bool isb = lane < nb;
+  const int b = isb ? lane : 0;
+  const int jt = s.mc.b_jtype[b], qa = s.mc.b_qadr[b], da = s.mc.b_dadr[b];
+  if (isb) {
+    m3 Rl; v3 pl;
+    if (jt == JJ_HINGE) {
+      Rl = mul(ldm(s.mc.b_mat[b]), axis_rot(ld3(s.mc.b_axis[b]), s.qpos[qa] - s.mc.b_qpos0[b]));
+      pl = ld3(s.mc.b_pos[b]);
     } else {
-      pos = ld3(&s.qpos[qa]);
       float w = s.qpos[qa + 3], x = s.qpos[qa + 4], y = s.qpos[qa + 5], z = s.qpos[qa + 6];
       float n = sqrtf(w * w + x * x + y * y + z * z);
       if (n < JMINVAL) { w = 1.f; x = y = z = 0.f; } else { float in = 1.f / n; w *= in; x *= in; y *= in; z *= in; }
-      R = quat2mat(w, x, y, z);
-      // translational dofs: world axes, no cdof_dot
-      sv St[3], Sr[3];
+      Rl = quat2mat(w, x, y, z);
+      pl = ld3(&s.qpos[qa]);
+    }
+    stm(T + 12 * b, Rl);
+    st3(T + 12 * b + 9, pl);
+  }
+  wave_sync();
+  m3 R; v3 pos;
+  if (isb) {
+    R = ldm(T + 12 * b); pos = ld3(T + 12 * b + 9);
+    for (int p = s.mc.b_parent[b]; p >= 0; p = s.mc.b_parent[p]) {   // left-multiply by the ancestors' transforms
+      m3 Rp = ldm(T + 12 * p);
+      pos = ld3(T + 12 * p + 9) + mul(Rp, pos);
+      R = mul(Rp, R);
+    }
+  }
+  wave_sync();   // T is dead from here on (cinert / crb get rebuilt by stage G)
+  if (isb) {
+    st3(s.xpos[b], pos);
+    stm(s.xmat[b], R);
+    st3(s.xipos[b], pos + mul(R, ld3(s.mc.b_com[b])));
+    if (jt == JJ_HINGE) {
+      sv S;
+      S.a = mul(R, ld3(s.mc.b_axis[b]));   // the joint rotation leaves its own axis invariant
+      S.b = cross(pos, S.a);
+      stsv(s.cdof[da], S);
+      stsv(Sq + 6 * da, S * s.qvel[da]);
+    } else {
 #pragma unroll
       for (int c = 0; c < 3; c++) {
-        St[c].a = mk3(0, 0, 0);
-        St[c].b = mk3(c == 0 ? 1.f : 0.f, c == 1 ? 1.f : 0.f, c == 2 ? 1.f : 0.f);
-        cvel = cvel + St[c] * s.qvel[da + c];
-        Sr[c].a = col(R, c);
-        Sr[c].b = cross(pos, Sr[c].a);
-      }
-      sv vbase = cvel;
-#pragma unroll
-      for (int c = 0; c < 3; c++) {
-        float qd = s.qvel[da + 3 + c];
-        cacc = cacc + cross_motion(vbase, Sr[c]) * qd;
-        cvel = cvel + Sr[c] * qd;
-      }
-      if (wr) {
-#pragma unroll
-        for (int c = 0; c < 3; c++) { stsv(s.cdof[da + c], St[c]); stsv(s.cdof[da + 3 + c], Sr[c]); }
+        sv St, Sr;
+        St.a = mk3(0, 0, 0);
+        St.b = mk3(c == 0 ? 1.f : 0.f, c == 1 ? 1.f : 0.f, c == 2 ? 1.f : 0.f);
+        Sr.a = col(R, c);
+        Sr.b = cross(pos, Sr.a);
+        stsv(s.cdof[da + c], St); stsv(s.cdof[da + 3 + c], Sr);
+        stsv(Sq + 6 * (da + c), St * s.qvel[da + c]); stsv(Sq + 6 * (da + 3 + c), Sr * s.qvel[da + 3 + c]);
       }
     }
-    if (wr) {
-      st3(s.xpos[b], pos);
-      stm(s.xmat[b], R);
-      st3(s.xipos[b], pos + mul(R, ld3(s.mc.b_com[b])));
-      stsv(s.cvel[b], cvel);
-      stsv(s.cacc[b], cacc);
+  }
+  wave_sync();
+  if (isb) {   // body velocity: own dofs + all ancestors' dofs
+    sv v; v.a = v.b = mk3(0, 0, 0);
+    int nd = jt == JJ_HINGE ? 1 : 6;
+    for (int c = 0; c < nd; c++) v = v + ldsv(Sq + 6 * (da + c));
+    for (int p = s.mc.b_parent[b]; p >= 0; p = s.mc.b_parent[p]) v = v + ldsv(Sq + 6 * s.mc.b_dadr[p]);   // ancestors are hinges
+    stsv(s.cvel[b], v);
+  }
+  wave_sync();
+  if (lane < nv) {   // S_d-dot * qvel_d, S_d-dot = (velocity before dof d) x_m S_d
+    int d = lane, bd = s.mc.d_body[d], pb = s.mc.b_parent[bd];
+    sv vb; vb.a = vb.b = mk3(0, 0, 0);
+    if (pb >= 0) vb = ldsv(s.cvel[pb]);
+    sv r; r.a = r.b = mk3(0, 0, 0);
+    int k = d - s.mc.b_dadr[bd];
+    if (s.mc.b_jtype[bd] == JJ_HINGE) r = cross_motion(vb, ldsv(s.cdof[d])) * s.qvel[d];
+    else if (k >= 3) {   // free joint: translations have no S-dot; all three rotations see parent + translational velocity
+      int d0 = s.mc.b_dadr[bd];
+      sv vt = vb + ldsv(Sq + 6 * d0) + ldsv(Sq + 6 * (d0 + 1)) + ldsv(Sq + 6 * (d0 + 2));
+      r = cross_motion(vt, ldsv(s.cdof[d])) * s.qvel[d];
     }
+    stsv(Sq2 + 6 * d, r);
+  }
+  wave_sync();
+  if (isb) {
+    sv a; a.a = mk3(0, 0, 0);
+    a.b = mk3(-m->gravity[0], -m->gravity[1], -m->gravity[2]);
+    int nd = jt == JJ_HINGE ? 1 : 6;
+    for (int c = 0; c < nd; c++) a = a + ldsv(Sq2 + 6 * (da + c));
+    for (int p = s.mc.b_parent[b]; p >= 0; p = s.mc.b_parent[p]) a = a + ldsv(Sq2 + 6 * s.mc.b_dadr[p]);
+    stsv(s.cacc[b], a);
   }
 }
 
