@@ -129,6 +129,7 @@ struct JacoLDS {
   float J[C::MAXEFC * JLD];
   float e_aref[C::MAXEFC], e_D[C::MAXEFC], e_f[C::MAXEFC];
   int e_con[C::MAXEFC];                         // contact | edge << 8 | block bits << 16
+  float e_x[C::MAXEFC > 64 ? C::MAXEFC : 1];    // heavy tier only: residuals staged for the MFMA pass (light reuses `smooth`)
   int ncon, nefc, ncand, nlimit;
   float task[32];
   // per-launch copy of the small, hot model tables (per-lane gathers from LDS instead of dependent global loads)
@@ -593,17 +594,22 @@ JDEV float jt_vec(const float* J, const float (&f)[NR], int ne, int lane, int nv
 }
 
 template <class L>
-JDEV NewtonOut stage_newton(const JacoModelDev* m, L& s, const float (&mrow)[JNV], int lane, JProfCtx& pc) {
+JDEV NewtonOut stage_newton(const JacoModelDev* m, L& s, const float (&mrow)[JNV], float smooth, int lane, JProfCtx& pc) {
   (void)pc;
   constexpr int NR = L::Caps::NR, MAXEFC = L::Caps::MAXEFC;
   NewtonOut out;
   int nv = m->nv, ne = s.nefc;
-  float qas = lane < nv ? s.qacc_smooth[lane] : 0.f;
-  out.qacc = qas; out.qfrc_con = 0.f; out.iters = 0;
-  if (ne == 0) return out;
+  out.qfrc_con = 0.f; out.iters = 0;
+  float h0[JNV];
+#pragma unroll
+  for (int j = 0; j < JNV; j++) h0[j] = lane < nv ? mrow[j] : (lane == j ? 1.f : 0.f);
+  if (ne == 0) {   // unconstrained: qacc = M^-1 qfrc_smooth
+    out.qacc = ldl_solve<false>(h0, smooth, lane);
+    return out;
+  }
   if (ne > MAXEFC) ne = MAXEFC;
   bool valid[NR];
-  float D[NR], ar[NR], x[NR], xs[NR], f[NR], jp[NR];
+  float D[NR], ar[NR], x[NR], f[NR], jp[NR];
   int blk[NR];
   float jrow[JNV];
 #pragma unroll
@@ -618,36 +624,25 @@ JDEV NewtonOut stage_newton(const JacoModelDev* m, L& s, const float (&mrow)[JNV
   for (int k = 0; k < JNV; k++) jrow[k] = (NR == 1 && lane < ne) ? s.J[lane * JLD + k] : 0.f;
   float scale = 1.f / (m->meaninertia * (float)(nv > 1 ? nv : 1));
   float tol = m->tolerance;
-
-  // dof blocks that carry any constraint row; for the others the optimum is exactly qacc_smooth and stays there
+  // dof blocks that carry any constraint row; for the others the optimum is exactly M^-1 qfrc_smooth and stays there
   int rowblk = 0;
 #pragma unroll
   for (int q = 0; q < NR; q++) rowblk |= blk[q];
   const int rowblocks = (wave_ballot(rowblk & 1) ? 1 : 0) | (wave_ballot(rowblk & 2) ? 2 : 0) | (wave_ballot(rowblk & 4) ? 4 : 0);
-  const bool mine = ((lane < JB0 ? 1 : (lane < JB1 ? 2 : 4)) & rowblocks) != 0;
-  // starting point: cheaper of warm start and unconstrained acceleration
-  // (cross-lane helpers are always called by all 64 lanes; validity is applied to their results)
-  float a = (lane < nv && mine) ? s.qacc_ws[lane] : qas;
-  float Ma = mat_vec(mrow, a - qas);
+  const bool mine = lane < nv && ((lane < JB0 ? 1 : (lane < JB1 ? 2 : 4)) & rowblocks) != 0;
+  float afree = ldl_solve_blocks(h0, smooth, lane, ~rowblocks & 7);
+  // Primal problem in terms of qfrc_smooth (same optimum as MuJoCo's (a - a_s)' M (a - a_s) form, no M^-1 needed for
+  // the blocks that carry rows):  minimise 1/2 a'Ma - a'qfrc_smooth + sum_i 1/2 D_i min(0, J_i a - aref_i)^2.
+  // Start: warm start on the row-carrying blocks (MuJoCo additionally compares it with the unconstrained point; with
+  // an exact line search either start reaches the same optimum), exact solution elsewhere.
+  float a = mine ? s.qacc_ws[lane] : afree;
+  float Ma = mat_vec(mrow, a) - smooth;   // from here on "Ma" = gradient of the smooth part, M a - qfrc_smooth
+  Ma = mine ? Ma : 0.f;
   rows_dot<NR>(s.J, jrow, a, lane, ne, nv, x);
-  rows_dot<NR>(s.J, jrow, qas, lane, ne, nv, xs);
-  float cw = 0.5f * Ma * (a - qas), cs = 0.f;
 #pragma unroll
-  for (int q = 0; q < NR; q++) {
-    x[q] = valid[q] ? x[q] - ar[q] : 0.f;
-    xs[q] = valid[q] ? xs[q] - ar[q] : 0.f;
-    cw += x[q] < 0.f ? 0.5f * D[q] * x[q] * x[q] : 0.f;
-    cs += xs[q] < 0.f ? 0.5f * D[q] * xs[q] * xs[q] : 0.f;
-  }
-  cw = wave_sum(cw);
-  cs = wave_sum(cs);
-  if (!(cw < cs)) {
-    a = qas; Ma = 0.f;
-#pragma unroll
-    for (int q = 0; q < NR; q++) x[q] = xs[q];
-  }
-
-  int it = 0;
+  for (int q = 0; q < NR; q++) x[q] = valid[q] ? x[q] - ar[q] : 0.f;
+  JSTAMP(11);
+  int it = 0, nls = 0;
   for (; it < m->iterations; it++) {
     bool coupled = false;
 #pragma unroll
@@ -659,22 +654,28 @@ JDEV NewtonOut stage_newton(const JacoModelDev* m, L& s, const float (&mrow)[JNV
     // One matrix-core pass builds both the Hessian term and J^T f:  C = Jh^T diag(D*active) Jh  with Jh = [J | -x]
     // (32 columns: 21 dofs, column 21 = -x, rest zero), two constraint rows per v_mfma_f32_32x32x2_f32.
     // C[0..20][0..20] = sum_active D_r J_r^T J_r,  C[21][0..20] = J^T f  (f_r = -D_r x_r on active rows).
+    // Per-row weights and residuals are staged in LDS so that every operand of a step is an independent LDS read
+    // (4 steps in flight): e_f is only written at the very end; smooth / qacc_smooth / qfrc_con are dead by now.
+    float* xs = NR == 1 ? s.smooth : s.e_x;
+#pragma unroll
+    for (int q = 0; q < NR; q++) if (valid[q]) { s.e_f[lane + 64 * q] = x[q] < 0.f ? D[q] : 0.f; xs[lane + 64 * q] = x[q]; }
+    wave_sync();
     acc32x32 C;
     acc_zero(C);
     const int uh = lane >> 5, col = lane & 31;
+    for (int r0 = 0; r0 < ne; r0 += 8) {
+      float jv[4], wv[4];
 #pragma unroll
-    for (int q = 0; q < NR; q++) {
-      float w = x[q] < 0.f ? D[q] : 0.f;
-      int n = ne - 64 * q;
-      n = n > 64 ? 64 : n;
-      for (int rl = 0; rl < n; rl += 2) {
-        float x0 = wave_bcast(x[q], rl), x1 = wave_bcast(x[q], rl + 1), w0 = wave_bcast(w, rl), w1 = wave_bcast(w, rl + 1);
-        bool ok = rl + uh < n;
-        float xr = uh ? x1 : x0, wr = ok ? (uh ? w1 : w0) : 0.f;
-        float jv = (ok && col < JNV) ? s.J[(64 * q + rl + uh) * JLD + col] : 0.f;
-        float av = col == JNV ? (ok ? -xr : 0.f) : jv;
-        wave_mfma_32x32x2(av, wr * av, C);
+      for (int u = 0; u < 4; u++) {
+        int r = r0 + 2 * u + uh;
+        bool ok = r < ne;
+        float xv = ok ? xs[r] : 0.f;
+        jv[u] = (ok && col < JNV) ? s.J[r * JLD + col] : 0.f;
+        jv[u] = col == JNV ? -xv : jv[u];
+        wv[u] = ok ? s.e_f[r] : 0.f;
       }
+#pragma unroll
+      for (int u = 0; u < 4; u++) wave_mfma_32x32x2(jv[u], wv[u] * jv[u], C);
     }
     JSTAMP(12);
     // C is symmetric: row j of the tile, column `lane`, is where lane `lane` finds H[lane][j]
@@ -715,6 +716,7 @@ JDEV NewtonOut stage_newton(const JacoModelDev* m, L& s, const float (&mrow)[JNV
       if (!(nx > lo && nx < hi)) nx = hi < 1.0e38f ? 0.5f * (lo + hi) : 2.f * al + 1.f;
       if (nx == al) break;
       al = nx;
+      nls++;
     }
     // move; the cost decrease is evaluated along the line in cancellation-free form so that MuJoCo's absolute
     // tolerance stays meaningful in fp32 (the 1280 kg pedestal's cost terms are ~1e3, the object's ~1e-3)
@@ -735,7 +737,7 @@ JDEV NewtonOut stage_newton(const JacoModelDev* m, L& s, const float (&mrow)[JNV
   for (int q = 0; q < NR; q++) f[q] = x[q] < 0.f ? -D[q] * x[q] : 0.f;
   out.qacc = a;
   out.qfrc_con = jt_vec<NR>(s.J, f, ne, lane, nv);
-  out.iters = it;
+  out.iters = it | (nls << 8);
 #pragma unroll
   for (int q = 0; q < NR; q++) if (valid[q]) s.e_f[lane + 64 * q] = f[q];
   return out;
@@ -790,7 +792,7 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
   stage_model(m, s, lane);
   unsigned flags = LIGHT ? 0u : JFLAG_HEAVY_TIER;
   float sens = 0.f;
-  int iters = 0, left = 0, sub0 = 0;
+  int iters = 0, left = 0, sub0 = 0, nls_last = 0;
   const int emode = A.env_mode;
   if (emode) {   // task row + the one-substep-stale quantities the controller reads (env_logic.h)
     if (lane < JTASK_N) s.task[lane] = A.task[(size_t)env * JTASK_N + lane];
@@ -878,15 +880,15 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
     }
     float mrow[JNV], h[JNV];   // M[lane][:] stays in registers for the rest of the substep
 #pragma unroll
-    for (int j = 0; j < JNV; j++) { mrow[j] = lane < nv ? s.M[lane * JNV + j] : 0.f; h[j] = lane < nv ? mrow[j] : (lane == j ? 1.f : 0.f); }
+    for (int j = 0; j < JNV; j++) mrow[j] = lane < nv ? s.M[lane * JNV + j] : 0.f;
     float smooth = lane < nv ? s.smooth[lane] : 0.f;
-    float qas = ldl_solve<false>(h, smooth, lane);
-    if (lane < nv) s.qacc_smooth[lane] = qas;
+    float qas = 0.f;   // (qacc_smooth is no longer formed; kept in the dump layout)
     wave_sync();
-    flags |= cflags;
-    NewtonOut nw = stage_newton(m, s, mrow, lane, pc);
+    NewtonOut nw = stage_newton(m, s, mrow, smooth, lane, pc);
     JSTAMP(6);
-    iters = nw.iters;
+    iters = nw.iters & 255;
+    int nls_dbg = nw.iters >> 8;
+    nls_last = nls_dbg;
     if (iters >= m->iterations) flags |= JFLAG_SOLVER_MAXITER;
     wave_sync();
     stage_touch(m, s, lane, &sens);
@@ -1007,7 +1009,7 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
     if (lane == 0 && A.flags) A.flags[env] |= f;
   }
   if (left == 0 && lane == 0 && A.stats) {
-    A.stats[4 * env] = s.ncon; A.stats[4 * env + 1] = s.nefc; A.stats[4 * env + 2] = iters; A.stats[4 * env + 3] = s.ncand;
+    A.stats[4 * env] = s.ncon; A.stats[4 * env + 1] = s.nefc; A.stats[4 * env + 2] = iters; A.stats[4 * env + 3] = s.ncand | (nls_last << 16);
   }
   wave_sync();
   return left;

@@ -20,11 +20,11 @@ env._chk(env.L.jaco_stage_profile(env.h, prof.ctypes.data_as(ctypes.POINTER(ctyp
 t = time.time(); env.send_forces(c, nsub=nsub); torch.cuda.synchronize(); dt = time.time() - t
 env._chk(env.L.jaco_stage_profile(env.h, prof.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), 1))
 names = ["walk", "geoms+inertia", "accum+mass+act", "limit rows", "collision: narrowphase", "contact rows", "newton: rest (start, qacc_smooth, final)", "touch",
-         "euler+integrate", "collision: spheres", "collision: OBB cull", "-", "newton: MFMA H build", "newton: H fetch+LDL", "newton: line search", "-"]
+         "euler+integrate", "collision: spheres", "collision: OBB cull", "newton: prologue (M rows, qacc_smooth, start point)", "newton: MFMA H build", "newton: H fetch+LDL", "newton: line search", "-"]
 per = prof[:, :16].astype(np.float64) / nsub
 print("B", B, "nsub", nsub, "substeps/s %.3g" % (B * nsub / dt), "flags", int(env.flags().max()))
 st = env.stats().cpu().numpy()
-print("stats mean", st.mean(0), "max", st.max(0))
+print("stats mean", st.mean(0), "max", st.max(0), "line-search iterations mean", (st[:, 3] >> 16).mean(), "cand", (st[:, 3] & 0xffff).mean())
 tot = per.sum(1)
 for i, n in enumerate(names):
     if n == '-': continue
