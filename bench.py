@@ -86,18 +86,19 @@ def main():
     M = blob.load(os.path.join(ROOT, "mujoco_jaco_amd", "assets", args.model + ".jacomdl"))
     if args.level == "env":
         from mujoco_jaco_amd.env import JacoBatchedEnv
-        genv = JacoBatchedEnv(num_envs=B, device=local_rank, frame_skip=fs, seed=1000 + rank, task="picking", robot_file=args.model)
+        from mujoco_jaco_amd.sharding import ObsGather, env_seed
+        genv = JacoBatchedEnv(num_envs=B, device=local_rank, frame_skip=fs, seed=env_seed(1000, rank), task="picking", robot_file=args.model)
         env = genv.sim
         obs = genv.reset()
         gen = torch.Generator(device=dev); gen.manual_seed(2000 + rank)
         actions = [torch.rand(B, 7, device=dev, generator=gen) * 2 - 1 for _ in range(4)]
-        gathered = torch.empty(world * B, 26, device=dev) if world > 1 else None
+        gather = ObsGather(B, 26, dev) if world > 1 else None
         it = [0]
 
         def step():
             o, r, d, _ = genv.step(actions[it[0] % 4]); it[0] += 1
             if world > 1:  # one collective per rollout step: concatenate the observation rows of all shards
-                dist.all_gather_into_tensor(gathered, o)
+                gather(o)
     else:
         env = BatchedMujoco(B, robot_file=args.model, device=local_rank, frame_skip=fs, seed=rank)
         q = torch.tensor(workload.reset_states(M["qpos0"], B, seed=1000 + rank), dtype=torch.float32, device=dev)
@@ -140,6 +141,13 @@ def main():
         if args.level == "env":  # + action in, obs / reward / done out, task and controller-cache rows in and out
             bytes_per_env = 4 * (2 * env.nq + 4 * env.nv + env.nsensor + 7 + 26 + 1 + 2 * 32 + 2 * 96) + 1
         achieved = bytes_per_env * B / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+        traffic = None
+        try:  # HBM bytes per launch from the committed rocprofv3 PMC passes (tools/profile_pmc.sh), same level / batch only
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            key = "%s_B%d_fs%d" % (args.level, B, fs)
+            traffic = pm.get(key, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            pass
         out = {
             "metric": "env-steps/sec at batch 65 536 (full Jaco + gripper + contacts)",
             "value": world * B * args.steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -154,7 +162,7 @@ def main():
                        "mean_contacts": float(stats[0]), "mean_rows": float(stats[1]), "mean_newton_iters": float(stats[2]), "flags_or": flags,
                        "heavy_tier_fraction": float(((env.flags() & 32) != 0).float().mean().item())},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "jaco_physics_kernel", "kernel_ms": kern_ms, "launches": launches,
+                         "traffic": traffic, "kernel": "jaco_physics_kernel", "kernel_ms": kern_ms, "launches": launches,
                          "algorithmic_bytes_per_env_launch": bytes_per_env,
                          "note": "latency/occupancy-bound by design (SURVEY 8d): algorithmic traffic is ~1 KB per env per launch"},
         }

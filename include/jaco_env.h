@@ -37,7 +37,7 @@ extern "C" {
 #define JACO_FLAG_NAN 8u            /* non-finite velocity: env should be reset */
 #define JACO_FLAG_SOLVER_MAXITER 16u
 #define JACO_FLAG_HEAVY_TIER 32u     /* informational: stepped by the 256-row tier at least once (not an error) */
-#define JACO_FLAG_OSC_SINGULAR 64u   /* |det(J M^-1 J^T)| < 1e-3: abr_control would switch to the SVD pseudo-inverse (not implemented) */
+#define JACO_FLAG_OSC_SINGULAR 64u   /* informational: |det(J M^-1 J^T)| < 1e-3, the controller used its pseudo-inverse branch */
 
 /* task ids (env_script/env_mujoco.py:18-23; only picking/placing return the 4-tuple step() unpacks) */
 #define JACO_TASK_PICKING 0

@@ -193,6 +193,49 @@ JDEV float gj_inverse6(float (&A)[6], float (&B)[6], int lane) {
   return det;
 }
 
+// Pseudo-inverse of a symmetric PSD 6x6 matrix X (LDS, destroyed) with abr_control's rule "singular values < 0.005 are
+// dropped" (np.linalg.svd branch of OSC.generate): cyclic Jacobi eigen-decomposition, V accumulated in LDS, result in `out`.
+// Rare path (|det| < 1e-3, ~0.1 % of env steps), all control flow is wave-uniform.
+JDEV void pinv6_jacobi(float* X, float* V, float* out, int lane) {
+  if (lane < 36) V[lane] = (lane / 6 == lane % 6) ? 1.f : 0.f;
+  wave_sync();
+  for (int sweep = 0; sweep < 6; sweep++) {
+    for (int p = 0; p < 5; p++)
+      for (int q = p + 1; q < 6; q++) {
+        float app = X[p * 6 + p], aqq = X[q * 6 + q], apq = X[p * 6 + q];
+        float c = 1.f, sn = 0.f;
+        if (fabsf(apq) > 1e-12f * (fabsf(app) + fabsf(aqq)) && apq != 0.f) {
+          float theta = (aqq - app) / (2.f * apq);
+          float t = (theta >= 0.f ? 1.f : -1.f) / (fabsf(theta) + sqrtf(theta * theta + 1.f));
+          c = 1.f / sqrtf(t * t + 1.f);
+          sn = t * c;
+        }
+        wave_sync();   // every lane has read the pivot entries
+        if (lane < 6) {   // X <- X G, V <- V G   (G: Givens rotation in the (p, q) plane)
+          float akp = X[lane * 6 + p], akq = X[lane * 6 + q], vkp = V[lane * 6 + p], vkq = V[lane * 6 + q];
+          X[lane * 6 + p] = c * akp - sn * akq; X[lane * 6 + q] = sn * akp + c * akq;
+          V[lane * 6 + p] = c * vkp - sn * vkq; V[lane * 6 + q] = sn * vkp + c * vkq;
+        }
+        wave_sync();
+        if (lane < 6) {   // X <- G^T X
+          float apk = X[p * 6 + lane], aqk = X[q * 6 + lane];
+          X[p * 6 + lane] = c * apk - sn * aqk; X[q * 6 + lane] = sn * apk + c * aqk;
+        }
+        wave_sync();
+      }
+  }
+  if (lane < 36) {
+    int r = lane / 6, c = lane - 6 * r;
+    float a = 0.f;
+    for (int k = 0; k < 6; k++) {
+      float ev = fabsf(X[k * 6 + k]);
+      a += V[r * 6 + k] * (ev < 0.005f ? 0.f : 1.f / ev) * (X[k * 6 + k] < 0.f ? -1.f : 1.f) * V[c * 6 + k];
+    }
+    out[lane] = a;
+  }
+  wave_sync();
+}
+
 // Writes the six arm torques into s.ctrl[0..5].  Scratch: the (not yet built) constraint-row area s.J.
 template <class L>
 JDEV void stage_osc(const JacoModelDev* m, L& s, int lane, unsigned& flags) {
@@ -225,9 +268,13 @@ JDEV void stage_osc(const JacoModelDev* m, L& s, int lane, unsigned& flags) {
 #pragma unroll
   for (int j = 0; j < 6; j++) { A[j] = X[i * 6 + j]; B[j] = (lane == j) ? 1.f : 0.f; }
   float det = gj_inverse6(A, B, lane);
-  // abr_control: plain inverse when |det| >= 1e-3, else SVD pseudo-inverse dropping singular values < 0.005.
-  // The pseudo-inverse branch is not implemented yet: flagged, plain inverse used (DESIGN.md "Next").
-  if (fabsf(det) < 1e-3f) flags |= JFLAG_OSC_SINGULAR;
+  // abr_control: plain inverse when |det| >= 1e-3, else SVD pseudo-inverse dropping singular values < 0.005
+  if (fabsf(det) < 1e-3f) {
+    flags |= JFLAG_OSC_SINGULAR;   // informational
+    pinv6_jacobi(X, s.J + 150, s.J + 186, lane);
+#pragma unroll
+    for (int j = 0; j < 6; j++) B[j] = s.J[186 + i * 6 + j];
+  }
   // task-space error (uniform across lanes)
   const float* tg = s.task + JT_TARGET;
   float ut[6];

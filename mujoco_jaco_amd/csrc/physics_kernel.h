@@ -832,6 +832,7 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
         if (lane == 0) s.task[JT_PENDING] = 0.f;
       } else {
         stage_osc(m, s, lane, flags);   // _step_simulation: feedback -> OSC torque (env_mujoco_util.py:73-90)
+        JSTAMP(15);
         if (lane >= 6 && lane < nu) {   // gripper ramp np.linspace(prev, new, skip_frames)[gripper_iter] (:631,:78)
           float g0 = s.task[JT_GRIP_PREV], g1 = s.task[JT_GRIP];
           s.ctrl[lane] = nsub > 1 ? g0 + (g1 - g0) * ((float)sub / (float)(nsub - 1)) : g1;

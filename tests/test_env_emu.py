@@ -54,3 +54,27 @@ def test_timeout_and_freeze(names, model_arrays):
     q = e.qpos.copy()
     _, r, d = e.env_step(z)                                              # frozen until reset
     assert d[0] == 1 and r[0] == 0 and np.array_equal(q, e.qpos)
+
+
+def test_osc_pseudo_inverse_branch(names, model_arrays):
+    """Wrist-singular arm pose (joint4 ~ 0): |det(J M^-1 J^T)| < 1e-3 -> abr_control's SVD branch (singular values < 0.005
+    dropped).  The kernel's Jacobi pseudo-inverse must reproduce the oracle's np.linalg.svd path."""
+    import glue
+    e = EmuJacoEnv(frame_skip=4)
+    oe = OracleEnv(names, frame_skip=4)
+    q = model_arrays["qpos0"].copy()
+    q[:6] = [0.9757, 4.054, 1.8082, 1.6956, -0.0194, 1.6474]
+    q[9:12] = [0.0, 0.65, 0.1898]; q[16:18] = [0.4, 0.3]
+    oe.obj_goal = q[9:12].copy(); oe.dest_goal = np.array([0.4, 0.3, 0.3468])
+    oe.set_state(q.astype(np.float32).astype(np.float64))
+    o = oe.o
+    jp, jr = o.jac_body_com(oe.ee); J = np.vstack([jp[:, :6], jr[:, :6]]); M6 = o.get("qM").reshape(21, 21)[:6, :6]
+    assert abs(np.linalg.det(J @ np.linalg.inv(M6) @ J.T)) < 1e-3          # the scenario really is in the SVD branch
+    e.qpos[0] = q; e.task[0, 4:7] = oe.obj_goal; e.task[0, 7:10] = oe.dest_goal
+    nz = np.full((1, 12), 0.5, np.float32)
+    e.forward(nz)
+    a = np.array([0.3, -0.5, 0.2, 0.1, 0.4, -0.2, 0.0], np.float32)
+    obs, rew, done = e.env_step(a, nz)
+    oo, orew, odone, _ = oe.step(a.astype(np.float64), nz[0].astype(np.float64))
+    assert e.flags[0] & 64                                                   # informational flag: branch taken
+    assert np.abs(e.qpos[0, :9] - o.get("qpos")[:9]).max() < 2e-4 and np.abs(obs[0] - oo).max() < 2e-4

@@ -10,17 +10,30 @@ from mujoco_jaco_amd import workload
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 nsub = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 M = blob.load(os.path.join(ROOT, "mujoco_jaco_amd", "assets", "jaco2_curtain_torque.jacomdl"))
-env = BatchedMujoco(B)
-q = torch.tensor(workload.reset_states(M["qpos0"], B), dtype=torch.float32, device=env.device)
-c = torch.tensor(workload.random_ctrl(B, scale=0.2), dtype=torch.float32, device=env.device)
-env.set_state(q, None, None)
-env.send_forces(c, nsub=100); torch.cuda.synchronize()   # settle initial interpenetration
+envlevel = "--env" in sys.argv
 prof = np.zeros((B, 16), np.uint64)
-env._chk(env.L.jaco_stage_profile(env.h, prof.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), 1))
-t = time.time(); env.send_forces(c, nsub=nsub); torch.cuda.synchronize(); dt = time.time() - t
+if envlevel:
+    from mujoco_jaco_amd.env import JacoBatchedEnv
+    genv = JacoBatchedEnv(num_envs=B, seed=1000, task="picking", frame_skip=nsub)
+    env = genv.sim
+    genv.reset()
+    gen = torch.Generator(device=env.device); gen.manual_seed(2000)
+    acts = [torch.rand(B, 7, device=env.device, generator=gen) * 2 - 1 for _ in range(4)]
+    for i in range(3): genv.step(acts[i])
+    torch.cuda.synchronize()
+    env._chk(env.L.jaco_stage_profile(env.h, prof.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), 1))
+    t = time.time(); genv.step(acts[3]); torch.cuda.synchronize(); dt = time.time() - t
+else:
+    env = BatchedMujoco(B)
+    q = torch.tensor(workload.reset_states(M["qpos0"], B), dtype=torch.float32, device=env.device)
+    c = torch.tensor(workload.random_ctrl(B, scale=0.2), dtype=torch.float32, device=env.device)
+    env.set_state(q, None, None)
+    env.send_forces(c, nsub=100); torch.cuda.synchronize()   # settle initial interpenetration
+    env._chk(env.L.jaco_stage_profile(env.h, prof.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), 1))
+    t = time.time(); env.send_forces(c, nsub=nsub); torch.cuda.synchronize(); dt = time.time() - t
 env._chk(env.L.jaco_stage_profile(env.h, prof.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), 1))
 names = ["walk", "geoms+inertia", "accum+mass+act", "limit rows", "collision: narrowphase", "contact rows", "newton: rest (start, qacc_smooth, final)", "touch",
-         "euler+integrate", "collision: spheres", "collision: OBB cull", "newton: prologue (M rows, qacc_smooth, start point)", "newton: MFMA H build", "newton: H fetch+LDL", "newton: line search", "-"]
+         "euler+integrate", "collision: spheres", "collision: OBB cull", "newton: prologue (M rows, qacc_smooth, start point)", "newton: MFMA H build", "newton: H fetch+LDL", "newton: line search", "OSC (env level only)"]
 per = prof[:, :16].astype(np.float64) / nsub
 print("B", B, "nsub", nsub, "substeps/s %.3g" % (B * nsub / dt), "flags", int(env.flags().max()))
 st = env.stats().cpu().numpy()

@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$1
 rm -rf $OUT && mkdir -p $OUT
-CMD="python3 $GRAFT_REPO_ROOT/bench.py --level ${2:-ctrl} --steps 3 --warmup 1 --no-cpu-baseline"
+CMD="python3 $GRAFT_REPO_ROOT/bench.py --level ${2:-ctrl} --steps 3 --warmup ${3:-1} --no-cpu-baseline"
 i=0
 for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" \
            "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
