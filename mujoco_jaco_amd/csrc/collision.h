@@ -369,10 +369,11 @@ JDEV void stage_collision(const JacoStepArgs& A, const JacoModelDev* m, L& s, in
     bool valid = k < m->npair;
     int code = codes[ch];
     int g1 = code & 255, g2 = (code >> 8) & 255, t1 = (code >> 16) & 15;
-    v3 df = ld3(s.gpos[g2]) - ld3(s.gpos[g1]);
+    v4 pa = ld4(s.gpos[g1]), pb = ld4(s.gpos[g2]);
+    v3 df = mk3(pb.x - pa.x, pb.y - pa.y, pb.z - pa.z);
     bool pass;
-    if (t1 == JG_PLANE) pass = !(dot(df, col(ldm(s.gmat[g1]), 2)) > s.mc.g_rbound[g2]);
-    else { float r = s.mc.g_rbound[g1] + s.mc.g_rbound[g2]; pass = !(dot(df, df) > r * r); }
+    if (t1 == JG_PLANE) pass = !(dot(df, col(ldm(s.gmat[g1]), 2)) > pb.w);
+    else { float r = pa.w + pb.w; pass = !(dot(df, df) > r * r); }
     pass = pass && valid;
     unsigned long long mask = wave_ballot(pass);
     int idx = n1 + wave_prefix_count(mask);
@@ -407,7 +408,7 @@ JDEV void stage_collision(const JacoStepArgs& A, const JacoModelDev* m, L& s, in
   // phase 3: narrowphase, whole wave per candidate
   int ncon = 0;
   for (int c = 0; c < ncand; c++) {
-    int pk = s.cand[c];
+    int pk = wave_uniform_i(s.cand[c]);
     int code = m->pair_code[pk];
     int g1 = code & 255, g2 = (code >> 8) & 255, t1 = (code >> 16) & 15, t2 = (code >> 20) & 15;
     int before = ncon;
@@ -437,7 +438,7 @@ JDEV void stage_collision(const JacoStepArgs& A, const JacoModelDev* m, L& s, in
 template <class L>
 JDEV void stage_contact_rows(const JacoModelDev* m, L& s, int lane, unsigned& flags) {
   constexpr int MAXEFC = L::Caps::MAXEFC;
-  const int nv = m->nv, ncon = s.ncon, nlim = s.nlimit;
+  const int nv = m->nv, ncon = wave_uniform_i(s.ncon), nlim = wave_uniform_i(s.nlimit);
   // rows per contact and row offsets: lane = contact
   int dim = 0, nrow = 0;
   float mu0 = 0.f, mu1 = 0.f, mu2 = 0.f;
@@ -563,7 +564,7 @@ JDEV bool ray_hits_site(int type, float sx, float sy, float sz, v3 p, v3 d) {
 }
 template <class L>
 JDEV void stage_touch(const JacoModelDev* m, L& s, int lane, float* sens) {
-  int ncon = s.ncon;
+  int ncon = wave_uniform_i(s.ncon);
   if (lane < ncon) {
     int cd = s.c_dim[lane];
     int nrow = cd == 1 ? 1 : 2 * (cd - 1), r0 = s.c_efc[lane];

@@ -236,6 +236,17 @@ JDEV void pinv6_jacobi(float* X, float* V, float* out, int lane) {
   wave_sync();
 }
 
+// Target orientation of the env step as a unit quaternion (abr_control: transformations.quaternion_from_euler(..., 'rxyz')).
+// The target (task row) only changes in take_action, so this runs once per env step, not once per substep.
+template <class L>
+JDEV void osc_target_quat(L& s, int lane) {
+  const float* tg = s.task + JT_TARGET;
+  float qd[4];
+  euler_rxyz_to_quat(tg[3], tg[4], tg[5], qd);
+  float qn = rsqrtf(qd[0] * qd[0] + qd[1] * qd[1] + qd[2] * qd[2] + qd[3] * qd[3]);
+  if (lane < 4) s.osc_qd[lane] = (lane == 0 ? qd[0] : lane == 1 ? qd[1] : lane == 2 ? qd[2] : qd[3]) * qn;
+}
+
 // Writes the six arm torques into s.ctrl[0..5].  Scratch: the (not yet built) constraint-row area s.J.
 template <class L>
 JDEV void stage_osc(const JacoModelDev* m, L& s, int lane, unsigned& flags) {
@@ -279,10 +290,7 @@ JDEV void stage_osc(const JacoModelDev* m, L& s, int lane, unsigned& flags) {
   const float* tg = s.task + JT_TARGET;
   float ut[6];
   ut[0] = pe.x - tg[0]; ut[1] = pe.y - tg[1]; ut[2] = pe.z - tg[2];
-  float qd[4], qe[4];
-  euler_rxyz_to_quat(tg[3], tg[4], tg[5], qd);
-  float qn = rsqrtf(qd[0] * qd[0] + qd[1] * qd[1] + qd[2] * qd[2] + qd[3] * qd[3]);
-  for (int k = 0; k < 4; k++) qd[k] *= qn;
+  float qd[4] = {s.osc_qd[0], s.osc_qd[1], s.osc_qd[2], s.osc_qd[3]}, qe[4];   // osc_target_quat(), once per env step
   mat_to_quat(Re, qe);
   // q_e = q_d * conj(q_EE)
   float cw = qe[0], cx = -qe[1], cy = -qe[2], cz = -qe[3];

@@ -17,6 +17,9 @@ JDEV float wave_bcast(float v, int src) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
 }
 JDEV int wave_bcast_i(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+// A value every lane already holds (e.g. read from the same LDS word): moved to an SGPR so that loop bounds, table
+// indices and model loads derived from it become scalar (s_load / s_cbranch) instead of per-lane work.
+JDEV int wave_uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // Arbitrary per-lane gather (ds_bpermute_b32).
 JDEV float wave_shfl(float v, int src) { return __shfl(v, src, 64); }
 JDEV int wave_shfl_i(int v, int src) { return __shfl(v, src, 64); }
@@ -89,8 +92,11 @@ JDEV int jaco_atomic_inc(int* p) { return atomicAdd(p, 1); }
 // loads out of the substep loop and keeping them live (in VGPRs) across the whole loop body.
 template <class T>
 JDEV const T* opaque_ptr(const T* p) {
-  asm volatile("" : "+s"(p));
-  return p;
+  unsigned long long v = (unsigned long long)p;
+  asm volatile("" : "+s"(v));
+  // the asm hides the pointer's provenance; restate that it is constant global memory so loads through it become global_load / 
+  // s_load (a generic pointer would compile to flat_load, which also ties up the LDS counter)
+  return (const T*)(const __attribute__((address_space(4))) T*)v;
 }
 
 // 32x32 f32 accumulator tile of v_mfma_f32_32x32x2_f32: element (row, col) lives in lane (col + 32 * ((row >> 2) & 1)),

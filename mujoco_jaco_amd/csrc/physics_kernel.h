@@ -113,11 +113,13 @@ struct JacoLDS {
   float qpos[24], qvel[24], qacc_ws[24], ctrl[12];
   float xpos[JNB][3], xmat[JNB][9], xipos[JNB][3];
   float cdof[JNV][6];
-  float cinert[JNB][10], crb[JNB][10];
+  alignas(16) float cinert[JNB][10];            // (16-byte aligned: cinert+crb double as the frame scratch of stage K)
+  float crb[JNB][10];
   float cvel[JNB][6], cacc[JNB][6], cfrc[JNB][6];
   float M[JNV * JNV];
-  float bias[24], smooth[24], qacc_smooth[24], qfrc_con[24];
-  float gpos[JMAXGEOM][3], gmat[JMAXGEOM][9];
+  float bias[24], smooth[72];                   // smooth[0..nv); the light tier also stages its <= 64 row residuals here (MFMA pass)
+  alignas(16) float gpos[JMAXGEOM][4];          // world position + bounding radius: one 16-byte LDS read per geom in the broadphase
+  float gmat[JMAXGEOM][9];
   // contacts
   float c_dist[C::MAXCON], c_pos[C::MAXCON][3], c_frame[C::MAXCON][9], c_fn[C::MAXCON];
   int c_pair[C::MAXCON], c_efc[C::MAXCON];
@@ -126,19 +128,20 @@ struct JacoLDS {
   int c_dim[C::MAXCON];
   int cand[C::MAXCAND];
   // constraint rows
-  float J[C::MAXEFC * JLD];
+  alignas(16) float J[C::MAXEFC * JLD];
   float e_aref[C::MAXEFC], e_D[C::MAXEFC], e_f[C::MAXEFC];
   int e_con[C::MAXEFC];                         // contact | edge << 8 | block bits << 16
   float e_x[C::MAXEFC > 64 ? C::MAXEFC : 1];    // heavy tier only: residuals staged for the MFMA pass (light reuses `smooth`)
   int ncon, nefc, ncand, nlimit;
   float task[32];
+  float osc_qd[4];                              // target orientation quaternion of the current env step (constant over its substeps)
   // per-launch copy of the small, hot model tables (per-lane gathers from LDS instead of dependent global loads)
   struct {
     float b_pos[JNB][3], b_mat[JNB][9], b_axis[JNB][3], b_com[JNB][3], b_qpos0[JNB];
-    int b_jtype[JNB], b_qadr[JNB], b_dadr[JNB], b_writer[JNB], b_parent[JNB];
-    int leaf_depth[JMAXLEAF], leaf_path[JMAXLEAF][JMAXDEPTH];
+    int b_jtype[JNB], b_qadr[JNB], b_dadr[JNB], b_parent[JNB];
+    int b_anc[JNB][3];                          // ancestors 1, 2 and 4 levels up (-1: none), for the pointer-jumping tree stages
     int d_body[JNV], d_parent[JNV];
-    float g_size[JMAXGEOM][3], g_rbound[JMAXGEOM];
+    float g_size[JMAXGEOM][3];
   } mc;
 };
 
@@ -149,17 +152,15 @@ JDEV void stage_model(const JacoModelDev* m, L& s, int lane) {
     for (int k = 0; k < 3; k++) { s.mc.b_pos[b][k] = m->b_pos[b][k]; s.mc.b_axis[b][k] = m->b_axis[b][k]; s.mc.b_com[b][k] = m->b_com[b][k]; }
     for (int k = 0; k < 9; k++) s.mc.b_mat[b][k] = m->b_mat[b][k];
     s.mc.b_qpos0[b] = m->b_qpos0[b]; s.mc.b_jtype[b] = m->b_jtype[b]; s.mc.b_qadr[b] = m->b_qadr[b]; s.mc.b_dadr[b] = m->b_dadr[b];
-    s.mc.b_writer[b] = m->b_writer[b]; s.mc.b_parent[b] = m->b_parent[b];
-  }
-  if (lane < JMAXLEAF) {
-    s.mc.leaf_depth[lane] = m->leaf_depth[lane];
-    for (int k = 0; k < JMAXDEPTH; k++) s.mc.leaf_path[lane][k] = m->leaf_path[lane][k];
+    int p1 = m->b_parent[b], p2 = p1 >= 0 ? m->b_parent[p1] : -1, p3 = p2 >= 0 ? m->b_parent[p2] : -1, p4 = p3 >= 0 ? m->b_parent[p3] : -1;
+    s.mc.b_parent[b] = p1;
+    s.mc.b_anc[b][0] = p1; s.mc.b_anc[b][1] = p2; s.mc.b_anc[b][2] = p4;
   }
   if (lane < JNV) { s.mc.d_body[lane] = m->d_body[lane]; s.mc.d_parent[lane] = m->d_parent[lane]; }
   {
     int g = lane;
     for (int k = 0; k < 3; k++) s.mc.g_size[g][k] = m->g_size[g][k];
-    s.mc.g_rbound[g] = m->g_rbound[g];
+    s.gpos[g][3] = m->g_rbound[g];   // constant slot of the (position, radius) quadruple
   }
 }
 
@@ -168,6 +169,8 @@ struct v3 { float x, y, z; };
 JDEV v3 mk3(float x, float y, float z) { v3 r; r.x = x; r.y = y; r.z = z; return r; }
 JDEV v3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
 JDEV void st3(float* p, v3 a) { p[0] = a.x; p[1] = a.y; p[2] = a.z; }
+struct alignas(16) v4 { float x, y, z, w; };
+JDEV v4 ld4(const float* p) { return *reinterpret_cast<const v4*>(p); }   // p must be 16-byte aligned
 JDEV v3 operator+(v3 a, v3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
 JDEV v3 operator-(v3 a, v3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
 JDEV v3 operator*(v3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
@@ -206,10 +209,25 @@ JDEV m3 quat2mat(float w, float x, float y, float z) {
   r.m[6] = 2 * (x * z - w * y); r.m[7] = 2 * (y * z + w * x); r.m[8] = w * w - x * x - y * y + z * z;
   return r;
 }
+// sin and cos of a joint angle: two-constant Cody-Waite reduction to [-pi/4, pi/4] + the cephes sinf/cosf minimax
+// polynomials (< 1.5 ulp for |x| < 1e4; beyond that the library routine with its large-argument reduction takes over).
+JDEV void joint_sincos(float x, float* sn, float* cs) {
+  if (fabsf(x) > 1.0e4f) { sincosf(x, sn, cs); return; }
+  float k = rintf(x * 0.63661977236758134f);
+  float r = fmaf(k, -1.5707963705062866f, x);
+  r = fmaf(k, 4.3711390001862412e-8f, r);
+  float z = r * r;
+  float ps = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f), z * r, r);
+  float pc = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f), z * z, fmaf(-0.5f, z, 1.f));
+  int q = (int)k;
+  float a = (q & 1) ? pc : ps, b = (q & 1) ? ps : pc;
+  *sn = (q & 2) ? -a : a;
+  *cs = ((q + 1) & 2) ? -b : b;
+}
 // rotation by angle about unit axis (Rodrigues)
 JDEV m3 axis_rot(v3 a, float ang) {
   float s, c;
-  sincosf(ang, &s, &c);   // one shared range reduction
+  joint_sincos(ang, &s, &c);
   float t = 1.f - c;
   m3 r;
   r.m[0] = c + t * a.x * a.x; r.m[1] = t * a.x * a.y - s * a.z; r.m[2] = t * a.x * a.z + s * a.y;
@@ -312,76 +330,99 @@ JDEV void load_rows(float (&h)[JNV], const float* M, int nv, int lane) {
 
 // ---------------------------------------------------------------- stage K: kinematic tree
 // K1 (lane = body): joint-local transform T_b = [R_b0 Rot(axis, q - q0) | pos_b] (free bodies: world pose from qpos).
-// K2 (lane = body): world frame = product of the ancestors' T (parent pointers, <= 7 levels), motion subspaces S_d,
-//                   and S_d * qvel_d per dof.
-// K3 (lane = body): body velocity = sum of S_d qvel_d over the dofs that move it;  K4 (lane = dof): S_d-dot * qvel_d with
-//                   the velocity "before" that dof;  K5 (lane = body): bias acceleration = -gravity + sum over the chain.
+// K2 (lane = body): world frame = product of the ancestors' T, by pointer jumping: round r composes each body's partial
+//                   product with the one 2^r levels up (3 rounds cover the 7-body chain link1..link6, finger).
+// K2b (lane = dof): motion subspaces S_d and S_d * qvel_d.
+// K3 (lane = body): body velocity = sum of S_d qvel_d over the dofs that move it (own dofs, then the same pointer jumping);
+// K4 (lane = dof): S_d-dot * qvel_d with the velocity "before" that dof;  K5 (lane = body): bias acceleration = -gravity +
+//                   sum over the chain.
 // Scratch: s.cinert/s.crb (rebuilt right after) and the not-yet-built constraint-row area s.J.
+JDEV void ld_frame(const float* T, m3& R, v3& p) {   // 12 floats, 16-byte aligned: rotation (row-major), position
+  v4 a = ld4(T), b = ld4(T + 4), c = ld4(T + 8);
+  R.m[0] = a.x; R.m[1] = a.y; R.m[2] = a.z; R.m[3] = a.w; R.m[4] = b.x; R.m[5] = b.y; R.m[6] = b.z; R.m[7] = b.w; R.m[8] = c.x;
+  p = mk3(c.y, c.z, c.w);
+}
+JDEV void st_frame(float* T, const m3& R, v3 p) {
+  v4 a, b, c;
+  a.x = R.m[0]; a.y = R.m[1]; a.z = R.m[2]; a.w = R.m[3]; b.x = R.m[4]; b.y = R.m[5]; b.z = R.m[6]; b.w = R.m[7]; c.x = R.m[8];
+  c.y = p.x; c.z = p.y; c.w = p.z;
+  *reinterpret_cast<v4*>(T) = a; *reinterpret_cast<v4*>(T + 4) = b; *reinterpret_cast<v4*>(T + 8) = c;
+}
+// P[b] = own[b] + sum over b's ancestors of own[.], for 6-vectors: pointer jumping through two scratch buffers into `out`.
+template <class L>
+JDEV void chain_prefix6(L& s, sv own, bool isb, int b, int a1, int a2, int a4, float* X, float* Y, float* out) {
+  if (isb) stsv(X + 6 * b, own);
+  wave_sync();
+  if (isb) { if (a1 >= 0) own = own + ldsv(X + 6 * a1); stsv(Y + 6 * b, own); }
+  wave_sync();
+  if (isb) { if (a2 >= 0) own = own + ldsv(Y + 6 * a2); stsv(X + 6 * b, own); }
+  wave_sync();
+  if (isb) { if (a4 >= 0) own = own + ldsv(X + 6 * a4); stsv(out + 6 * b, own); }
+}
 template <class L>
 JDEV void stage_walk(const JacoModelDev* m, L& s, int lane) {
   const int nb = m->nbody, nv = m->nv;
-  float* T = &s.cinert[0][0];    // [JNB][12] local transforms (cinert+crb are contiguous: 2 * JNB * 10 floats)
-  float* Sq = s.J;               // [JNV][6] S_d * qvel_d      (the constraint-row area is free at this point)
+  float* TA = &s.cinert[0][0];   // [JNB][12] frames, ping  (cinert+crb are contiguous: 2 * JNB * 10 floats)
+  float* TB = s.J + 256;         // [JNB][12] frames, pong  (the constraint-row area is free at this point)
+  float* Sq = s.J;               // [JNV][6] S_d * qvel_d
   float* Sq2 = s.J + JNV * 6;    // [JNV][6] S_d-dot * qvel_d
+  float* VX = s.J + 400;         // [JNB][6] x 2: prefix-sum scratch
+  float* VY = s.J + 472;
   const bool isb = lane < nb;
   const int b = isb ? lane : 0;
   const int jt = s.mc.b_jtype[b], qa = s.mc.b_qadr[b], da = s.mc.b_dadr[b];
+  const int a1 = s.mc.b_anc[b][0], a2 = s.mc.b_anc[b][1], a4 = s.mc.b_anc[b][2];
+  m3 R; v3 pos;
   if (isb) {
-    m3 Rl; v3 pl;
     if (jt == JJ_HINGE) {
-      Rl = mul(ldm(s.mc.b_mat[b]), axis_rot(ld3(s.mc.b_axis[b]), s.qpos[qa] - s.mc.b_qpos0[b]));
-      pl = ld3(s.mc.b_pos[b]);
+      R = mul(ldm(s.mc.b_mat[b]), axis_rot(ld3(s.mc.b_axis[b]), s.qpos[qa] - s.mc.b_qpos0[b]));
+      pos = ld3(s.mc.b_pos[b]);
     } else {
       float w = s.qpos[qa + 3], x = s.qpos[qa + 4], y = s.qpos[qa + 5], z = s.qpos[qa + 6];
       float n = sqrtf(w * w + x * x + y * y + z * z);
       if (n < JMINVAL) { w = 1.f; x = y = z = 0.f; } else { float in = 1.f / n; w *= in; x *= in; y *= in; z *= in; }
-      Rl = quat2mat(w, x, y, z);
-      pl = ld3(&s.qpos[qa]);
+      R = quat2mat(w, x, y, z);
+      pos = ld3(&s.qpos[qa]);
     }
-    stm(T + 12 * b, Rl);
-    st3(T + 12 * b + 9, pl);
+    st_frame(TA + 12 * b, R, pos);
   }
   wave_sync();
-  m3 R; v3 pos;
   if (isb) {
-    R = ldm(T + 12 * b); pos = ld3(T + 12 * b + 9);
-    for (int p = s.mc.b_parent[b]; p >= 0; p = s.mc.b_parent[p]) {   // left-multiply by the ancestors' transforms
-      m3 Rp = ldm(T + 12 * p);
-      pos = ld3(T + 12 * p + 9) + mul(Rp, pos);
-      R = mul(Rp, R);
-    }
+    if (a1 >= 0) { m3 Rp; v3 pp; ld_frame(TA + 12 * a1, Rp, pp); pos = pp + mul(Rp, pos); R = mul(Rp, R); }
+    st_frame(TB + 12 * b, R, pos);
   }
-  wave_sync();   // T is dead from here on (cinert / crb get rebuilt by stage G)
+  wave_sync();
   if (isb) {
+    if (a2 >= 0) { m3 Rp; v3 pp; ld_frame(TB + 12 * a2, Rp, pp); pos = pp + mul(Rp, pos); R = mul(Rp, R); }
+    st_frame(TA + 12 * b, R, pos);
+  }
+  wave_sync();
+  if (isb) {
+    if (a4 >= 0) { m3 Rp; v3 pp; ld_frame(TA + 12 * a4, Rp, pp); pos = pp + mul(Rp, pos); R = mul(Rp, R); }
     st3(s.xpos[b], pos);
     stm(s.xmat[b], R);
     st3(s.xipos[b], pos + mul(R, ld3(s.mc.b_com[b])));
-    if (jt == JJ_HINGE) {
-      sv S;
-      S.a = mul(R, ld3(s.mc.b_axis[b]));   // the joint rotation leaves its own axis invariant
-      S.b = cross(pos, S.a);
-      stsv(s.cdof[da], S);
-      stsv(Sq + 6 * da, S * s.qvel[da]);
-    } else {
-#pragma unroll
-      for (int c = 0; c < 3; c++) {
-        sv St, Sr;
-        St.a = mk3(0, 0, 0);
-        St.b = mk3(c == 0 ? 1.f : 0.f, c == 1 ? 1.f : 0.f, c == 2 ? 1.f : 0.f);
-        Sr.a = col(R, c);
-        Sr.b = cross(pos, Sr.a);
-        stsv(s.cdof[da + c], St); stsv(s.cdof[da + 3 + c], Sr);
-        stsv(Sq + 6 * (da + c), St * s.qvel[da + c]); stsv(Sq + 6 * (da + 3 + c), Sr * s.qvel[da + 3 + c]);
-      }
-    }
+  }
+  wave_sync();   // TA is dead from here on (cinert / crb get rebuilt by stage G)
+  if (lane < nv) {   // S_d: hinge -> world axis through the body origin; free joint -> 3 world translations, 3 body-frame rotations
+    const int d = lane, bd = s.mc.d_body[d], k = d - s.mc.b_dadr[bd];
+    const bool hinge = s.mc.b_jtype[bd] == JJ_HINGE, rotational = hinge || k >= 3;
+    v3 al = hinge ? ld3(s.mc.b_axis[bd]) : mk3((k % 3) == 0 ? 1.f : 0.f, (k % 3) == 1 ? 1.f : 0.f, (k % 3) == 2 ? 1.f : 0.f);
+    sv S;
+    S.a = mul(ldm(s.xmat[bd]), al);   // (the joint rotation leaves its own axis invariant)
+    S.b = cross(ld3(s.xpos[bd]), S.a);
+    if (!rotational) { S.b = al; S.a = mk3(0.f, 0.f, 0.f); }
+    stsv(s.cdof[d], S);
+    stsv(Sq + 6 * d, S * s.qvel[d]);
   }
   wave_sync();
-  if (isb) {   // body velocity: own dofs + all ancestors' dofs
+  {   // body velocity: own dofs + all ancestors' dofs
     sv v; v.a = v.b = mk3(0, 0, 0);
-    int nd = jt == JJ_HINGE ? 1 : 6;
-    for (int c = 0; c < nd; c++) v = v + ldsv(Sq + 6 * (da + c));
-    for (int p = s.mc.b_parent[b]; p >= 0; p = s.mc.b_parent[p]) v = v + ldsv(Sq + 6 * s.mc.b_dadr[p]);   // ancestors are hinges
-    stsv(s.cvel[b], v);
+    if (isb) {
+      int nd = jt == JJ_HINGE ? 1 : 6;
+      for (int c = 0; c < nd; c++) v = v + ldsv(Sq + 6 * (da + c));
+    }
+    chain_prefix6(s, v, isb, b, a1, a2, a4, VX, VY, &s.cvel[0][0]);
   }
   wave_sync();
   if (lane < nv) {   // S_d-dot * qvel_d, S_d-dot = (velocity before dof d) x_m S_d
@@ -399,13 +440,15 @@ JDEV void stage_walk(const JacoModelDev* m, L& s, int lane) {
     stsv(Sq2 + 6 * d, r);
   }
   wave_sync();
-  if (isb) {
+  {
     sv a; a.a = mk3(0, 0, 0);
-    a.b = mk3(-m->gravity[0], -m->gravity[1], -m->gravity[2]);
-    int nd = jt == JJ_HINGE ? 1 : 6;
-    for (int c = 0; c < nd; c++) a = a + ldsv(Sq2 + 6 * (da + c));
-    for (int p = s.mc.b_parent[b]; p >= 0; p = s.mc.b_parent[p]) a = a + ldsv(Sq2 + 6 * s.mc.b_dadr[p]);
-    stsv(s.cacc[b], a);
+    // -gravity enters once per chain: root bodies carry it, the others inherit it through the prefix
+    a.b = a1 < 0 ? mk3(-m->gravity[0], -m->gravity[1], -m->gravity[2]) : mk3(0, 0, 0);
+    if (isb) {
+      int nd = jt == JJ_HINGE ? 1 : 6;
+      for (int c = 0; c < nd; c++) a = a + ldsv(Sq2 + 6 * (da + c));
+    }
+    chain_prefix6(s, a, isb, b, a1, a2, a4, VX, VY, &s.cacc[0][0]);
   }
 }
 
@@ -598,7 +641,7 @@ JDEV NewtonOut stage_newton(const JacoModelDev* m, L& s, const float (&mrow)[JNV
   (void)pc;
   constexpr int NR = L::Caps::NR, MAXEFC = L::Caps::MAXEFC;
   NewtonOut out;
-  int nv = m->nv, ne = s.nefc;
+  int nv = m->nv, ne = wave_uniform_i(s.nefc);
   out.qfrc_con = 0.f; out.iters = 0;
   float h0[JNV];
 #pragma unroll
@@ -655,7 +698,7 @@ JDEV NewtonOut stage_newton(const JacoModelDev* m, L& s, const float (&mrow)[JNV
     // (32 columns: 21 dofs, column 21 = -x, rest zero), two constraint rows per v_mfma_f32_32x32x2_f32.
     // C[0..20][0..20] = sum_active D_r J_r^T J_r,  C[21][0..20] = J^T f  (f_r = -D_r x_r on active rows).
     // Per-row weights and residuals are staged in LDS so that every operand of a step is an independent LDS read
-    // (4 steps in flight): e_f is only written at the very end; smooth / qacc_smooth / qfrc_con are dead by now.
+    // (4 steps in flight): e_f is only written at the very end; `smooth` (already in registers) is dead by now.
     float* xs = NR == 1 ? s.smooth : s.e_x;
 #pragma unroll
     for (int q = 0; q < NR; q++) if (valid[q]) { s.e_f[lane + 64 * q] = x[q] < 0.f ? D[q] : 0.f; xs[lane + 64 * q] = x[q]; }
@@ -784,7 +827,7 @@ JDEV void stage_integrate_pos(const JacoModelDev* m, L& s, int lane) {
 // One substep loop for one env; returns the number of substeps NOT done (light tier bail-out) or 0.
 template <class C, bool LIGHT>
 JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int lane) {
-  const JacoModelDev* m = A.model;
+  const JacoModelDev* m = opaque_ptr(A.model);
   const int nq = m->nq, nv = m->nv, nu = m->nu, ns = m->nsensor;
   if (lane < nq) s.qpos[lane] = A.qpos[(size_t)env * nq + lane];
   if (lane < nv) { s.qvel[lane] = A.qvel[(size_t)env * nv + lane]; s.qacc_ws[lane] = A.qacc_ws[(size_t)env * nv + lane]; }
@@ -808,13 +851,15 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
       if (lane == 0) { A.reward[env] = 0.f; A.done[env] = 1; }
       return 0;
     }
-    sub0 = (int)s.task[JT_SUB];
+    sub0 = wave_uniform_i((int)s.task[JT_SUB]);
     if (sub0 == 0) {
       // _take_action: the marker placement consumes 6 draws (a8), then the EE target and the gripper ramp
       take_action(m, s, A.action + (size_t)env * A.nact, A.nact, lane);
       if (lane == 0) { unsigned c = __float_as_uint(s.task[JT_RNG]); s.task[JT_RNG] = __uint_as_float(c + 6u); }
       wave_sync();
     }
+    osc_target_quat(s, lane);
+    wave_sync();
   }
   JProfCtx pc;
   pc.row = nullptr;
