@@ -360,21 +360,25 @@ JDEV void stage_collision(const JacoStepArgs& A, const JacoModelDev* m, L& s, in
   // phase 1: bounding spheres, lane = pair; the pair codes of all chunks are fetched up front (independent loads)
   int n1 = 0;
   int codes[JMAXPAIR / 64];
+  const int npair = m->npair;
 #pragma unroll
-  for (int ch = 0; ch < JMAXPAIR / 64; ch++) codes[ch] = (ch * 64 < m->npair) ? m->pair_code[(ch * 64 + lane < m->npair) ? ch * 64 + lane : 0] : 0;
+  for (int ch = 0; ch < JMAXPAIR / 64; ch++) codes[ch] = m->pair_code[ch * 64 + lane];   // (zero-padded to JMAXPAIR: straight-line loads)
 #pragma unroll
   for (int ch = 0; ch < JMAXPAIR / 64; ch++) {
-    if (ch * 64 >= m->npair) break;
+    if (ch * 64 >= npair) break;
     int k = ch * 64 + lane;
-    bool valid = k < m->npair;
+    bool valid = k < npair;
     int code = codes[ch];
     int g1 = code & 255, g2 = (code >> 8) & 255, t1 = (code >> 16) & 15;
     v4 pa = ld4(s.gpos[g1]), pb = ld4(s.gpos[g2]);
     v3 df = mk3(pb.x - pa.x, pb.y - pa.y, pb.z - pa.z);
-    bool pass;
-    if (t1 == JG_PLANE) pass = !(dot(df, col(ldm(s.gmat[g1]), 2)) > pb.w);
-    else { float r = pa.w + pb.w; pass = !(dot(df, df) > r * r); }
-    pass = pass && valid;
+    // branch-free: every lane also evaluates the plane form (normal = third column of g1's frame)
+    v3 nrm = mk3(s.gmat[g1][2], s.gmat[g1][5], s.gmat[g1][8]);
+    keep_loaded(nrm.x, nrm.y, nrm.z);
+    float r = pa.w + pb.w, dn = dot(df, nrm), dd = dot(df, df);
+    const bool plane = t1 == JG_PLANE;
+    float lhs = plane ? dn : dd, rhs = plane ? pb.w : r * r;
+    bool pass = !(lhs > rhs) & valid;
     unsigned long long mask = wave_ballot(pass);
     int idx = n1 + wave_prefix_count(mask);
     if (pass && idx < L::Caps::MAXCAND) s.cand[idx] = k;

@@ -88,6 +88,9 @@ JDEV int wave_argmax(float v, int idx, float* best) {
 JDEV int grid_size() { return (int)gridDim.x; }
 JDEV int jaco_atomic_inc(int* p) { return atomicAdd(p, 1); }
 
+// Pin three already-loaded values in VGPRs here: keeps the optimiser from sinking their loads into a (divergent) branch.
+JDEV void keep_loaded(float& a, float& b, float& c) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c)); }
+
 // Hide a (wave-uniform) pointer's provenance from the optimiser: stops it from hoisting per-lane model
 // loads out of the substep loop and keeping them live (in VGPRs) across the whole loop body.
 template <class T>
