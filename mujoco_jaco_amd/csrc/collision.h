@@ -432,7 +432,7 @@ JDEV void stage_collision(const JacoStepArgs& A, const JacoModelDev* m, L& s, in
       int b1 = m->g_body[g1], b2 = m->g_body[g2];
       unsigned m1 = b1 >= 0 ? m->b_chainmask[b1] : 0u, m2 = b2 >= 0 ? m->b_chainmask[b2] : 0u;
       int c = before + lane;
-      if (c < ncon) { s.c_m1[c] = m1; s.c_m2[c] = m2; s.c_ob[c] = m->g_origbody[g1] | (m->g_origbody[g2] << 16); s.c_dim[c] = m->pair[pk].condim; }
+      if (c < ncon) { s.c_m1[c] = m1; s.c_m2[c] = m2; s.c_ob[c] = m->g_origbody[g1] | ((b1 + 1) << 8) | (m->g_origbody[g2] << 16) | ((b2 + 1) << 24); s.c_dim[c] = m->pair[pk].condim; }
     }
   }
   if (lane == 0) { s.ncon = ncon; s.ncand = ncand; }
@@ -504,11 +504,28 @@ JDEV void stage_contact_rows(const JacoModelDev* m, L& s, int lane, unsigned& fl
     int ce = s.e_con[rr], c = ce & 255, e = (ce >> 8) & 255;
     const JacoPairParam& P = m->pair[s.c_pair[c]];
     int pd = P.condim;
-    float vel = 0.f;
-    for (int kk = 0; kk < nv; kk++) vel += s.J[rr * JLD + kk] * s.qvel[kk];
-    float tran = m->g_invweight[P.g1][0] + m->g_invweight[P.g2][0], rot = m->g_invweight[P.g1][1] + m->g_invweight[P.g2][1];
-    float pos = s.c_dist[c] - P.margin;
     int kf = pd == 1 ? 0 : 1 + (e >> 1);
+    // row velocity J_row . qvel, taken from the two bodies' spatial velocities: the contact-frame components of the relative
+    // point velocity (k < 3) or relative angular velocity (k >= 3), combined as the pyramid edge  v_0 +- mu_k v_k
+    float vel;
+    {
+      int obs = s.c_ob[c], b1 = ((obs >> 8) & 0xFF) - 1, b2 = ((obs >> 24) & 0xFF) - 1;
+      sv v1, v2;
+      v1.a = v1.b = v2.a = v2.b = mk3(0.f, 0.f, 0.f);
+      if (b1 >= 0) v1 = ldsv(s.cvel[b1]);
+      if (b2 >= 0) v2 = ldsv(s.cvel[b2]);
+      v3 cp = ld3(s.c_pos[c]);
+      v3 dw = v2.a - v1.a, dv = (v2.b - v1.b) + cross(dw, cp);
+      const float* fr = s.c_frame[c];
+      vel = dot(ld3(fr), dv);
+      if (pd > 1) {
+        int ax = kf < 3 ? kf : kf - 3;
+        float comp = dot(ld3(fr + 3 * ax), kf < 3 ? dv : dw);
+        vel += ((e & 1) ? -1.f : 1.f) * P.mu[kf - 1] * comp;
+      }
+    }
+    float tran = P.tran, rot = P.rot;
+    float pos = s.c_dist[c] - P.margin;
     float mu = pd == 1 ? 0.f : P.mu[kf - 1];
     float da = pd == 1 ? tran : tran + mu * mu * (kf < 3 ? tran : rot);
     float R, imp;
@@ -587,7 +604,7 @@ JDEV void stage_touch(const JacoModelDev* m, L& s, int lane, float* sens) {
     float sx = m->s_size[lane][0], sy = m->s_size[lane][1], sz = m->s_size[lane][2];
     for (int c = 0; c < ncon; c++) {
       int obs = s.c_ob[c];
-      bool on1 = (obs & 0xFFFF) == ob, on2 = (obs >> 16) == ob;
+      bool on1 = (obs & 0xFF) == ob, on2 = ((obs >> 16) & 0xFF) == ob;
       if (!on1 && !on2) continue;
       float fn = s.c_fn[c];
       if (!(fn > JMINVAL)) continue;

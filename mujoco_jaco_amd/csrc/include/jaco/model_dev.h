@@ -11,8 +11,8 @@
 #define JNSENS 20     // touch sensors (xml:352-374)
 #define JMAXGEOM 64   // collidable geoms
 #define JMAXPAIR 768  // geom pairs passing the static collision filter
-#define JMAXLEAF 8    // leaves of the kinematic tree (3 fingers + 2 free bodies)
-#define JMAXDEPTH 8   // longest root->leaf path (link1..link6, finger)
+#define JMAXINNER 6   // bodies that have children (link1..link6)
+#define JMAXMPAIR 128 // structurally non-zero lower-triangle mass-matrix entries (84 for this model)
 #define JNMOCAP 16
 
 enum { JG_PLANE = 0, JG_SPHERE = 2, JG_CYLINDER = 5, JG_BOX = 6, JG_MESH = 7 };
@@ -25,11 +25,11 @@ struct JacoPairParam {
   float margin;
   int condim;        // max of the two geoms
   int g1, g2;        // fused geom ids, type(g1) <= type(g2)
-  int pad;
+  float tran, rot;   // translational / rotational body_invweight0 of the two geoms' bodies, summed (diagApprox of contact rows)
 };
 
 struct JacoModelDev {
-  int nbody, nv, nq, nu, ngeom, npair, nsensor, nleaf, nhullvert, nmocap;
+  int nbody, nv, nq, nu, ngeom, npair, nsensor, nhullvert, nmocap;
   float timestep, gravity[3], tolerance, meaninertia, mpr_tolerance;
   int iterations, ls_iterations, mpr_iterations;
   float ls_tolerance;
@@ -40,9 +40,9 @@ struct JacoModelDev {
   float b_mass[JNB], b_com[JNB][3], b_inertia[JNB][6];  // xx yy zz xy xz yz about the CoM, body frame
   float b_range[JNB][2], b_solref[JNB][2], b_solimp[JNB][5];  // joint-limit solver parameters
   unsigned b_chainmask[JNB];                       // bit d set: dof d moves body b
-  int leaf_body[JMAXLEAF], leaf_depth[JMAXLEAF];   // root->leaf paths walked by one lane each
-  int leaf_path[JMAXLEAF][JMAXDEPTH];
-  int b_writer[JNB];                               // leaf index whose lane publishes body b's frame
+  unsigned b_descmask[JNB];                        // bit x set: body x is in the subtree rooted at b (b included)
+  int ninner, inner_body[JMAXINNER];               // bodies with children: the only ones whose composite sums differ from their own
+  int nmpair, mpair[JMAXMPAIR];                    // (dof d | ancestor-or-self dof j << 8): one lane per mass-matrix entry
 
   // dofs
   int d_body[JNV], d_parent[JNV];

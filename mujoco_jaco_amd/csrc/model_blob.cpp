@@ -128,23 +128,26 @@ int jaco_model_from_blob(const void* buf, size_t size, JacoModelDev* m, std::vec
     for (int k = 0; k < n; k++) mask |= 1u << (da[b] + k);
     m->b_chainmask[b] = mask;
   }
-  // ---- leaves and root->leaf paths
-  int nleaf = 0;
+  // ---- subtree tables for the composite-inertia / mass-matrix stages
+  int ninner = 0;
   for (int b = 0; b < nb; b++) {
-    bool leaf = true;
-    for (int c = 0; c < nb; c++) if (par[c] == b) leaf = false;
-    if (!leaf) continue;
-    if (nleaf >= JMAXLEAF) FAIL("too many leaves");
-    int path[JMAXDEPTH], depth = 0;
-    for (int x = b; x >= 0; x = par[x]) { if (depth >= JMAXDEPTH) FAIL("tree too deep"); path[depth++] = x; }
-    m->leaf_body[nleaf] = b; m->leaf_depth[nleaf] = depth;
-    for (int k = 0; k < depth; k++) m->leaf_path[nleaf][k] = path[depth - 1 - k];
-    nleaf++;
+    unsigned desc = 0;   // bit x: body x lies in the subtree rooted at b (b included)
+    for (int x = 0; x < nb; x++)
+      for (int y = x; y >= 0; y = par[y]) if (y == b) { desc |= 1u << x; break; }
+    m->b_descmask[b] = desc;
+    if (desc != (1u << b)) {
+      if (ninner >= JMAXINNER) FAIL("too many bodies with children for the kernels' subtree stage");
+      m->inner_body[ninner++] = b;
+    }
   }
-  m->nleaf = nleaf;
-  for (int b = 0; b < nb; b++) m->b_writer[b] = -1;
-  for (int l = 0; l < nleaf; l++)
-    for (int k = 0; k < m->leaf_depth[l]; k++) if (m->b_writer[m->leaf_path[l][k]] < 0) m->b_writer[m->leaf_path[l][k]] = l;
+  m->ninner = ninner;
+  int nmp = 0;   // structurally non-zero lower-triangle entries of the mass matrix: (dof d, ancestor-or-self dof j)
+  for (int d = 0; d < nv; d++)
+    for (int j = d; j >= 0; j = dpar[j]) {
+      if (nmp >= JMAXMPAIR) FAIL("too many mass-matrix entries for the kernels' pair table");
+      m->mpair[nmp++] = d | (j << 8);
+    }
+  m->nmpair = nmp;
   // ---- actuators
   const int32_t *ajnt = B.i32("actuator_jntid", nu), *apos = B.i32("actuator_position", nu), *acl = B.i32("actuator_ctrllimited", nu);
   const int32_t *afl = B.i32("actuator_forcelimited", nu), *jq = B.i32("jnt_qposadr"), *jd = B.i32("jnt_dofadr");
@@ -190,6 +193,7 @@ int jaco_model_from_blob(const void* buf, size_t size, JacoModelDev* m, std::vec
     int g1 = pg[2 * k], g2 = pg[2 * k + 1];
     if (gty[g1] > gty[g2]) { int t = g1; g1 = g2; g2 = t; }
     P.g1 = g1; P.g2 = g2; P.condim = pd[k]; P.margin = (float)pmar[k];
+    P.tran = m->g_invweight[g1][0] + m->g_invweight[g2][0]; P.rot = m->g_invweight[g1][1] + m->g_invweight[g2][1];
     for (int i = 0; i < 5; i++) { P.mu[i] = (float)pmu[5 * k + i]; P.solimp[i] = (float)pimp[5 * k + i]; }
     P.solref[0] = (float)pref[2 * k]; P.solref[1] = (float)pref[2 * k + 1];
     m->pair_code[k] = g1 | (g2 << 8) | (gty[g1] << 16) | (gty[g2] << 20);

@@ -124,7 +124,7 @@ struct JacoLDS {
   float c_dist[C::MAXCON], c_pos[C::MAXCON][3], c_frame[C::MAXCON][9], c_fn[C::MAXCON];
   int c_pair[C::MAXCON], c_efc[C::MAXCON];
   unsigned c_m1[C::MAXCON], c_m2[C::MAXCON];   // dof chain masks of the two bodies
-  int c_ob[C::MAXCON];                          // original (unfused) body ids of the two geoms: ob1 | ob2 << 16 (touch sensors)
+  int c_ob[C::MAXCON];                          // per geom: original (unfused) body id | (fused body + 1) << 8; geom 2 in the upper half
   int c_dim[C::MAXCON];
   int cand[C::MAXCAND];
   // constraint rows
@@ -139,6 +139,8 @@ struct JacoLDS {
   struct {
     float b_pos[JNB][3], b_mat[JNB][9], b_axis[JNB][3], b_com[JNB][3], b_qpos0[JNB];
     int b_jtype[JNB], b_qadr[JNB], b_dadr[JNB], b_parent[JNB];
+    int inner_body[JMAXINNER];
+    unsigned b_descmask[JNB];
     int b_anc[JNB][3];                          // ancestors 1, 2 and 4 levels up (-1: none), for the pointer-jumping tree stages
     int d_body[JNV], d_parent[JNV];
     float g_size[JMAXGEOM][3];
@@ -154,6 +156,8 @@ JDEV void stage_model(const JacoModelDev* m, L& s, int lane) {
     s.mc.b_qpos0[b] = m->b_qpos0[b]; s.mc.b_jtype[b] = m->b_jtype[b]; s.mc.b_qadr[b] = m->b_qadr[b]; s.mc.b_dadr[b] = m->b_dadr[b];
     int p1 = m->b_parent[b], p2 = p1 >= 0 ? m->b_parent[p1] : -1, p3 = p2 >= 0 ? m->b_parent[p2] : -1, p4 = p3 >= 0 ? m->b_parent[p3] : -1;
     s.mc.b_parent[b] = p1;
+    s.mc.b_descmask[b] = m->b_descmask[b];
+    if (b < JMAXINNER) s.mc.inner_body[b] = m->inner_body[b];
     s.mc.b_anc[b][0] = p1; s.mc.b_anc[b][1] = p2; s.mc.b_anc[b][2] = p4;
   }
   if (lane < JNV) { s.mc.d_body[lane] = m->d_body[lane]; s.mc.d_parent[lane] = m->d_parent[lane]; }
@@ -489,35 +493,57 @@ JDEV void stage_geoms_inertia(const JacoModelDev* m, L& s, int lane) {
     sv v = ldsv(s.cvel[b]), a = ldsv(s.cacc[b]);
     sv f = inert_mul(o, a) + cross_force(v, inert_mul(o, v));
     stsv(s.cfrc[b], f);
+    stsv(s.cacc[b], f);   // subtree force sum, completed for bodies with children by stage_accumulate
   }
 }
 
-// children -> parents: composite inertias (lanes 0..9) and RNE forces (lanes 16..21), component-parallel
+// Subtree sums for the bodies that have children (leaves keep their own values from stage G): composite inertias
+// crb[a] = sum of cinert over a's subtree (lane = (a, component), 10 components) and RNE forces cacc[a] = sum of cfrc over
+// the subtree (6 components; cacc is dead as an acceleration by now and doubles as the summed force).  Sources and
+// destinations are different arrays, so there is no ordering between lanes.
 template <class L>
 JDEV void stage_accumulate(const JacoModelDev* m, L& s, int lane) {
-  for (int b = m->nbody - 1; b > 0; b--) {
-    int p = s.mc.b_parent[b];
-    if (p < 0) continue;
-    if (lane < 10) s.crb[p][lane] += s.crb[b][lane];
-    else if (lane >= 16 && lane < 22) s.cfrc[p][lane - 16] += s.cfrc[b][lane - 16];
+  const int ni = m->ninner;
+  if (lane < 10 * ni) {
+    const int a = s.mc.inner_body[lane / 10], c = lane % 10;
+    float acc = 0.f;
+    for (unsigned mm = s.mc.b_descmask[a]; mm; mm &= mm - 1u) acc += s.cinert[__builtin_ctz(mm)][c];
+    s.crb[a][c] = acc;
+  }
+  if (lane < 6 * ni) {
+    const int a = s.mc.inner_body[lane / 6], c = lane % 6;
+    float acc = 0.f;
+    for (unsigned mm = s.mc.b_descmask[a]; mm; mm &= mm - 1u) acc += s.cfrc[__builtin_ctz(mm)][c];
+    s.cacc[a][c] = acc;
   }
 }
 
 // ---------------------------------------------------------------- stage M: mass matrix, bias, actuation
+// lane = dof: F_d = Ic(body d) S_d and the bias force; then lane = structurally non-zero entry (d, j), j an ancestor-or-self
+// dof of d: M[d][j] = S_j . F_d.  Scratch: the not-yet-built constraint-row area s.J.
 template <class L>
 JDEV void stage_mass_bias(const JacoModelDev* m, L& s, int lane) {
+  float* Fd = s.J;   // [JNV][6]
+  const int nmp = m->nmpair;
+  int code0 = m->mpair[lane], code1 = m->mpair[64 + lane];   // (table is zero-padded to JMAXMPAIR)
   if (lane < m->nv) {
     int d = lane, b = s.mc.d_body[d];
     sv S = ldsv(s.cdof[d]);
-    sv F = inert_mul(s.crb[b], S);
-    for (int j = d; j >= 0; j = s.mc.d_parent[j]) {
-      float v = dot(ldsv(s.cdof[j]), F);
+    stsv(Fd + 6 * d, inert_mul(s.crb[b], S));
+    float bias = dot(S, ldsv(s.cacc[b]));
+    s.bias[d] = bias;
+    s.smooth[d] = -m->d_damping[d] * s.qvel[d] - bias;
+  }
+  wave_sync();
+#pragma unroll
+  for (int h = 0; h < JMAXMPAIR / 64; h++) {
+    int code = h == 0 ? code0 : code1;
+    if (h * 64 + lane < nmp) {
+      int d = code & 255, j = code >> 8;
+      float v = dot(ldsv(s.cdof[j]), ldsv(Fd + 6 * d));
       s.M[d * JNV + j] = v;
       s.M[j * JNV + d] = v;
     }
-    float bias = dot(S, ldsv(s.cfrc[b]));
-    s.bias[d] = bias;
-    s.smooth[d] = -m->d_damping[d] * s.qvel[d] - bias;
   }
 }
 template <class L>
