@@ -244,11 +244,59 @@ JDEV void collide_box_box(const JacoModelDev* m, L& s, int g1, int g2, int pair,
 
 // ---------------------------------------------------------------- MPR (all lanes run the same serial control flow)
 struct Sup { v3 v, v1, v2; };
+// Everything a support query needs about one geom, fetched once per candidate pair.
+struct MprGeom { GeomPose P; v3 size; int type, adr, nvert; };
 template <class L>
-JDEV Sup mpr_support(const JacoStepArgs& A, const JacoModelDev* m, const L& s, int g1, int t1, int g2, int t2, v3 dir, int lane) {
+JDEV MprGeom mpr_geom(const JacoModelDev* m, const L& s, int g, int type) {
+  MprGeom G;
+  G.P = geom_pose(s, g);
+  G.size = ld3(s.mc.g_size[g]);
+  G.type = type;
+  G.adr = type == JG_MESH ? m->g_vertadr[g] : 0;
+  G.nvert = type == JG_MESH ? m->g_vertnum[g] : 0;
+  return G;
+}
+JDEV v3 support_prim(const MprGeom& G, v3 l) {   // box / sphere, local frame
+  if (G.type == JG_BOX) return mk3(l.x > 0.f ? G.size.x : -G.size.x, l.y > 0.f ? G.size.y : -G.size.y, l.z > 0.f ? G.size.z : -G.size.z);
+  float n = norm(l);
+  return l * (n > JMINVAL ? G.size.x / n : 0.f);
+}
+// Support point of the Minkowski difference G1 - G2 along `dir` (wave-uniform).  Hull meshes: the vertices of both hulls
+// are scanned in one loop (64 lanes x float4 loads, both geoms' loads in flight together); every lane keeps the coordinates
+// of its own best vertex, so after the DPP argmax the winner is broadcast from its lane instead of being re-fetched from
+// memory.  Lowest vertex index wins ties (a serial first-max scan), as in support_geom.
+JDEV Sup mpr_support(const JacoStepArgs& A, const MprGeom& G1, const MprGeom& G2, v3 dir, int lane) {
+  const v3 l1 = mulT(G1.P.R, dir), l2 = mulT(G2.P.R, -dir);
+  const int n1 = G1.nvert, n2 = G2.nvert, nmax = n1 > n2 ? n1 : n2;
+  float best1 = -3.0e38f, best2 = -3.0e38f;
+  int bi1 = 0x7fffffff, bi2 = 0x7fffffff;
+  v3 c1 = mk3(0.f, 0.f, 0.f), c2 = mk3(0.f, 0.f, 0.f);
+  for (int i = lane; i < nmax; i += 64) {
+    if (i < n1) {
+      const v4 v = ld4(A.hull + 4 * (size_t)(G1.adr + i));
+      float t = v.x * l1.x + v.y * l1.y + v.z * l1.z;
+      if (t > best1) { best1 = t; bi1 = i; c1 = mk3(v.x, v.y, v.z); }
+    }
+    if (i < n2) {
+      const v4 v = ld4(A.hull + 4 * (size_t)(G2.adr + i));
+      float t = v.x * l2.x + v.y * l2.y + v.z * l2.z;
+      if (t > best2) { best2 = t; bi2 = i; c2 = mk3(v.x, v.y, v.z); }
+    }
+  }
+  v3 sp1, sp2;
+  if (n1 > 0) {
+    float bv;
+    const int wl = wave_argmax(best1, bi1, &bv) & 63;   // vertex i was scanned by lane i % 64
+    sp1 = mk3(wave_bcast(c1.x, wl), wave_bcast(c1.y, wl), wave_bcast(c1.z, wl));
+  } else sp1 = support_prim(G1, l1);
+  if (n2 > 0) {
+    float bv;
+    const int wl = wave_argmax(best2, bi2, &bv) & 63;
+    sp2 = mk3(wave_bcast(c2.x, wl), wave_bcast(c2.y, wl), wave_bcast(c2.z, wl));
+  } else sp2 = support_prim(G2, l2);
   Sup r;
-  r.v1 = support_geom(A, m, s, g1, t1, dir, lane);
-  r.v2 = support_geom(A, m, s, g2, t2, -dir, lane);
+  r.v1 = G1.P.p + mul(G1.P.R, sp1);
+  r.v2 = G2.P.p + mul(G2.P.R, sp2);
   r.v = r.v1 - r.v2;
   return r;
 }
@@ -307,10 +355,11 @@ JDEV bool mpr_penetration(const JacoStepArgs& A, const JacoModelDev* m, const L&
                           float* depth, v3* dirout, v3* pos) {
   Sup p0, p1, p2, p3, v4;
   float tol = m->mpr_tolerance;
-  p0.v1 = ld3(s.gpos[g1]); p0.v2 = ld3(s.gpos[g2]); p0.v = p0.v1 - p0.v2;
+  const MprGeom G1 = mpr_geom(m, s, g1, t1), G2 = mpr_geom(m, s, g2, t2);
+  p0.v1 = G1.P.p; p0.v2 = G2.P.p; p0.v = p0.v1 - p0.v2;
   if (norm(p0.v) < 1e-9f) p0.v.x = 1e-5f;
   v3 dr = normalized(-p0.v);
-  p1 = mpr_support(A, m, s, g1, t1, g2, t2, dr, lane);
+  p1 = mpr_support(A, G1, G2, dr, lane);
   if (dot(p1.v, dr) <= 0.f) return false;
   dr = cross(p0.v, p1.v);
   if (norm(dr) < 1e-9f) {
@@ -318,13 +367,13 @@ JDEV bool mpr_penetration(const JacoStepArgs& A, const JacoModelDev* m, const L&
     return true;
   }
   dr = normalized(dr);
-  p2 = mpr_support(A, m, s, g1, t1, g2, t2, dr, lane);
+  p2 = mpr_support(A, G1, G2, dr, lane);
   if (dot(p2.v, dr) <= 0.f) return false;
   dr = normalized(cross(p1.v - p0.v, p2.v - p0.v));
   if (dot(dr, p0.v) > 0.f) { Sup t = p1; p1 = p2; p2 = t; dr = -dr; }
   for (int it = 0;; it++) {
     if (it > 100) return false;
-    p3 = mpr_support(A, m, s, g1, t1, g2, t2, dr, lane);
+    p3 = mpr_support(A, G1, G2, dr, lane);
     if (dot(p3.v, dr) <= 0.f) return false;
     bool cont = false;
     if (dot(cross(p1.v, p3.v), p0.v) < -1e-11f) { p2 = p3; cont = true; }
@@ -335,13 +384,13 @@ JDEV bool mpr_penetration(const JacoStepArgs& A, const JacoModelDev* m, const L&
   for (int it = 0;; it++) {
     dr = portal_dir(p1, p2, p3);
     if (dot(dr, p1.v) >= 0.f) break;
-    v4 = mpr_support(A, m, s, g1, t1, g2, t2, dr, lane);
+    v4 = mpr_support(A, G1, G2, dr, lane);
     if (dot(v4.v, dr) < 0.f || reach_tol(p1, p2, p3, v4, dr, tol) || it > m->mpr_iterations) return false;
     expand_portal(p0, p1, p2, p3, v4);
   }
   for (int it = 0;; it++) {
     dr = portal_dir(p1, p2, p3);
-    v4 = mpr_support(A, m, s, g1, t1, g2, t2, dr, lane);
+    v4 = mpr_support(A, G1, G2, dr, lane);
     if (reach_tol(p1, p2, p3, v4, dr, tol) || it > m->mpr_iterations) {
       v3 cp;
       *depth = point_tri_closest(p1.v, p2.v, p3.v, &cp);

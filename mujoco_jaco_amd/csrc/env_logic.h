@@ -194,42 +194,49 @@ JDEV float gj_inverse6(float (&A)[6], float (&B)[6], int lane) {
 }
 
 // Pseudo-inverse of a symmetric PSD 6x6 matrix X (LDS, destroyed) with abr_control's rule "singular values < 0.005 are
-// dropped" (np.linalg.svd branch of OSC.generate): cyclic Jacobi eigen-decomposition, V accumulated in LDS, result in `out`.
-// Rare path (|det| < 1e-3, ~0.1 % of env steps), all control flow is wave-uniform.
+// dropped" (np.linalg.svd branch of OSC.generate): Jacobi eigen-decomposition, V accumulated in LDS, result in `out`.
+// Parallel (round-robin) ordering: each of the 5 rounds of a sweep applies 3 rotations on disjoint index pairs at once,
+// lane = (matrix row or column, pair).  Rare path (|det| < 1e-3, a few % of env steps under random actions); all control
+// flow is wave-uniform.
 JDEV void pinv6_jacobi(float* X, float* V, float* out, int lane) {
+  // round r, pair j: p = nibble 2j, q = nibble 2j+1 (circle method for 6 players)
+  const unsigned rounds[5] = {0x324150u, 0x213540u, 0x152430u, 0x541320u, 0x435210u};
   if (lane < 36) V[lane] = (lane / 6 == lane % 6) ? 1.f : 0.f;
   wave_sync();
+  const int k = lane % 6, jp = lane / 6;   // lanes 0..17: row/column k, pair jp
   for (int sweep = 0; sweep < 6; sweep++) {
-    for (int p = 0; p < 5; p++)
-      for (int q = p + 1; q < 6; q++) {
-        float app = X[p * 6 + p], aqq = X[q * 6 + q], apq = X[p * 6 + q];
-        float c = 1.f, sn = 0.f;
-        if (fabsf(apq) > 1e-12f * (fabsf(app) + fabsf(aqq)) && apq != 0.f) {
-          float theta = (aqq - app) / (2.f * apq);
-          float t = (theta >= 0.f ? 1.f : -1.f) / (fabsf(theta) + sqrtf(theta * theta + 1.f));
-          c = 1.f / sqrtf(t * t + 1.f);
-          sn = t * c;
-        }
-        wave_sync();   // every lane has read the pivot entries
-        if (lane < 6) {   // X <- X G, V <- V G   (G: Givens rotation in the (p, q) plane)
-          float akp = X[lane * 6 + p], akq = X[lane * 6 + q], vkp = V[lane * 6 + p], vkq = V[lane * 6 + q];
-          X[lane * 6 + p] = c * akp - sn * akq; X[lane * 6 + q] = sn * akp + c * akq;
-          V[lane * 6 + p] = c * vkp - sn * vkq; V[lane * 6 + q] = sn * vkp + c * vkq;
-        }
-        wave_sync();
-        if (lane < 6) {   // X <- G^T X
-          float apk = X[p * 6 + lane], aqk = X[q * 6 + lane];
-          X[p * 6 + lane] = c * apk - sn * aqk; X[q * 6 + lane] = sn * apk + c * aqk;
-        }
-        wave_sync();
+#pragma unroll
+    for (int r = 0; r < 5; r++) {
+      const unsigned code = rounds[r] >> (8 * (jp < 3 ? jp : 0));
+      const int p = code & 15, q = (code >> 4) & 15;
+      float app = X[p * 6 + p], aqq = X[q * 6 + q], apq = X[p * 6 + q];
+      float c = 1.f, sn = 0.f;
+      if (fabsf(apq) > 1e-12f * (fabsf(app) + fabsf(aqq)) && apq != 0.f) {
+        float theta = (aqq - app) / (2.f * apq);
+        float t = (theta >= 0.f ? 1.f : -1.f) / (fabsf(theta) + sqrtf(theta * theta + 1.f));
+        c = 1.f / sqrtf(t * t + 1.f);
+        sn = t * c;
       }
+      wave_sync();   // every lane has read its pivot entries
+      if (lane < 18) {   // X <- X G, V <- V G   (G: the three Givens rotations of this round)
+        float akp = X[k * 6 + p], akq = X[k * 6 + q], vkp = V[k * 6 + p], vkq = V[k * 6 + q];
+        X[k * 6 + p] = c * akp - sn * akq; X[k * 6 + q] = sn * akp + c * akq;
+        V[k * 6 + p] = c * vkp - sn * vkq; V[k * 6 + q] = sn * vkp + c * vkq;
+      }
+      wave_sync();
+      if (lane < 18) {   // X <- G^T X
+        float apk = X[p * 6 + k], aqk = X[q * 6 + k];
+        X[p * 6 + k] = c * apk - sn * aqk; X[q * 6 + k] = sn * apk + c * aqk;
+      }
+      wave_sync();
+    }
   }
   if (lane < 36) {
     int r = lane / 6, c = lane - 6 * r;
     float a = 0.f;
-    for (int k = 0; k < 6; k++) {
-      float ev = fabsf(X[k * 6 + k]);
-      a += V[r * 6 + k] * (ev < 0.005f ? 0.f : 1.f / ev) * (X[k * 6 + k] < 0.f ? -1.f : 1.f) * V[c * 6 + k];
+    for (int kk = 0; kk < 6; kk++) {
+      float ev = fabsf(X[kk * 6 + kk]);
+      a += V[r * 6 + kk] * (ev < 0.005f ? 0.f : 1.f / ev) * (X[kk * 6 + kk] < 0.f ? -1.f : 1.f) * V[c * 6 + kk];
     }
     out[lane] = a;
   }

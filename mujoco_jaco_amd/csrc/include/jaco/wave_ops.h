@@ -85,6 +85,7 @@ JDEV int wave_argmax(float v, int idx, float* best) {
   return bi;
 }
 
+JDEV unsigned long long wave_clock() { return __builtin_amdgcn_s_memtime(); }   // free-running shader clock
 JDEV int grid_size() { return (int)gridDim.x; }
 JDEV int jaco_atomic_inc(int* p) { return atomicAdd(p, 1); }
 

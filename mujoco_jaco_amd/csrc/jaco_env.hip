@@ -26,6 +26,9 @@ struct JacoHandle {
   int* stats = nullptr;
   int *remaining = nullptr, *heavy_list = nullptr, *heavy_count = nullptr;
   float *task_rows = nullptr, *cache = nullptr;
+  unsigned* cost = nullptr;   // per env: shader-clock ticks its last step took (>> 4)
+  int* order = nullptr;       // launch order of the env-level light kernel: expensive envs first
+  int schedule = 1;           // option "schedule": 0 = launch envs in index order
   const float* noise = nullptr;
   unsigned long long* prof = nullptr;
   std::vector<float> qpos0;
@@ -97,6 +100,9 @@ extern "C" int jaco_create(const JacoConfig* cfg, JacoHandle** out) {
   CREATECHK(hipMalloc(&h->heavy_list, B * sizeof(int)));
   CREATECHK(hipMalloc(&h->heavy_count, sizeof(int)));
   CREATECHK(hipMemset(h->remaining, 0, B * sizeof(int)));
+  CREATECHK(hipMalloc(&h->cost, B * sizeof(unsigned)));
+  CREATECHK(hipMalloc(&h->order, B * sizeof(int)));
+  CREATECHK(hipMemset(h->cost, 0, B * sizeof(unsigned)));
   CREATECHK(hipMalloc(&h->task_rows, B * JTASK_N * sizeof(float)));
   CREATECHK(hipMalloc(&h->cache, B * JCACHE_N * sizeof(float)));
   CREATECHK(hipMemset(h->task_rows, 0, B * JTASK_N * sizeof(float)));
@@ -135,7 +141,7 @@ extern "C" int jaco_destroy(JacoHandle* h) {
   if (!h) return JACO_EINVAL;
   (void)hipSetDevice(h->device);
   for (auto& e : h->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-  void* ptrs[] = {h->model_dev, h->hull_dev, h->qpos, h->qvel, h->qacc_ws, h->sensordata, h->flags, h->stats, h->dbg, h->prof, h->remaining, h->heavy_list, h->heavy_count, h->task_rows, h->cache};
+  void* ptrs[] = {h->model_dev, h->hull_dev, h->qpos, h->qvel, h->qacc_ws, h->sensordata, h->flags, h->stats, h->dbg, h->prof, h->remaining, h->heavy_list, h->heavy_count, h->task_rows, h->cache, h->cost, h->order};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   delete h;
   return JACO_OK;
@@ -193,6 +199,49 @@ extern "C" int jaco_reset_state(JacoHandle* h, void* stream) {
 
 struct EnvIO { int mode = 0; const float* action = nullptr; float* obs = nullptr; float* reward = nullptr; unsigned char* done = nullptr; };
 
+// Launch order for the next env step: envs sorted by the cost of their previous step, most expensive first (32 buckets of
+// 1/8 of the mean cost).  An env step is ~1.5 ms of one wavefront and the expensive ones (hull-hull narrowphase, the
+// controller's pseudo-inverse branch) take 2-8x the mean; started last they would leave the chip idle behind them.
+// Costs persist from step to step (contact state, arm configuration), so last step's cost predicts this step's.
+// One workgroup; wave-aggregated LDS atomics.  The order within a bucket is arbitrary: envs are independent.
+__global__ __launch_bounds__(1024) void jaco_order_kernel(const unsigned* cost, int* order, int n) {
+  __shared__ unsigned hist[32], base[32];
+  __shared__ unsigned long long total;
+  const int tid = (int)threadIdx.x, lane = tid & 63;
+  if (tid < 32) hist[tid] = 0;
+  if (tid == 0) total = 0;
+  __syncthreads();
+  unsigned long long loc = 0;
+  for (int i = tid; i < n; i += 1024) loc += cost[i];
+  for (int o = 32; o > 0; o >>= 1) loc += __shfl_xor(loc, o, 64);
+  if (lane == 0) atomicAdd(&total, loc);
+  __syncthreads();
+  const unsigned ref = (unsigned)(total / (unsigned long long)n) + 1u;
+  for (int pass = 0; pass < 2; pass++) {
+    for (int i0 = 0; i0 < n; i0 += 1024) {
+      const int i = i0 + tid;
+      const bool valid = i < n;
+      unsigned b = 0;
+      if (valid) { unsigned long long q = (unsigned long long)cost[i] * 8ull / ref; b = q > 31ull ? 31u : (unsigned)q; }
+      unsigned long long todo = __ballot(valid);
+      while (todo) {   // one atomic per distinct bucket in the wave
+        const int leader = __ffsll((long long)todo) - 1;
+        const unsigned lb = (unsigned)__shfl((int)b, leader, 64);
+        const unsigned long long same = __ballot(valid && b == lb);
+        const int cnt = __popcll(same);
+        unsigned pos = 0;
+        if (lane == leader) pos = pass == 0 ? atomicAdd(&hist[lb], (unsigned)cnt) : atomicAdd(&base[lb], (unsigned)cnt);
+        pos = (unsigned)__shfl((int)pos, leader, 64);
+        if (pass == 1 && valid && b == lb) order[pos + __popcll(same & ((1ull << lane) - 1ull))] = i;
+        todo &= ~same;
+      }
+    }
+    __syncthreads();
+    if (pass == 0 && tid == 0) { unsigned p = 0; for (int b = 31; b >= 0; b--) { base[b] = p; p += hist[b]; } }
+    __syncthreads();
+  }
+}
+
 static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t st, float* dbg, int dbg_env, const EnvIO& io = EnvIO()) {
   if ((!ctrl && io.mode == 0) || nsub <= 0) { h->err = "jaco_physics_step: bad arguments"; return JACO_EINVAL; }
   JacoStepArgs A{};
@@ -203,6 +252,8 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
   A.remaining = h->remaining; A.heavy_list = h->heavy_list; A.heavy_count = h->heavy_count;
   A.env_mode = io.mode; A.task_id = h->task; A.nact = h->task == JACO_TASK_REACHING ? 6 : 7; A.seed = h->seed;
   A.task = h->task_rows; A.cache = h->cache; A.action = io.action; A.noise = h->noise; A.obs = io.obs; A.reward = io.reward; A.done = io.done;
+  A.cost = h->cost;
+  const bool reorder = io.mode == 1 && h->schedule && nsub >= 8 && h->num_envs >= 4096;
   std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
   if (h->timing) {
     if (h->events_used == h->events.size()) {
@@ -216,6 +267,11 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
   }
   // light tier for every env, then the heavy tier for the envs that overflowed the light capacities
   HIPCHK(h, hipMemsetAsync(h->heavy_count, 0, sizeof(int), st));
+  if (reorder) {
+    hipLaunchKernelGGL(jaco_order_kernel, dim3(1), dim3(1024), 0, st, h->cost, h->order, h->num_envs);
+    HIPCHK(h, hipGetLastError());
+    A.order = h->order;
+  }
   hipLaunchKernelGGL(jaco_physics_kernel, dim3((unsigned)h->num_envs), dim3(64), 0, st, A);
   HIPCHK(h, hipGetLastError());
   unsigned hg = (unsigned)(h->num_envs < 1024 ? h->num_envs : 1024);
@@ -343,6 +399,7 @@ extern "C" int jaco_set_option(JacoHandle* h, const char* name, double v) {
   if (!h || !name) return JACO_EINVAL;
   JacoModelDev& m = h->model_host;
   if (!strcmp(name, "disable_contact")) { h->disable_contact = v != 0; return JACO_OK; }
+  if (!strcmp(name, "schedule")) { h->schedule = v != 0; return JACO_OK; }
   else if (!strcmp(name, "iterations")) m.iterations = (int)v;
   else if (!strcmp(name, "tolerance")) m.tolerance = (float)v;
   else if (!strcmp(name, "ls_iterations")) m.ls_iterations = (int)v;

@@ -25,8 +25,8 @@ template <int MAXEFC_, int MAXCON_, int MAXCAND_>
 struct JacoCaps {
   static constexpr int MAXEFC = MAXEFC_, MAXCON = MAXCON_, MAXCAND = MAXCAND_, NR = MAXEFC_ / 64;
 };
-typedef JacoCaps<64, 32, 64> JacoLight;
-typedef JacoCaps<256, 64, 128> JacoHeavy;
+typedef JacoCaps<64, 32, 128> JacoLight;   // (candidates = bounding-sphere survivors: closed fingers alone contribute > 64)
+typedef JacoCaps<256, 64, 256> JacoHeavy;
 #define JDBG_MAXCON 64
 #define JDBG_MAXEFC 256
 #define JLD (JNV)     // row stride of per-row dof vectors in LDS (21: odd, conflict-free for lane-per-row access)
@@ -85,6 +85,8 @@ struct JacoStepArgs {
   float* obs;                // [nenv][26]
   float* reward;             // [nenv]
   unsigned char* done;       // [nenv]
+  unsigned* cost;            // [nenv] shader-clock ticks (>> 4) the env's last step took (launch-order heuristic), or nullptr
+  const int* order;          // light tier, optional: workgroup -> env permutation (expensive envs first), else identity
   unsigned long long* prof;  // diagnostic build only: [nenv][JPROF_N] cycle sums, else nullptr
   float* dbg;          // optional stage dump of env dbg_env (see JDBG_* offsets), else nullptr
   int dbg_env;
@@ -855,6 +857,7 @@ template <class C, bool LIGHT>
 JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int lane) {
   const JacoModelDev* m = opaque_ptr(A.model);
   const int nq = m->nq, nv = m->nv, nu = m->nu, ns = m->nsensor;
+  const unsigned long long t_start = wave_clock();
   if (lane < nq) s.qpos[lane] = A.qpos[(size_t)env * nq + lane];
   if (lane < nv) { s.qvel[lane] = A.qvel[(size_t)env * nv + lane]; s.qacc_ws[lane] = A.qacc_ws[(size_t)env * nv + lane]; }
   if (lane < nu) s.ctrl[lane] = A.ctrl[(size_t)env * nu + lane];
@@ -874,7 +877,7 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
   wave_sync();
   if (emode == 1) {
     if (s.task[JT_DONE] != 0.f) {   // finished and not yet reset: frozen (no auto-reset)
-      if (lane == 0) { A.reward[env] = 0.f; A.done[env] = 1; }
+      if (lane == 0) { A.reward[env] = 0.f; A.done[env] = 1; if (A.cost) A.cost[env] = 0u; }
       return 0;
     }
     sub0 = wave_uniform_i((int)s.task[JT_SUB]);
@@ -1083,6 +1086,10 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
   if (left == 0 && lane == 0 && A.stats) {
     A.stats[4 * env] = s.ncon; A.stats[4 * env + 1] = s.nefc; A.stats[4 * env + 2] = iters; A.stats[4 * env + 3] = s.ncand | (nls_last << 16);
   }
+  if (lane == 0 && A.cost) {
+    unsigned c = (unsigned)((wave_clock() - t_start) >> 4);
+    A.cost[env] = LIGHT ? c : A.cost[env] + c;   // the heavy tier finishes what the light tier started
+  }
   wave_sync();
   return left;
 }
@@ -1090,8 +1097,9 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
 // light tier: one workgroup (= one wavefront) per env
 __global__ __launch_bounds__(64, 2) void jaco_physics_kernel(JacoStepArgs A) {
   __shared__ JacoLDS<JacoLight> s;
-  const int lane = lane_id(), env = env_id();
-  if (env >= A.nenv) return;
+  const int lane = lane_id();
+  if (env_id() >= A.nenv) return;
+  const int env = A.order ? A.order[env_id()] : env_id();
   int left = run_env<JacoLight, true>(A, s, env, A.nsub, lane);
   if (left > 0 && lane == 0) {
     A.remaining[env] = left;

@@ -20,6 +20,7 @@ JDEV int emu_post_i(int v) { int p = emu_cnt[emu_cur_lane]++ & 1; emu_x[p][emu_c
 
 JDEV float wave_bcast(float v, int src) { int p = emu_post_f(v); emu_collective(); return emu_x[p][src].f; }
 JDEV int wave_bcast_i(int v, int src) { int p = emu_post_i(v); emu_collective(); return emu_x[p][src].i; }
+JDEV unsigned long long wave_clock() { return 0ull; }
 JDEV int wave_uniform_i(int v) { return wave_bcast_i(v, 0); }
 JDEV void keep_loaded(float&, float&, float&) {}
 JDEV float wave_shfl(float v, int src) { int p = emu_post_f(v); emu_collective(); return emu_x[p][src & 63].f; }

@@ -11,6 +11,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 nsub = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 M = blob.load(os.path.join(ROOT, "mujoco_jaco_amd", "assets", "jaco2_curtain_torque.jacomdl"))
 envlevel = "--env" in sys.argv
+presteps = int(sys.argv[sys.argv.index("--presteps") + 1]) if "--presteps" in sys.argv else 3   # env steps before the profiled one
 prof = np.zeros((B, 16), np.uint64)
 if envlevel:
     from mujoco_jaco_amd.env import JacoBatchedEnv
@@ -19,10 +20,11 @@ if envlevel:
     genv.reset()
     gen = torch.Generator(device=env.device); gen.manual_seed(2000)
     acts = [torch.rand(B, 7, device=env.device, generator=gen) * 2 - 1 for _ in range(4)]
-    for i in range(3): genv.step(acts[i])
+    for i in range(presteps): genv.step(acts[i % 4])
     torch.cuda.synchronize()
     env._chk(env.L.jaco_stage_profile(env.h, prof.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), 1))
-    t = time.time(); genv.step(acts[3]); torch.cuda.synchronize(); dt = time.time() - t
+    env.clear_flags()
+    t = time.time(); genv.step(acts[presteps % 4]); torch.cuda.synchronize(); dt = time.time() - t
 else:
     env = BatchedMujoco(B)
     q = torch.tensor(workload.reset_states(M["qpos0"], B), dtype=torch.float32, device=env.device)
@@ -42,4 +44,18 @@ tot = per.sum(1)
 for i, n in enumerate(names):
     if n == '-': continue
     print("%-42s mean %9.0f cyc  (%4.1f%%)  p99 %9.0f" % (n, per[:, i].mean(), 100 * per[:, i].mean() / tot.mean(), np.percentile(per[:, i], 99)))
+if "--slow" in sys.argv:   # what the slowest 2 % of envs spend their time on
+    slow = tot >= np.percentile(tot, 98)
+    print("slowest 2 %% of envs: total mean %.0f" % tot[slow].mean())
+    for i, n in enumerate(names): print("   %-42s mean %9.0f" % (n, per[slow, i].mean()))
+    fl = env.flags().cpu().numpy()
+    print("   flags: singular %.3f heavy %.3f maxiter %.3f; ncon mean %.1f cand mean %.1f iters mean %.2f" % (((fl[slow] & 64) != 0).mean(), ((fl[slow] & 32) != 0).mean(), ((fl[slow] & 16) != 0).mean(), st[slow, 0].mean(), (st[slow, 3] & 0xffff).mean(), st[slow, 2].mean()))
+if "--heavy" in sys.argv:   # envs the heavy tier touched in the profiled step (flags are cleared before it)
+    fl = env.flags().cpu().numpy()
+    hv = (fl & 32) != 0
+    print("heavy-tier envs: %d, total mean %.0f cycles/substep" % (hv.sum(), tot[hv].mean() if hv.any() else 0))
+    if hv.any():
+        for i, n in enumerate(names): print("   %-42s mean %9.0f" % (n, per[hv, i].mean()))
+        print("   ncon mean %.1f max %d  nefc mean %.1f max %d  cand mean %.1f iters mean %.2f" % (st[hv, 0].mean(), st[hv, 0].max(), st[hv, 1].mean(), st[hv, 1].max(), (st[hv, 3] & 0xffff).mean(), st[hv, 2].mean()))
+        print("   per-env totals:", np.sort(tot[hv]).astype(int))
 print("total per substep: mean %.0f cycles, p50 %.0f, p99 %.0f, max %.0f" % (tot.mean(), np.median(tot), np.percentile(tot, 99), tot.max()))

@@ -1,0 +1,26 @@
+"""Per-step timing and workload statistics of the default bench workload (diagnostic)."""
+import os, sys, time
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+import torch
+from mujoco_jaco_amd.env import JacoBatchedEnv
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+genv = JacoBatchedEnv(num_envs=B, device=0, frame_skip=50, seed=1000, task="picking", robot_file="jaco2_curtain_torque")
+env = genv.sim
+dev = torch.device("cuda:0")
+if "--no-schedule" in sys.argv: env.set_option("schedule", 0)
+genv.reset()
+gen = torch.Generator(device=dev); gen.manual_seed(2000)
+actions = [torch.rand(B, 7, device=dev, generator=gen) * 2 - 1 for _ in range(4)]
+for i in range(n):
+    env.clear_flags()
+    torch.cuda.synchronize(); t = time.perf_counter()
+    o, r, d, _ = genv.step(actions[i % 4])
+    torch.cuda.synchronize(); dt = time.perf_counter() - t
+    st = env.stats().float()
+    fl = env.flags()
+    print("step %2d  %.2f ms  done %.4f  ncon mean %.2f max %d  nefc mean %.1f  iters mean %.3f  cand mean %.2f  heavy %.4f  singular %.4f" % (
+        i, dt * 1e3, d.float().mean().item(), st[:, 0].mean().item(), int(st[:, 0].max().item()), st[:, 1].mean().item(), st[:, 2].mean().item(),
+        (st[:, 3].long() & 0xffff).float().mean().item(), ((fl & 32) != 0).float().mean().item(), ((fl & 64) != 0).float().mean().item()))

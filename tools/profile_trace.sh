@@ -1,0 +1,20 @@
+#!/bin/bash
+# Per-launch kernel durations (rocprofv3 kernel trace) of the 30-step trace workload: light tier, heavy tier, order kernel.
+cd /tmp && export TMPDIR=/tmp
+OUT=$GRAFT_REPO_ROOT/gpurun_out/ktrace
+rm -rf $OUT && mkdir -p $OUT
+rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/tools/gpu_step_trace.py 65536 ${1:-30} > $OUT/run.log 2>&1
+python3 - <<PY
+import csv, glob
+rows = []
+for f in glob.glob("$OUT/*/*kernel_trace.csv"):
+    for r in csv.DictReader(open(f)):
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+rows.sort()
+step = -1
+for s, e, k in rows:
+    short = "order" if "order" in k else "heavy" if "heavy" in k else "light" if "jaco_physics_kernel" in k else None
+    if short is None: continue
+    if short == "order": step += 1
+    print("launch %3d %-6s %8.3f ms" % (step, short, (e - s) * 1e-6))
+PY
