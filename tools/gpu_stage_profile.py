@@ -2,7 +2,7 @@
 import ctypes, os, sys, time
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
-os.environ["JACO_ENV_LIB"] = "libjaco_env_prof.so"
+os.environ.setdefault("JACO_ENV_LIB", "libjaco_env_prof.so")
 import numpy as np, torch
 from mujoco_jaco_amd.physics import BatchedMujoco
 from mujoco_jaco_amd.modelc import blob
