@@ -93,7 +93,11 @@ int jaco_get_stats(JacoHandle* h, int32_t* out_dev, void* stream);
 /* ---- env level: JacoMujocoEnv.reset / step (env_script/env_mujoco.py:99-139), batched -------------------------
  * jaco_reset: _reset (env_mujoco_util.py:92-174) for the envs whose mask byte is non-zero (NULL = all): counter-based
  *   RNG draws of the per-task initial state (Appendix A of SURVEY.md), sim.forward(), then _get_observation for every
- *   env into obs_dev [num_envs][26].  Task `placing` (object in hand + 150 held substeps) is not implemented yet.
+ *   env into obs_dev [num_envs][26].  Task `placing` runs jaco_placing_hold(mask, 150) between the draws and the observation.
+ * jaco_placing_hold: the object part of the placing reset (env_mujoco_util.py:106-117): object to the grasp frame EE_obj
+ *   (4 cm back along its x axis), EE target = current EE pose, then nsub x { OSC torque from the current state's M, J, bias
+ *   (each iteration follows a sim.forward()), sim.step() with gripper command 0.6, set_obj_xyz: object re-pinned, velocities
+ *   of all free bodies zeroed (mujoco.py:217-227) }.  Exposed so that a caller can replay the hold from its own state.
  * jaco_step: clip is the caller's job (env_mujoco.py:117 np.clip); then _take_action, frame_skip x (OSC torque +
  *   sim.step()), make_observation, _get_reward, terminal_inspection.  action_dev [num_envs][7] (6 for reaching),
  *   obs_dev [num_envs][26] f32, reward_dev [num_envs] f32, done_dev [num_envs] u8.  An env that returned done stays
@@ -104,6 +108,7 @@ int jaco_get_stats(JacoHandle* h, int32_t* out_dev, void* stream);
  * Task rows ([num_envs][jaco_task_row_floats()], layout JT_* in csrc/env_logic.h) expose gripper command, step
  *   counters, goals and the success flag (get_wb / accum_succ bookkeeping stay on the host side). */
 int jaco_reset(JacoHandle* h, const uint8_t* mask_dev, float* obs_dev, void* stream);
+int jaco_placing_hold(JacoHandle* h, const uint8_t* mask_dev, int nsub, void* stream);
 int jaco_step(JacoHandle* h, const float* action_dev, float* obs_dev, float* reward_dev, uint8_t* done_dev, void* stream);
 int jaco_forward(JacoHandle* h, float* obs_dev, void* stream);
 int jaco_set_noise(JacoHandle* h, const float* noise_dev);

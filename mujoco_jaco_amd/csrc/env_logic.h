@@ -31,7 +31,8 @@
 #define JC_EEPOS 78      // [3] frame of the body carrying the EE
 #define JC_EEMAT 81      // [9]
 #define JC_OBJPOS 90     // [3] object body position
-#define JCACHE_N 96
+#define JC_PIN 96        // [7] placing reset: pose (xyz, quat) the object is pinned to while the fingers close
+#define JCACHE_N 104
 
 #define JFLAG_OSC_SINGULAR 64u
 
@@ -91,6 +92,15 @@ JDEV void ee_frame(const JacoModelDev* m, const L& s, v3* pos, m3* R) {
   m3 Rb = ldm(s.xmat[eb]);
   *pos = ld3(s.xpos[eb]) + mul(Rb, ld3(m->ee_pos));
   *R = mul(Rb, ldm(m->ee_mat));
+}
+
+// EE_obj frame (the grasp frame the placing reset pins the object to, env_mujoco_util.py:107)
+template <class L>
+JDEV void eeobj_frame(const JacoModelDev* m, const L& s, v3* pos, m3* R) {
+  int eb = m->eeobj_body;
+  m3 Rb = ldm(s.xmat[eb]);
+  *pos = ld3(s.xpos[eb]) + mul(Rb, ld3(m->eeobj_pos));
+  *R = mul(Rb, ldm(m->eeobj_mat));
 }
 
 // ---------------------------------------------------------------- a8: rule-based subgoal (env_mujoco_util.py:273-300)

@@ -197,7 +197,8 @@ extern "C" int jaco_reset_state(JacoHandle* h, void* stream) {
   return JACO_OK;
 }
 
-struct EnvIO { int mode = 0; const float* action = nullptr; float* obs = nullptr; float* reward = nullptr; unsigned char* done = nullptr; };
+#define JACO_PLACING_HOLD_SUBSTEPS 150   // reset_frame_skip (env_mujoco_util.py:114)
+struct EnvIO { int mode = 0; const float* action = nullptr; float* obs = nullptr; float* reward = nullptr; unsigned char* done = nullptr; const unsigned char* mask = nullptr; };
 
 // Launch order for the next env step: envs sorted by the cost of their previous step, most expensive first (32 buckets of
 // 1/8 of the mean cost).  An env step is ~1.5 ms of one wavefront and the expensive ones (hull-hull narrowphase, the
@@ -251,7 +252,7 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
   A.disable_contact = h->disable_contact; A.dbg = dbg; A.dbg_env = dbg_env; A.prof = h->prof;
   A.remaining = h->remaining; A.heavy_list = h->heavy_list; A.heavy_count = h->heavy_count;
   A.env_mode = io.mode; A.task_id = h->task; A.nact = h->task == JACO_TASK_REACHING ? 6 : 7; A.seed = h->seed;
-  A.task = h->task_rows; A.cache = h->cache; A.action = io.action; A.noise = h->noise; A.obs = io.obs; A.reward = io.reward; A.done = io.done;
+  A.task = h->task_rows; A.cache = h->cache; A.action = io.action; A.noise = h->noise; A.obs = io.obs; A.reward = io.reward; A.done = io.done; A.mask = io.mask;
   A.cost = h->cost;
   const bool reorder = io.mode == 1 && h->schedule && nsub >= 8 && h->num_envs >= 4096;
   std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
@@ -324,15 +325,24 @@ extern "C" int jaco_forward(JacoHandle* h, float* obs_dev, void* stream) {
   EnvIO io; io.mode = 2; io.obs = obs_dev;
   return launch_step(h, nullptr, 1, (hipStream_t)stream, nullptr, -1, io);
 }
+extern "C" int jaco_placing_hold(JacoHandle* h, const uint8_t* mask_dev, int nsub, void* stream) {
+  if (!h || nsub <= 0) return JACO_EINVAL;
+  if (h->model_host.eeobj_body < 0 || h->model_host.nq < 23) { h->err = "jaco_placing_hold: the model has no EE_obj frame / object body"; return JACO_EINVAL; }
+  EnvIO hold; hold.mode = 3; hold.mask = mask_dev;
+  return launch_step(h, nullptr, nsub, (hipStream_t)stream, nullptr, -1, hold);
+}
 extern "C" int jaco_reset(JacoHandle* h, const uint8_t* mask_dev, float* obs_dev, void* stream) {
   if (!h || !obs_dev) return JACO_EINVAL;
-  if (h->task == JACO_TASK_PLACING) { h->err = "jaco_reset: the placing reset (object in hand + 150 held substeps, env_mujoco_util.py:106-117) is not implemented yet"; return JACO_EINVAL; }
   hipStream_t st = (hipStream_t)stream;
   const JacoModelDev& m = h->model_host;
   HIPCHK(h, hipMemcpyAsync(h->dbg, h->qpos0.data(), m.nq * sizeof(float), hipMemcpyHostToDevice, st));
   JacoResetArgs R{h->dbg, h->qpos, h->qvel, h->qacc_ws, h->task_rows, mask_dev, h->num_envs, m.nq, m.nv, h->task, m.nq >= 23, h->seed};
   hipLaunchKernelGGL(jaco_reset_kernel, dim3((unsigned)((h->num_envs + 255) / 256)), dim3(256), 0, st, R);
   HIPCHK(h, hipGetLastError());
+  if (h->task == JACO_TASK_PLACING) {   // object into the hand, 150 held substeps while the fingers close (env_mujoco_util.py:106-117)
+    int rc = jaco_placing_hold(h, mask_dev, JACO_PLACING_HOLD_SUBSTEPS, stream);
+    if (rc) return rc;
+  }
   // sim.forward() + _get_observation for every env (unmasked envs recompute the same cache and observation)
   return jaco_forward(h, obs_dev, stream);
 }

@@ -75,7 +75,9 @@ struct JacoStepArgs {
   int* heavy_count;    // [1]
   int nenv, nsub, disable_contact;
   // env-level mode (jaco_step / jaco_reset): nsub = frame_skip
-  int env_mode;              // 0 ctrl-level, 1 env step, 2 forward only (reset: fill cache + observation)
+  int env_mode;              // 0 ctrl-level, 1 env step, 2 forward only (reset: fill cache + observation),
+                             // 3 placing reset: nsub controlled substeps with the object pinned in the hand (env_mujoco_util.py:106-117)
+  const unsigned char* mask; // mode 3: envs to run (nullptr = all)
   int task_id, nact;
   unsigned long long seed;
   float* task;               // [nenv][JTASK_N]
@@ -858,6 +860,7 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
   const JacoModelDev* m = opaque_ptr(A.model);
   const int nq = m->nq, nv = m->nv, nu = m->nu, ns = m->nsensor;
   const unsigned long long t_start = wave_clock();
+  if (A.env_mode == 3 && A.mask && !A.mask[env]) return 0;
   if (lane < nq) s.qpos[lane] = A.qpos[(size_t)env * nq + lane];
   if (lane < nv) { s.qvel[lane] = A.qvel[(size_t)env * nv + lane]; s.qacc_ws[lane] = A.qacc_ws[(size_t)env * nv + lane]; }
   if (lane < nu) s.ctrl[lane] = A.ctrl[(size_t)env * nu + lane];
@@ -890,6 +893,41 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
     osc_target_quat(s, lane);
     wave_sync();
   }
+  float pinv = 0.f;   // mode 3, lanes 9..15: the pinned object pose
+  if (emode == 3) {
+    // placing reset (env_mujoco_util.py:106-117): the object goes to the grasp frame EE_obj, 4 cm back along its x axis, and
+    // is re-pinned there (zero velocity for every free body) after each of the nsub substeps, while the controller
+    // holds the EE at its reset pose and the finger servos close onto the object (gripper command 0.6).
+    sub0 = wave_uniform_i((int)s.task[JT_SUB]);
+    float* PIN = A.cache + (size_t)env * JCACHE_N + JC_PIN;
+    if (sub0 == 0) {
+      stage_walk(m, s, lane);
+      wave_sync();
+      v3 po, pe; m3 Ro, Re;
+      eeobj_frame(m, s, &po, &Ro);
+      ee_frame(m, s, &pe, &Re);
+      po = po - col(Ro, 0) * 0.04f;
+      float q[4], eul[3];
+      mat_to_quat(Ro, q);
+      mat_to_euler_rxyz(Re, eul);
+      float pin[7] = {po.x, po.y, po.z, q[0], q[1], q[2], q[3]};
+#pragma unroll
+      for (int k = 0; k < 7; k++) if (lane == 9 + k) pinv = pin[k];
+      if (lane >= 9 && lane < 16) PIN[lane - 9] = pinv;
+      if (lane == 0) {
+        float* t = s.task;
+        t[JT_TARGET + 0] = pe.x; t[JT_TARGET + 1] = pe.y; t[JT_TARGET + 2] = pe.z;
+        t[JT_TARGET + 3] = eul[0]; t[JT_TARGET + 4] = eul[1]; t[JT_TARGET + 5] = eul[2];
+        t[JT_GRIP] = 0.6f; t[JT_GRIP_PREV] = 0.6f;
+      }
+      wave_sync();
+      if (lane >= 9 && lane < 16) s.qpos[lane] = pinv;
+      if (lane >= 9 && lane < nv) s.qvel[lane] = 0.f;
+    } else if (lane >= 9 && lane < 16) pinv = PIN[lane - 9];   // resumed by the heavy tier
+    wave_sync();
+    osc_target_quat(s, lane);
+    wave_sync();
+  }
   JProfCtx pc;
   pc.row = nullptr;
   pc.tprev = 0;
@@ -899,6 +937,13 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
 #endif
   for (int sub = sub0; sub < nsub; sub++) {
     m = opaque_ptr(A.model);
+    bool held_pending = false;
+    if (emode == 3 && s.task[JT_PENDING] != 0.f) {   // resume of an interrupted held substep: its ctrl was saved
+      if (lane < nu) s.ctrl[lane] = s.task[JT_CTRL + lane];
+      wave_sync();
+      if (lane == 0) s.task[JT_PENDING] = 0.f;
+      held_pending = true;
+    }
     if (emode == 1) {
       if (s.task[JT_PENDING] != 0.f) {   // resume of a substep interrupted by the light tier: its ctrl was saved
         if (lane < nu) s.ctrl[lane] = s.task[JT_CTRL + lane];
@@ -925,6 +970,11 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
     wave_sync();
     stage_mass_bias(m, s, lane);
     wave_sync();
+    if (emode == 3 && !held_pending) {   // every held substep follows a sim.forward(): the controller sees *this* state's M, J, bias
+      stage_osc(m, s, lane, flags);
+      if (lane >= 6 && lane < nu) s.ctrl[lane] = 0.6f;
+      wave_sync();
+    }
     stage_actuation(m, s, lane);
     wave_sync();
     JSTAMP(2);
@@ -946,7 +996,7 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
     }
     if (LIGHT && cflags) {   // capacity exceeded: leave this substep (and the rest) to the heavy tier; nothing was mutated
       left = nsub - sub;
-      if (emode == 1) {
+      if (emode == 1 || emode == 3) {
         if (lane < nu) s.task[JT_CTRL + lane] = s.ctrl[lane];
         if (lane == 0) { s.task[JT_PENDING] = 1.f; s.task[JT_SUB] = (float)sub; }
         wave_sync();
@@ -1013,6 +1063,11 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
     wave_sync();
     stage_integrate_pos(m, s, lane);
     wave_sync();
+    if (emode == 3) {   // set_obj_xyz (mujoco.py:217-227): object back to the pinned pose, all free-body velocities zeroed
+      if (lane >= 9 && lane < 16) s.qpos[lane] = pinv;
+      if (lane >= 9 && lane < nv) s.qvel[lane] = 0.f;
+      wave_sync();
+    }
     JSTAMP(8);
   }
   if (emode != 2) {
@@ -1021,7 +1076,7 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
   }
   if (left == 0 && lane < ns && A.sensordata) A.sensordata[(size_t)env * ns + lane] = sens;
   if (emode) {
-    if (left == 0) {
+    if (left == 0 && emode != 3) {
       // observation, reward, termination from the poses / sensors of the last forward pass (one substep stale, as in
       // the reference) -- make_observation, _get_reward, terminal_inspection (env_mujoco.py:122-126)
       float* CW = A.cache + (size_t)env * JCACHE_N;
@@ -1074,6 +1129,7 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
         A.obs[(size_t)env * 26 + lane] = o;
       }
     }
+    if (left == 0 && emode == 3 && lane == 0) { s.task[JT_SUB] = 0.f; s.task[JT_PENDING] = 0.f; }
     wave_sync();
     if (lane < JTASK_N) A.task[(size_t)env * JTASK_N + lane] = s.task[lane];
   }
@@ -1114,6 +1170,6 @@ __global__ __launch_bounds__(64) void jaco_physics_kernel_heavy(JacoStepArgs A) 
   const int count = *A.heavy_count;
   for (int i = env_id(); i < count; i += grid_size()) {
     int env = A.heavy_list[i];
-    run_env<JacoHeavy, false>(A, s, env, A.env_mode == 1 ? A.nsub : A.remaining[env], lane);
+    run_env<JacoHeavy, false>(A, s, env, (A.env_mode == 1 || A.env_mode == 3) ? A.nsub : A.remaining[env], lane);
   }
 }

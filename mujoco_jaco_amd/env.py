@@ -100,6 +100,11 @@ class JacoBatchedEnv:
         self.sim._chk(self.L.jaco_reset(self.h, self._p(m) if m is not None else None, self._p(self._obs), self.sim._stream()))
         return self._out(self._obs)[0]
 
+    def _placing_hold(self, mask=None, nsub=150):
+        """The held part of the placing reset on its own (env_mujoco_util.py:106-117); reset() runs it for task 'placing'."""
+        m = None if mask is None else mask.to(self.device).to(torch.uint8).contiguous()
+        self.sim._chk(self.L.jaco_placing_hold(self.h, self._p(m) if m is not None else None, int(nsub), self.sim._stream()))
+
     def step(self, action, weight=None, subgoal=None, id=None):
         a = torch.as_tensor(action, dtype=torch.float32, device=self.device).reshape(self.num_envs, -1)
         a = torch.max(torch.min(a, self._amax), self._amin).contiguous()          # np.clip (env_mujoco.py:117)

@@ -88,6 +88,14 @@ class EmuJacoEnv(EmuEnv):
         assert rc == 0
         self.heavy_envs = hv.value
 
+    def placing_hold(self, nsub=150):
+        """mode 3: the held part of the placing reset (jaco_reset runs it between the reset kernel and jaco_forward)."""
+        fs, self.frame_skip = self.frame_skip, nsub
+        try:
+            self._call(3, None, None)
+        finally:
+            self.frame_skip = fs
+
     def forward(self, noise=None):
         self._call(2, None, None if noise is None else np.ascontiguousarray(noise, np.float32))
         return self.obs.copy()

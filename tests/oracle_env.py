@@ -18,6 +18,7 @@ class OracleEnv:
         self.task, self.frame_skip = task, frame_skip
         self.ee = names["body"].index("EE")
         self.obj = names["body"].index("object_body")
+        self.ee_obj = names["body"].index("EE_obj") if "EE_obj" in names["body"] else -1
         self.base = np.array([0.0, 0.0, 0.157])
         self.grip, self.steps, self.episodes = 0.6, 0, 0
         self.obj_goal, self.dest_goal = np.zeros(3), np.zeros(3)
@@ -60,3 +61,35 @@ class OracleEnv:
         if self.steps < 700:
             self.episodes += 1
         return obs, rew + bonus, done, succ
+
+    def placing_hold(self, nsub=150):
+        """The object part of the placing reset (env_mujoco_util.py:106-117): object into the grasp frame, `nsub` controlled
+        substeps (gripper command 0.6) each followed by set_obj_xyz, i.e. re-pin + zero free-body velocities + sim.forward(),
+        so the controller always reads the *current* state's M, J, bias (no staleness inside this loop)."""
+        o = self.o
+        po = o.get("xpos").reshape(-1, 3)[self.ee_obj].copy()
+        qo = o.get("xquat").reshape(-1, 4)[self.ee_obj].copy()
+        eul = glue.euler_from_quat(qo)
+        quat = glue.quat_from_euler(*eul)
+        pos = po + glue.get_rotation(eul[0], eul[1], eul[2], [-0.04, 0, 0])
+        pe, qe = self._ee()
+
+        def pin():
+            q, v = o.get("qpos").copy(), o.get("qvel").copy()
+            q[9:12], q[12:16] = pos, quat
+            v[9:] = 0
+            o.set("qpos", q); o.set("qvel", v)
+            o.forward()
+        pin()
+        pe, qe = self._ee()
+        target = np.concatenate([pe, glue.euler_from_quat(qe)])
+        self.grip = 0.6
+        for _ in range(nsub):
+            jp, jr = o.jac_body_com(self.ee)
+            J = np.vstack([jp[:, :6], jr[:, :6]])
+            M = o.get("qM").reshape(o.nv, o.nv)[:6, :6]
+            pe, qe = self._ee()
+            u = glue.osc_generate(o.get("qvel")[:6], target, J, M, o.get("qfrc_bias")[:6], pe, qe)
+            o.step(np.concatenate([u, [0.6] * 3]))
+            pin()
+        return pos, quat, target

@@ -78,3 +78,35 @@ def test_osc_pseudo_inverse_branch(names, model_arrays):
     oo, orew, odone, _ = oe.step(a.astype(np.float64), nz[0].astype(np.float64))
     assert e.flags[0] & 64                                                   # informational flag: branch taken
     assert np.abs(e.qpos[0, :9] - o.get("qpos")[:9]).max() < 2e-4 and np.abs(obs[0] - oo).max() < 2e-4
+
+
+def _placing_state(M, seed):
+    """Arm angles of the reference's placing reset (env_mujoco_util.py:181-185); object / pedestal as sampled by __sample_goal."""
+    rng = np.random.default_rng(seed)
+    q = workload.reset_states(M["qpos0"], 1, seed=seed)[0]
+    a0 = rng.uniform(3 * np.pi / 8, np.pi / 2) if rng.uniform() < 0.5 else rng.uniform(np.pi / 2, 5 * np.pi / 8)
+    q[:6] = [a0, 3.85, rng.uniform(1, 1.1), rng.uniform(2, 2.1), rng.uniform(0.8, 2.3), rng.uniform(-1.2, -1.1)]
+    return q
+
+
+def test_placing_hold_matches_oracle(names, model_arrays):
+    """Placing reset, object part: object pinned to the grasp frame while the fingers close for `nsub` controlled substeps
+    (fresh controller data every substep).  Short hold here (the GPU tier runs the reference's 150)."""
+    nsub = 25
+    q = _placing_state(model_arrays, 11)
+    e = EmuJacoEnv(task_id=1)
+    oe = OracleEnv(names, task="placing")
+    oe.set_state(q.astype(np.float32).astype(np.float64))
+    e.qpos[0] = q
+    e.placing_hold(nsub)
+    pos, quat, target = oe.placing_hold(nsub)
+    # object pose: pinned (bit-for-bit the value written to the cache row), quaternion equal up to sign
+    pin = e.cache[0, 96:103]
+    assert np.array_equal(e.qpos[0, 9:16], pin) and np.all(e.qvel[0, 9:] == 0)
+    sgn = 1.0 if np.dot(pin[3:], quat) > 0 else -1.0
+    assert np.abs(pin[:3] - pos).max() < 1e-6 and np.abs(sgn * pin[3:] - quat).max() < 1e-6
+    assert np.abs(e.task[0, 10:16] - target).max() < 1e-5                      # controller target = EE pose at reset
+    oq = oe.o.get("qpos")
+    assert np.abs(e.qpos[0, :9] - oq[:9]).max() < 2e-4                         # arm + fingers after the hold
+    assert e.qpos[0, 6:9].max() < q[6:9].min() - 0.003                         # the finger servos moved towards the 0.6 command
+    assert e.task[0, 17] == 0 and e.task[0, 19] == 0                           # substep counter / pending flag cleared
