@@ -37,6 +37,7 @@ extern "C" {
 #define JACO_FLAG_NAN 8u            /* non-finite velocity: env should be reset */
 #define JACO_FLAG_SOLVER_MAXITER 16u
 #define JACO_FLAG_HEAVY_TIER 32u     /* informational: stepped by the 256-row tier at least once (not an error) */
+#define JACO_FLAG_TIER_RETURN 128u   /* informational: the heavy tier gave the env back to the light code in mid-step (overflow was transient) */
 #define JACO_FLAG_OSC_SINGULAR 64u   /* informational: |det(J M^-1 J^T)| < 1e-3, the controller used its pseudo-inverse branch */
 
 /* task ids (env_script/env_mujoco.py:18-23; only picking/placing return the 4-tuple step() unpacks) */
@@ -115,6 +116,12 @@ int jaco_set_noise(JacoHandle* h, const float* noise_dev);
 int jaco_get_task_state(JacoHandle* h, float* out_dev, void* stream);
 int jaco_set_task_state(JacoHandle* h, const float* in_dev, void* stream);
 int jaco_task_row_floats(void);
+/* Marker poses [num_envs][2][12] f32: {"hand", "subgoal_reach"} x {position, rotation matrix row-major} -- the two mocap bodies
+ * _take_action moves every env step (set_mocap_xyz / set_mocap_orientation, mujoco.py:248-256, env_mujoco_util.py:613-615,
+ * 644-646).  Their contype-8 geoms collide with the EE axis sticks; jaco_step updates them in-kernel, jaco_reset* park
+ * them at their XML pose. */
+int jaco_get_markers(JacoHandle* h, float* out_dev, void* stream);
+int jaco_set_markers(JacoHandle* h, const float* in_dev, void* stream);
 int jaco_set_frame_skip(JacoHandle* h, int frame_skip);
 
 /* Solver / collision options, MuJoCo <option> names: "iterations", "tolerance", "ls_iterations",

@@ -54,6 +54,14 @@ JDEV void euler_rxyz_to_quat(float a, float b, float c, float* q) {
   float w1 = ca * cb, x1 = sa * cb, y1 = ca * sb, z1 = sa * sb;
   q[0] = w1 * cc - z1 * sc; q[1] = x1 * cc + y1 * sc; q[2] = y1 * cc - x1 * sc; q[3] = w1 * sc + z1 * cc;
 }
+JDEV m3 euler_rxyz_to_mat(float a, float b, float c) {   // Rx(a) Ry(b) Rz(c)
+  float ca = cosf(a), sa = sinf(a), cb = cosf(b), sb = sinf(b), cc = cosf(c), sc = sinf(c);
+  m3 M;
+  M.m[0] = cb * cc; M.m[1] = -cb * sc; M.m[2] = sb;
+  M.m[3] = sa * sb * cc + ca * sc; M.m[4] = -sa * sb * sc + ca * cc; M.m[5] = -sa * cb;
+  M.m[6] = -ca * sb * cc + sa * sc; M.m[7] = ca * sb * sc + sa * cc; M.m[8] = ca * cb;
+  return M;
+}
 JDEV void mat_to_quat(const m3& R, float* q) {
   float t = R.m[0] + R.m[4] + R.m[8];
   if (t > 0.f) {

@@ -57,6 +57,12 @@ struct JacoModelDev {
   int g_body[JMAXGEOM], g_type[JMAXGEOM], g_vertadr[JMAXGEOM], g_vertnum[JMAXGEOM], g_origbody[JMAXGEOM], g_mocap[JMAXGEOM];
   float g_pos[JMAXGEOM][3], g_mat[JMAXGEOM][9], g_size[JMAXGEOM][3], g_rbound[JMAXGEOM], g_invweight[JMAXGEOM][2];
 
+  // geoms riding on the two markers the task layer moves every env step ("hand" = 0, "subgoal_reach" = 1): g_marker is the
+  // marker index or -1; for those geoms g_lpos / g_lmat hold the pose in the marker's frame (g_pos / g_mat: XML rest pose)
+  int g_marker[JMAXGEOM];
+  float g_lpos[JMAXGEOM][3], g_lmat[JMAXGEOM][9];
+  float marker_rest[2][12];   // rest pose of the two markers (position, rotation row-major): where sim.reset() puts them
+
   JacoPairParam pair[JMAXPAIR];
   int pair_code[JMAXPAIR];   // g1 | g2 << 8 | type(g1) << 16 | type(g2) << 20, for the lane-per-pair broadphase
 

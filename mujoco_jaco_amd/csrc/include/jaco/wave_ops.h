@@ -88,6 +88,12 @@ JDEV int wave_argmax(float v, int idx, float* best) {
 JDEV unsigned long long wave_clock() { return __builtin_amdgcn_s_memtime(); }   // free-running shader clock
 JDEV int grid_size() { return (int)gridDim.x; }
 JDEV int jaco_atomic_inc(int* p) { return atomicAdd(p, 1); }
+JDEV int jaco_atomic_dec(int* p) { return __hip_atomic_fetch_sub(p, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+// device-scope publish / observe for the light -> heavy work list (the two tiers run concurrently in different workgroups)
+JDEV void dev_fence() { __threadfence(); }
+JDEV void dev_store_release(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+JDEV int dev_load_acquire(const int* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); }
+JDEV void wave_sleep() { __builtin_amdgcn_s_sleep(127); }   // ~8k cycles
 
 // Pin three already-loaded values in VGPRs here: keeps the optimiser from sinking their loads into a (divergent) branch.
 JDEV void keep_loaded(float& a, float& b, float& c) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c)); }

@@ -2,6 +2,7 @@
 // Host side owns model constants, per-env state rows and launch plumbing; all arithmetic is in
 // physics_kernel.h.  There is no CPU fallback: without a HIP device jaco_create fails.
 #include <hip/hip_runtime.h>
+#include <cstddef>
 
 #include <cstdio>
 #include <cstring>
@@ -24,8 +25,12 @@ struct JacoHandle {
   float *qpos = nullptr, *qvel = nullptr, *qacc_ws = nullptr, *sensordata = nullptr, *dbg = nullptr;
   unsigned* flags = nullptr;
   int* stats = nullptr;
-  int *remaining = nullptr, *heavy_list = nullptr, *heavy_count = nullptr;
+  int *remaining = nullptr, *heavy_list = nullptr, *heavy_count = nullptr;   // heavy_count[0..2]: appended, claimed, light workgroups left
+  hipStream_t side = nullptr;                 // heavy-tier workers run here, concurrently with the light tier
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int concurrent = 1, workers = 128, tier_return = 1;           // options "concurrent_heavy", "heavy_workers"
   float *task_rows = nullptr, *cache = nullptr;
+  float* marker = nullptr;    // [num_envs][2][12] poses of the "hand" / "subgoal_reach" markers (mocap bodies the task layer moves)
   unsigned* cost = nullptr;   // per env: shader-clock ticks its last step took (>> 4)
   int* order = nullptr;       // launch order of the env-level light kernel: expensive envs first
   int schedule = 1;           // option "schedule": 0 = launch envs in index order
@@ -98,8 +103,17 @@ extern "C" int jaco_create(const JacoConfig* cfg, JacoHandle** out) {
   CREATECHK(hipMalloc(&h->dbg, JDBG_SIZE * sizeof(float)));
   CREATECHK(hipMalloc(&h->remaining, B * sizeof(int)));
   CREATECHK(hipMalloc(&h->heavy_list, B * sizeof(int)));
-  CREATECHK(hipMalloc(&h->heavy_count, sizeof(int)));
+  CREATECHK(hipMalloc(&h->heavy_count, 4 * sizeof(int)));
+  CREATECHK(hipMemset(h->heavy_count, 0, 4 * sizeof(int)));
+  {
+    int lo = 0, hi = 0;
+    CREATECHK(hipDeviceGetStreamPriorityRange(&lo, &hi));   // (hi = numerically lowest = highest priority)
+    CREATECHK(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, hi));
+    CREATECHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    CREATECHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+  }
   CREATECHK(hipMemset(h->remaining, 0, B * sizeof(int)));
+  CREATECHK(hipMalloc(&h->marker, B * 24 * sizeof(float)));
   CREATECHK(hipMalloc(&h->cost, B * sizeof(unsigned)));
   CREATECHK(hipMalloc(&h->order, B * sizeof(int)));
   CREATECHK(hipMemset(h->cost, 0, B * sizeof(unsigned)));
@@ -141,7 +155,10 @@ extern "C" int jaco_destroy(JacoHandle* h) {
   if (!h) return JACO_EINVAL;
   (void)hipSetDevice(h->device);
   for (auto& e : h->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-  void* ptrs[] = {h->model_dev, h->hull_dev, h->qpos, h->qvel, h->qacc_ws, h->sensordata, h->flags, h->stats, h->dbg, h->prof, h->remaining, h->heavy_list, h->heavy_count, h->task_rows, h->cache, h->cost, h->order};
+  if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+  void* ptrs[] = {h->model_dev, h->hull_dev, h->qpos, h->qvel, h->qacc_ws, h->sensordata, h->flags, h->stats, h->dbg, h->prof, h->remaining, h->heavy_list, h->heavy_count, h->task_rows, h->cache, h->cost, h->order, h->marker};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   delete h;
   return JACO_OK;
@@ -194,6 +211,10 @@ extern "C" int jaco_reset_state(JacoHandle* h, void* stream) {
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipMemsetAsync(h->qvel, 0, B * m.nv * sizeof(float), st));
   HIPCHK(h, hipMemsetAsync(h->qacc_ws, 0, B * m.nv * sizeof(float), st));
+  // markers back to their XML rest pose (sim.reset() restores mocap_pos / mocap_quat)
+  const float* rest = (const float*)((const char*)h->model_dev + offsetof(JacoModelDev, marker_rest));
+  hipLaunchKernelGGL(jaco_fill_rows_kernel, dim3((unsigned)((B * 24 + 255) / 256)), dim3(256), 0, st, h->marker, rest, 24, (int)B);
+  HIPCHK(h, hipGetLastError());
   return JACO_OK;
 }
 
@@ -243,16 +264,23 @@ __global__ __launch_bounds__(1024) void jaco_order_kernel(const unsigned* cost, 
   }
 }
 
+// work-list reset before every launch: counters = {0 appended, 0 claimed, nenv light workgroups to go}, entries = -1
+__global__ void jaco_prepare_kernel(int* ctl, int* list, int n) {
+  int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i < n) list[i] = -1;
+  if (i == 0) { ctl[0] = 0; ctl[1] = 0; ctl[2] = n; }
+}
+
 static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t st, float* dbg, int dbg_env, const EnvIO& io = EnvIO()) {
   if ((!ctrl && io.mode == 0) || nsub <= 0) { h->err = "jaco_physics_step: bad arguments"; return JACO_EINVAL; }
   JacoStepArgs A{};
   A.model = h->model_dev; A.hull = h->hull_dev; A.qpos = h->qpos; A.qvel = h->qvel; A.qacc_ws = h->qacc_ws;
   A.ctrl = ctrl ? ctrl : h->qvel;   // env modes compute ctrl in-kernel; the pointer only has to be readable
   A.sensordata = h->sensordata; A.flags = h->flags; A.stats = h->stats; A.nenv = h->num_envs; A.nsub = nsub;
-  A.disable_contact = h->disable_contact; A.dbg = dbg; A.dbg_env = dbg_env; A.prof = h->prof;
-  A.remaining = h->remaining; A.heavy_list = h->heavy_list; A.heavy_count = h->heavy_count;
+  A.disable_contact = h->disable_contact; A.no_tier_return = !h->tier_return; A.dbg = dbg; A.dbg_env = dbg_env; A.prof = h->prof;
+  A.remaining = h->remaining; A.heavy_list = h->heavy_list; A.heavy_count = h->heavy_count; A.heavy_taken = h->heavy_count + 1; A.light_left = h->heavy_count + 2;
   A.env_mode = io.mode; A.task_id = h->task; A.nact = h->task == JACO_TASK_REACHING ? 6 : 7; A.seed = h->seed;
-  A.task = h->task_rows; A.cache = h->cache; A.action = io.action; A.noise = h->noise; A.obs = io.obs; A.reward = io.reward; A.done = io.done; A.mask = io.mask;
+  A.task = h->task_rows; A.cache = h->cache; A.action = io.action; A.noise = h->noise; A.obs = io.obs; A.reward = io.reward; A.done = io.done; A.mask = io.mask; A.marker = h->marker;
   A.cost = h->cost;
   const bool reorder = io.mode == 1 && h->schedule && nsub >= 8 && h->num_envs >= 4096;
   std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
@@ -266,17 +294,31 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
     ev = &h->events[h->events_used++];
     HIPCHK(h, hipEventRecord(ev->first, st));
   }
-  // light tier for every env, then the heavy tier for the envs that overflowed the light capacities
-  HIPCHK(h, hipMemsetAsync(h->heavy_count, 0, sizeof(int), st));
+  // Light tier for every env.  An env that overflows the light capacities is handed over (work list) to the heavy tier,
+  // whose few persistent workgroups run concurrently on a second, higher-priority stream: started just before the light
+  // grid they are resident from the beginning (a heavy wave needs a SIMD of its own and would otherwise starve behind the
+  // light grid, leaving a serial tail of several ms per env step).  The drain launch that follows in stream order
+  // serves whatever the workers did not (all of it when concurrency is off).
+  hipLaunchKernelGGL(jaco_prepare_kernel, dim3((unsigned)((h->num_envs + 255) / 256)), dim3(256), 0, st, h->heavy_count, h->heavy_list, h->num_envs);
+  HIPCHK(h, hipGetLastError());
   if (reorder) {
     hipLaunchKernelGGL(jaco_order_kernel, dim3(1), dim3(1024), 0, st, h->cost, h->order, h->num_envs);
     HIPCHK(h, hipGetLastError());
     A.order = h->order;
   }
+  const bool conc = h->concurrent && io.mode == 1 && nsub >= 8 && h->num_envs >= 4096;
+  if (conc) {
+    HIPCHK(h, hipEventRecord(h->ev_fork, st));
+    HIPCHK(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
+    hipLaunchKernelGGL(jaco_physics_kernel_heavy, dim3((unsigned)h->workers), dim3(64), 0, h->side, A);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipEventRecord(h->ev_join, h->side));
+  }
   hipLaunchKernelGGL(jaco_physics_kernel, dim3((unsigned)h->num_envs), dim3(64), 0, st, A);
   HIPCHK(h, hipGetLastError());
+  if (conc) HIPCHK(h, hipStreamWaitEvent(st, h->ev_join, 0));
   unsigned hg = (unsigned)(h->num_envs < 1024 ? h->num_envs : 1024);
-  hipLaunchKernelGGL(jaco_physics_kernel_heavy, dim3(hg), dim3(64), 0, st, A);
+  hipLaunchKernelGGL(jaco_physics_kernel_heavy_drain, dim3(hg), dim3(64), 0, st, A);
   HIPCHK(h, hipGetLastError());
   if (ev) HIPCHK(h, hipEventRecord(ev->second, st));
   return JACO_OK;
@@ -288,7 +330,7 @@ extern "C" int jaco_physics_step(JacoHandle* h, const float* ctrl_dev, int nsub,
 }
 // ---- env level: reset / step with the reference's Gym-style semantics, batched -------------------------
 struct JacoResetArgs {
-  const float* qpos0; float* qpos; float* qvel; float* qacc_ws; float* task; const unsigned char* mask;
+  const float* qpos0; float* qpos; float* qvel; float* qacc_ws; float* task; const unsigned char* mask; float* marker; const float* marker_rest;
   int nenv, nq, nv, task_id, has_free; unsigned long long seed;
 };
 __global__ void jaco_reset_kernel(JacoResetArgs R) {
@@ -300,6 +342,7 @@ __global__ void jaco_reset_kernel(JacoResetArgs R) {
   float* q = R.qpos + (size_t)e * R.nq;
   for (int k = 0; k < R.nq; k++) q[k] = R.qpos0[k];
   for (int k = 0; k < R.nv; k++) { R.qvel[(size_t)e * R.nv + k] = 0.f; R.qacc_ws[(size_t)e * R.nv + k] = 0.f; }
+  for (int k = 0; k < 24; k++) R.marker[(size_t)e * 24 + k] = R.marker_rest[k];   // sim.reset(): markers back to their XML pose
   // _create_init_angle (env_mujoco_util.py:176-185); fingers stay at qpos0 (mujoco.py:342-343)
   if (R.task_id == JACO_TASK_PLACING) {
     const float PI = 3.14159265358979323846f;
@@ -336,7 +379,8 @@ extern "C" int jaco_reset(JacoHandle* h, const uint8_t* mask_dev, float* obs_dev
   hipStream_t st = (hipStream_t)stream;
   const JacoModelDev& m = h->model_host;
   HIPCHK(h, hipMemcpyAsync(h->dbg, h->qpos0.data(), m.nq * sizeof(float), hipMemcpyHostToDevice, st));
-  JacoResetArgs R{h->dbg, h->qpos, h->qvel, h->qacc_ws, h->task_rows, mask_dev, h->num_envs, m.nq, m.nv, h->task, m.nq >= 23, h->seed};
+  const float* rest = (const float*)((const char*)h->model_dev + offsetof(JacoModelDev, marker_rest));
+  JacoResetArgs R{h->dbg, h->qpos, h->qvel, h->qacc_ws, h->task_rows, mask_dev, h->marker, rest, h->num_envs, m.nq, m.nv, h->task, m.nq >= 23, h->seed};
   hipLaunchKernelGGL(jaco_reset_kernel, dim3((unsigned)((h->num_envs + 255) / 256)), dim3(256), 0, st, R);
   HIPCHK(h, hipGetLastError());
   if (h->task == JACO_TASK_PLACING) {   // object into the hand, 150 held substeps while the fingers close (env_mujoco_util.py:106-117)
@@ -367,6 +411,16 @@ extern "C" int jaco_set_task_state(JacoHandle* h, const float* in_dev, void* str
   return JACO_OK;
 }
 extern "C" int jaco_task_row_floats(void) { return JTASK_N; }
+extern "C" int jaco_get_markers(JacoHandle* h, float* out_dev, void* stream) {
+  if (!h || !out_dev) return JACO_EINVAL;
+  HIPCHK(h, hipMemcpyAsync(out_dev, h->marker, (size_t)h->num_envs * 24 * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return JACO_OK;
+}
+extern "C" int jaco_set_markers(JacoHandle* h, const float* in_dev, void* stream) {
+  if (!h || !in_dev) return JACO_EINVAL;
+  HIPCHK(h, hipMemcpyAsync(h->marker, in_dev, (size_t)h->num_envs * 24 * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return JACO_OK;
+}
 extern "C" int jaco_set_frame_skip(JacoHandle* h, int frame_skip) {
   if (!h || frame_skip <= 0) return JACO_EINVAL;
   h->frame_skip = frame_skip;
@@ -410,6 +464,9 @@ extern "C" int jaco_set_option(JacoHandle* h, const char* name, double v) {
   JacoModelDev& m = h->model_host;
   if (!strcmp(name, "disable_contact")) { h->disable_contact = v != 0; return JACO_OK; }
   if (!strcmp(name, "schedule")) { h->schedule = v != 0; return JACO_OK; }
+  if (!strcmp(name, "concurrent_heavy")) { h->concurrent = v != 0; return JACO_OK; }
+  if (!strcmp(name, "tier_return")) { h->tier_return = v != 0; return JACO_OK; }
+  if (!strcmp(name, "heavy_workers")) { h->workers = v < 1 ? 1 : (int)v; return JACO_OK; }
   else if (!strcmp(name, "iterations")) m.iterations = (int)v;
   else if (!strcmp(name, "tolerance")) m.tolerance = (float)v;
   else if (!strcmp(name, "ls_iterations")) m.ls_iterations = (int)v;

@@ -169,7 +169,14 @@ int jaco_model_from_blob(const void* buf, size_t size, JacoModelDev* m, std::vec
   const double *grb = B.f64("f_geom_rbound", ng), *giw = B.f64("f_geom_invweight", 2 * ng);
   const double *mp0 = B.f64("mocap_pos0"), *mq0 = B.f64("mocap_quat0");
   if (!gb || !gty || !gva || !gvn || !gob || !gmo || !gp || !gq || !gs || !grb || !giw || !mp0 || !mq0) FAIL(B.err);
+  const int32_t* mk = B.has("f_marker_mocap") ? B.i32("f_marker_mocap", 2) : nullptr;
+  for (int k = 0; k < 2; k++) {
+    for (int i = 0; i < 12; i++) m->marker_rest[k][i] = 0.f;
+    m->marker_rest[k][3] = m->marker_rest[k][7] = m->marker_rest[k][11] = 1.f;
+    if (mk && mk[k] >= 0) { cp3(m->marker_rest[k], mp0 + 3 * mk[k]); quat2mat(mq0 + 4 * mk[k], m->marker_rest[k] + 3); }
+  }
   for (int g = 0; g < ng; g++) {
+    m->g_marker[g] = -1;
     m->g_body[g] = gb[g]; m->g_type[g] = gty[g]; m->g_vertadr[g] = gva[g]; m->g_vertnum[g] = gvn[g];
     m->g_origbody[g] = gob[g]; m->g_mocap[g] = gmo[g];
     cp3(m->g_pos[g], gp + 3 * g); quat2mat(gq + 4 * g, m->g_mat[g]); cp3(m->g_size[g], gs + 3 * g);
@@ -177,6 +184,8 @@ int jaco_model_from_blob(const void* buf, size_t size, JacoModelDev* m, std::vec
     if (gmo[g] >= 0) {  // marker geoms ride on mocap bodies: compose with the XML mocap pose (static until the task layer moves them)
       float R[9], lp[3] = {m->g_pos[g][0], m->g_pos[g][1], m->g_pos[g][2]}, lm[9];
       memcpy(lm, m->g_mat[g], sizeof lm);
+      for (int k = 0; k < 2; k++)
+        if (mk && mk[k] == gmo[g]) { m->g_marker[g] = k; memcpy(m->g_lpos[g], lp, sizeof lp); memcpy(m->g_lmat[g], lm, sizeof lm); }
       quat2mat(mq0 + 4 * gmo[g], R);
       for (int i = 0; i < 3; i++) {
         m->g_pos[g][i] = (float)mp0[3 * gmo[g] + i] + R[3 * i] * lp[0] + R[3 * i + 1] * lp[1] + R[3 * i + 2] * lp[2];

@@ -39,6 +39,7 @@ typedef JacoCaps<256, 64, 256> JacoHeavy;
 #define JFLAG_NAN 8u
 #define JFLAG_SOLVER_MAXITER 16u
 #define JFLAG_HEAVY_TIER 32u   // informational: env was stepped by the heavy tier at least once
+#define JFLAG_TIER_RETURN 128u  // informational: the heavy tier handed the env back to the light code in mid-step
 
 #define JMINVAL 1e-15f
 
@@ -72,12 +73,16 @@ struct JacoStepArgs {
   int* stats;          // [nenv][4]: ncon, nefc, newton iterations, candidates (last substep) or nullptr
   int* remaining;      // [nenv] substeps left for the heavy tier (written by the light tier)
   int* heavy_list;     // [nenv] env ids handed to the heavy tier
-  int* heavy_count;    // [1]
+  int* heavy_count;    // [1] entries appended to heavy_list
+  int* heavy_taken;    // [1] entries claimed by heavy-tier workgroups
+  int* light_left;     // [1] light-tier workgroups still running (0: no further entries will appear)
   int nenv, nsub, disable_contact;
+  int no_tier_return;  // 1: an env handed to the heavy tier stays there for the rest of the launch (option "tier_return" = 0)
   // env-level mode (jaco_step / jaco_reset): nsub = frame_skip
   int env_mode;              // 0 ctrl-level, 1 env step, 2 forward only (reset: fill cache + observation),
                              // 3 placing reset: nsub controlled substeps with the object pinned in the hand (env_mujoco_util.py:106-117)
   const unsigned char* mask; // mode 3: envs to run (nullptr = all)
+  float* marker;             // [nenv][2][12] poses (position, rotation) of the "hand" / "subgoal_reach" markers, or nullptr = XML rest pose
   int task_id, nact;
   unsigned long long seed;
   float* task;               // [nenv][JTASK_N]
@@ -462,10 +467,16 @@ JDEV void stage_walk(const JacoModelDev* m, L& s, int lane) {
 
 // ---------------------------------------------------------------- stage G: geom poses, body inertias, RNE body forces
 template <class L>
-JDEV void stage_geoms_inertia(const JacoModelDev* m, L& s, int lane) {
+JDEV void stage_geoms_inertia(const JacoModelDev* m, L& s, int lane, const float* mk) {
   if (lane < m->ngeom) {
     int b = m->g_body[lane];
-    if (b >= 0) {
+    const int km = mk ? m->g_marker[lane] : -1;
+    if (km >= 0) {   // geom on a marker the task layer moved (set_mocap_xyz / set_mocap_orientation): static, per-env pose
+      const float* P = mk + 12 * km;
+      m3 R = ldm(P + 3);
+      st3(s.gpos[lane], ld3(P) + mul(R, ld3(m->g_lpos[lane])));
+      stm(s.gmat[lane], mul(R, ldm(m->g_lmat[lane])));
+    } else if (b >= 0) {
       m3 R = ldm(s.xmat[b]);
       st3(s.gpos[lane], ld3(s.xpos[b]) + mul(R, ld3(m->g_pos[lane])));
       stm(s.gmat[lane], mul(R, ldm(m->g_mat[lane])));
@@ -856,10 +867,9 @@ JDEV void stage_integrate_pos(const JacoModelDev* m, L& s, int lane) {
 // ---------------------------------------------------------------- the kernels
 // One substep loop for one env; returns the number of substeps NOT done (light tier bail-out) or 0.
 template <class C, bool LIGHT>
-JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int lane) {
+JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int lane, bool handback = false) {
   const JacoModelDev* m = opaque_ptr(A.model);
   const int nq = m->nq, nv = m->nv, nu = m->nu, ns = m->nsensor;
-  const unsigned long long t_start = wave_clock();
   if (A.env_mode == 3 && A.mask && !A.mask[env]) return 0;
   if (lane < nq) s.qpos[lane] = A.qpos[(size_t)env * nq + lane];
   if (lane < nv) { s.qvel[lane] = A.qvel[(size_t)env * nv + lane]; s.qacc_ws[lane] = A.qacc_ws[(size_t)env * nv + lane]; }
@@ -867,7 +877,7 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
   stage_model(m, s, lane);
   unsigned flags = LIGHT ? 0u : JFLAG_HEAVY_TIER;
   float sens = 0.f;
-  int iters = 0, left = 0, sub0 = 0, nls_last = 0;
+  int iters = 0, left = 0, sub0 = 0, nls_last = 0, calm = 0;
   const int emode = A.env_mode;
   if (emode) {   // task row + the one-substep-stale quantities the controller reads (env_logic.h)
     if (lane < JTASK_N) s.task[lane] = A.task[(size_t)env * JTASK_N + lane];
@@ -880,14 +890,33 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
   wave_sync();
   if (emode == 1) {
     if (s.task[JT_DONE] != 0.f) {   // finished and not yet reset: frozen (no auto-reset)
-      if (lane == 0) { A.reward[env] = 0.f; A.done[env] = 1; if (A.cost) A.cost[env] = 0u; }
+      if (lane == 0) { A.reward[env] = 0.f; A.done[env] = 1; }
       return 0;
     }
     sub0 = wave_uniform_i((int)s.task[JT_SUB]);
     if (sub0 == 0) {
       // _take_action: the marker placement consumes 6 draws (a8), then the EE target and the gripper ramp
       take_action(m, s, A.action + (size_t)env * A.nact, A.nact, lane);
-      if (lane == 0) { unsigned c = __float_as_uint(s.task[JT_RNG]); s.task[JT_RNG] = __uint_as_float(c + 6u); }
+      const unsigned cnt0 = __float_as_uint(s.task[JT_RNG]);
+      wave_sync();
+      if (A.marker) {   // set_mocap_*("subgoal_reach", rule-based sub-goal) and set_mocap_*("hand", new target) (:613-615,:644-646)
+        float nz[6], spos[3], sori[3];
+        for (int k = 0; k < 6; k++) nz[k] = A.noise ? A.noise[(size_t)env * 12 + k] : rng_uniform(A.seed, (unsigned)env, cnt0 + k);
+        v3 pe; m3 Re;
+        ee_frame(m, s, &pe, &Re);
+        const int ob = m->obj_body >= 0 ? m->obj_body : 0;
+        rulebased_subgoal(A.task_id, pe, ld3(s.task + JT_OBJGOAL), s.xpos[ob][1], ld3(s.task + JT_DESTGOAL), nz, spos, sori);
+        // every lane whose geom rides on a marker stores that marker's pose itself (it is also the lane that reads it back)
+        const int km = lane < m->ngeom ? m->g_marker[lane] : -1;
+        if (km >= 0) {
+          const float* tg = s.task + JT_TARGET;
+          v3 mp = km == 0 ? ld3(tg) : mk3(spos[0], spos[1], spos[2]);
+          m3 MR = euler_rxyz_to_mat(km == 0 ? tg[3] : sori[0], km == 0 ? tg[4] : sori[1], km == 0 ? tg[5] : sori[2]);
+          float* P = A.marker + (size_t)env * 24 + 12 * km;
+          st3(P, mp); stm(P + 3, MR);
+        }
+      }
+      if (lane == 0) s.task[JT_RNG] = __uint_as_float(cnt0 + 6u);
       wave_sync();
     }
     osc_target_quat(s, lane);
@@ -963,7 +992,7 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
     for (int i = lane; i < JNV * JNV; i += 64) s.M[i] = 0.f;
     wave_sync();
     JSTAMP(0);
-    stage_geoms_inertia(m, s, lane);
+    stage_geoms_inertia(m, s, lane, A.marker ? A.marker + (size_t)env * 24 : nullptr);
     wave_sync();
     JSTAMP(1);
     stage_accumulate(m, s, lane);
@@ -994,6 +1023,7 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
       if (lane == 0) { s.ncon = 0; s.ncand = 0; }
       wave_sync();
     }
+    if (!LIGHT) calm = (s.ncon <= JacoLight::MAXCON && s.nefc <= JacoLight::MAXEFC && s.ncand <= JacoLight::MAXCAND / 2) ? calm + 1 : 0;
     if (LIGHT && cflags) {   // capacity exceeded: leave this substep (and the rest) to the heavy tier; nothing was mutated
       left = nsub - sub;
       if (emode == 1 || emode == 3) {
@@ -1069,6 +1099,14 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
       wave_sync();
     }
     JSTAMP(8);
+    // heavy tier: the burst that overflowed the light capacities is over (two substeps in a row would have fitted): give
+    // the env back to the light code for the rest of the step (the caller alternates the two tiers)
+    if (!LIGHT && handback && calm >= 2 && sub + 1 < nsub && emode != 2) {
+      left = nsub - (sub + 1);
+      flags |= JFLAG_TIER_RETURN;
+      if (emode == 1 || emode == 3) { if (lane == 0) { s.task[JT_PENDING] = 0.f; s.task[JT_SUB] = (float)(sub + 1); } wave_sync(); }
+      break;
+    }
   }
   if (emode != 2) {
     if (lane < nq) A.qpos[(size_t)env * nq + lane] = s.qpos[lane];
@@ -1076,15 +1114,20 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
   }
   if (left == 0 && lane < ns && A.sensordata) A.sensordata[(size_t)env * ns + lane] = sens;
   if (emode) {
-    if (left == 0 && emode != 3) {
-      // observation, reward, termination from the poses / sensors of the last forward pass (one substep stale, as in
-      // the reference) -- make_observation, _get_reward, terminal_inspection (env_mujoco.py:122-126)
+    if ((left == 0 && emode != 3) || (!LIGHT && left > 0 && emode == 1)) {
+      // what the controller reads one substep late, for the next launch -- or, on a heavy -> light hand-back in the middle
+      // of a step, for the light code's next substep
       float* CW = A.cache + (size_t)env * JCACHE_N;
       if (lane < 36) { CW[JC_M + lane] = s.M[(lane / 6) * JNV + lane % 6]; CW[JC_CDOF + lane] = s.cdof[lane / 6][lane % 6]; }
       if (lane < 6) CW[JC_BIAS + lane] = s.bias[lane];
       int ob = m->obj_body >= 0 ? m->obj_body : 0;
       if (lane < 3) { CW[JC_EEPOS + lane] = s.xpos[m->ee_body][lane]; CW[JC_OBJPOS + lane] = s.xpos[ob][lane]; }
       if (lane < 9) CW[JC_EEMAT + lane] = s.xmat[m->ee_body][lane];
+    }
+    if (left == 0 && emode != 3) {
+      // observation, reward, termination from the poses / sensors of the last forward pass (one substep stale, as in
+      // the reference) -- make_observation, _get_reward, terminal_inspection (env_mujoco.py:122-126)
+      int ob = m->obj_body >= 0 ? m->obj_body : 0;
       v3 pe; m3 Re;
       ee_frame(m, s, &pe, &Re);
       float eul[3];
@@ -1142,10 +1185,6 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
   if (left == 0 && lane == 0 && A.stats) {
     A.stats[4 * env] = s.ncon; A.stats[4 * env + 1] = s.nefc; A.stats[4 * env + 2] = iters; A.stats[4 * env + 3] = s.ncand | (nls_last << 16);
   }
-  if (lane == 0 && A.cost) {
-    unsigned c = (unsigned)((wave_clock() - t_start) >> 4);
-    A.cost[env] = LIGHT ? c : A.cost[env] + c;   // the heavy tier finishes what the light tier started
-  }
   wave_sync();
   return left;
 }
@@ -1156,20 +1195,77 @@ __global__ __launch_bounds__(64, 2) void jaco_physics_kernel(JacoStepArgs A) {
   const int lane = lane_id();
   if (env_id() >= A.nenv) return;
   const int env = A.order ? A.order[env_id()] : env_id();
+  const unsigned long long t_start = wave_clock();
   int left = run_env<JacoLight, true>(A, s, env, A.nsub, lane);
-  if (left > 0 && lane == 0) {
-    A.remaining[env] = left;
-    int slot = jaco_atomic_inc(A.heavy_count);
-    A.heavy_list[slot] = env;
+  if (lane == 0 && A.cost) A.cost[env] = (unsigned)((wave_clock() - t_start) >> 4);
+  // hand-off: the env's state is in global memory (run_env wrote it); publish it device-wide, then append the env to
+  // the heavy tier's work list.  Heavy-tier workgroups run concurrently (jaco_env.hip) and poll the list.
+  if (left > 0) {
+    dev_fence();
+    wave_sync();
+    if (lane == 0) {
+      A.remaining[env] = left;
+      int slot = jaco_atomic_inc(A.heavy_count);
+      dev_store_release(&A.heavy_list[slot], env);
+    }
+  }
+  if (lane == 0 && A.light_left) jaco_atomic_dec(A.light_left);
+}
+// One handed-over env on a heavy-tier workgroup: the heavy code runs while the overflow lasts, the light code in between
+// (a heavy wave has its SIMD to itself, so both run at solo speed), until the env's step is complete.
+union JacoTierLDS { JacoLDS<JacoHeavy> heavy; JacoLDS<JacoLight> light; };
+JDEV void run_env_tiers(const JacoStepArgs& A, JacoTierLDS& u, int env, int lane) {
+  const unsigned long long t_start = wave_clock();
+  const bool stepmode = A.env_mode == 1 || A.env_mode == 3;
+  int left = stepmode ? A.nsub : A.remaining[env];
+  for (;;) {
+    left = run_env<JacoHeavy, false>(A, u.heavy, env, stepmode ? A.nsub : left, lane, !A.no_tier_return);
+    if (left <= 0) break;
+    wave_sync();
+    left = run_env<JacoLight, true>(A, u.light, env, stepmode ? A.nsub : left, lane);
+    if (left <= 0) break;
+    wave_sync();
+  }
+  if (lane == 0 && A.cost) A.cost[env] += (unsigned)((wave_clock() - t_start) >> 4);
+}
+// heavy tier, concurrent with the light tier: persistent workgroups claim entries of the work list.  Entries are -1 until the light tier publishes them;
+// a worker leaves when the light tier has finished and every published entry is claimed, or (safety) when the light tier
+// makes no progress for ~JACO_WORKER_PATIENCE polls, e.g. because the two launches were serialised; whatever is left is
+// picked up by the drain launch that follows the light tier in stream order.
+#define JACO_WORKER_PATIENCE 6000
+__global__ __launch_bounds__(64) void jaco_physics_kernel_heavy(JacoStepArgs A) {
+  __shared__ JacoTierLDS u;
+  const int lane = lane_id();
+  for (;;) {
+    int i = 0;
+    if (lane == 0) i = jaco_atomic_inc(A.heavy_taken);
+    i = wave_uniform_i(i);
+    if (i >= A.nenv) return;
+    int env = -1, last_left = -1, idle = 0;
+    for (;;) {
+      env = wave_uniform_i(dev_load_acquire(&A.heavy_list[i]));
+      if (env >= 0) break;
+      const int ll = wave_uniform_i(dev_load_acquire(A.light_left));
+      if (ll <= 0 && i >= wave_uniform_i(dev_load_acquire(A.heavy_count))) return;   // nothing more will be published
+      idle = ll == last_left ? idle + 1 : 0;
+      last_left = ll;
+      if (idle > JACO_WORKER_PATIENCE) return;   // (a slot claimed here and filled later is served by the drain launch)
+      wave_sleep();
+    }
+    if (lane == 0) A.heavy_list[i] = -2;   // taken
+    run_env_tiers(A, u, env, lane);
+    wave_sync();
   }
 }
-// heavy tier: workgroups stride over the envs the light tier handed over
-__global__ __launch_bounds__(64) void jaco_physics_kernel_heavy(JacoStepArgs A) {
-  __shared__ JacoLDS<JacoHeavy> s;
+// drain: after the light tier and the workers have finished (stream order), serve whatever entry is still pending
+__global__ __launch_bounds__(64) void jaco_physics_kernel_heavy_drain(JacoStepArgs A) {
+  __shared__ JacoTierLDS u;
   const int lane = lane_id();
   const int count = *A.heavy_count;
   for (int i = env_id(); i < count; i += grid_size()) {
     int env = A.heavy_list[i];
-    run_env<JacoHeavy, false>(A, s, env, (A.env_mode == 1 || A.env_mode == 3) ? A.nsub : A.remaining[env], lane);
+    if (env < 0) continue;
+    run_env_tiers(A, u, env, lane);
+    wave_sync();
   }
 }

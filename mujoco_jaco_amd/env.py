@@ -100,6 +100,17 @@ class JacoBatchedEnv:
         self.sim._chk(self.L.jaco_reset(self.h, self._p(m) if m is not None else None, self._p(self._obs), self.sim._stream()))
         return self._out(self._obs)[0]
 
+    def markers(self):
+        """[num_envs, 2, 12] poses (position, rotation matrix) of the "hand" and "subgoal_reach" markers that step() moves
+        (the reference's set_mocap_xyz / set_mocap_orientation, env_mujoco_util.py:613-615,644-646)."""
+        t = torch.empty(self.num_envs, 2, 12, dtype=torch.float32, device=self.device)
+        self.sim._chk(self.L.jaco_get_markers(self.h, self._p(t), self.sim._stream()))
+        return t
+
+    def set_markers(self, t):
+        t = t.to(self.device, torch.float32).reshape(self.num_envs, 2, 12).contiguous()
+        self.sim._chk(self.L.jaco_set_markers(self.h, self._p(t), self.sim._stream()))
+
     def _placing_hold(self, mask=None, nsub=150):
         """The held part of the placing reset on its own (env_mujoco_util.py:106-117); reset() runs it for task 'placing'."""
         m = None if mask is None else mask.to(self.device).to(torch.uint8).contiguous()

@@ -266,6 +266,8 @@ def fuse(M, names, pairs):
     F["f_site_origbody"] = i32([M["site_bodyid"][s] for s in M["sensor_siteid"]])
 
     # ---- named frames the task logic reads (env_mujoco_util.py:35,107,310)
+    # mocap ids of the markers _take_action moves every env step (env_mujoco_util.py:613-615,644-646); -1 if absent
+    F["f_marker_mocap"] = i32([M["body_mocapid"][names["body"].index(nm)] if nm in names["body"] else -1 for nm in ("hand", "subgoal_reach")])
     for nm in ("EE", "EE_obj", "link1", "object_body", "object_dest"):
         if nm in names["body"]:
             b = names["body"].index(nm)

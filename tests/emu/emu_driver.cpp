@@ -1,5 +1,6 @@
 // TEST INFRASTRUCTURE: runs the unmodified kernel source under the lockstep wavefront emulator.
 // Built by tests/emu/Makefile into libjaco_emu.so; used by CPU-side (-m "not gpu") kernel checks.
+#include <algorithm>
 #include <functional>
 #include <string>
 #include <vector>
@@ -15,29 +16,43 @@ extern "C" int emu_lds_bytes_heavy() { return (int)sizeof(JacoLDS<JacoHeavy>); }
 
 static JacoModelDev g_model;
 static std::vector<float> g_hull;
+static int g_no_tier_return_fwd();
 static int emu_launch(JacoStepArgs A, int* heavy_envs) {
+  A.no_tier_return = g_no_tier_return_fwd();
   std::vector<int> remaining(A.nenv, 0), list(A.nenv, 0);
-  int count = 0;
-  A.remaining = remaining.data(); A.heavy_list = list.data(); A.heavy_count = &count;
+  std::fill(list.begin(), list.end(), -1);
+  int count = 0, taken = 0, light_left = A.nenv;
+  A.remaining = remaining.data(); A.heavy_list = list.data(); A.heavy_count = &count; A.heavy_taken = &taken; A.light_left = &light_left;
   emu_grid = A.nenv;
   for (int e = 0; e < A.nenv; e++) emu_run_wave(e, [&]() { jaco_physics_kernel(A); });
   emu_grid = 1;
+  // the worker form of the heavy tier (here after the light tier: every entry is already published), then the drain
   if (count > 0) emu_run_wave(0, [&]() { jaco_physics_kernel_heavy(A); });
+  if (count > 0) emu_run_wave(0, [&]() { jaco_physics_kernel_heavy_drain(A); });
   if (heavy_envs) *heavy_envs = count;
   return 0;
 }
 // env-level call: mode 1 = step (nsub = frame_skip), mode 2 = forward only
 extern "C" int emu_env_call(const void* blob, long blob_size, int nenv, int mode, int frame_skip, int task_id, int nact, unsigned long long seed,
                             float* qpos, float* qvel, float* qacc_ws, float* sensordata, unsigned* flags, int* stats, float* task, float* cache,
-                            const float* action, const float* noise, float* obs, float* reward, unsigned char* done, int* heavy_envs) {
+                            const float* action, const float* noise, float* obs, float* reward, unsigned char* done, float* marker, int* heavy_envs) {
   std::string err;
   if (jaco_model_from_blob(blob, (size_t)blob_size, &g_model, &g_hull, &err)) { fprintf(stderr, "emu: %s\n", err.c_str()); return -1; }
   JacoStepArgs A{};
   A.model = &g_model; A.hull = g_hull.data(); A.qpos = qpos; A.qvel = qvel; A.qacc_ws = qacc_ws; A.ctrl = qvel; A.sensordata = sensordata;
   A.flags = flags; A.stats = stats; A.nenv = nenv; A.nsub = mode == 2 ? 1 : frame_skip; A.env_mode = mode; A.task_id = task_id; A.nact = nact;
-  A.seed = seed; A.task = task; A.cache = cache; A.action = action; A.noise = noise; A.obs = obs; A.reward = reward; A.done = done; A.dbg_env = -1;
+  A.seed = seed; A.task = task; A.cache = cache; A.action = action; A.noise = noise; A.obs = obs; A.reward = reward; A.done = done; A.marker = marker; A.dbg_env = -1;
   return emu_launch(A, heavy_envs);
 }
+// rest pose of the two task-layer markers (what jaco_reset_state writes): 24 floats
+extern "C" int emu_marker_rest(const void* blob, long blob_size, float* out) {
+  std::string err;
+  if (jaco_model_from_blob(blob, (size_t)blob_size, &g_model, &g_hull, &err)) { fprintf(stderr, "emu: %s\n", err.c_str()); return -1; }
+  for (int k = 0; k < 24; k++) out[k] = g_model.marker_rest[k / 12][k % 12];
+  return 0;
+}
+static int g_no_tier_return = 0;
+extern "C" void emu_set_tier_return(int on) { g_no_tier_return = !on; }
 extern "C" int emu_task_floats() { return JTASK_N; }
 extern "C" int emu_cache_floats() { return JCACHE_N; }
 
@@ -50,13 +65,16 @@ extern "C" int emu_physics_step(const void* blob, long blob_size, int nenv, int 
   JacoStepArgs A{};
   A.model = &model; A.hull = hull.data(); A.qpos = qpos; A.qvel = qvel; A.qacc_ws = qacc_ws; A.ctrl = ctrl; A.sensordata = sensordata;
   A.flags = flags; A.stats = stats; A.nenv = nenv; A.nsub = nsub; A.disable_contact = disable_contact; A.dbg = dbg; A.dbg_env = dbg_env;
-  std::vector<int> remaining(nenv, 0), list(nenv, 0);
-  int count = 0;
-  A.remaining = remaining.data(); A.heavy_list = list.data(); A.heavy_count = &count;
+  std::vector<int> remaining(nenv, 0), list(nenv, -1);
+  int count = 0, taken = 0, light_left = nenv;
+  A.remaining = remaining.data(); A.heavy_list = list.data(); A.heavy_count = &count; A.heavy_taken = &taken; A.light_left = &light_left;
   emu_grid = nenv;
   for (int e = 0; e < nenv; e++) emu_run_wave(e, [&]() { jaco_physics_kernel(A); });
   emu_grid = 1;
   if (count > 0) emu_run_wave(0, [&]() { jaco_physics_kernel_heavy(A); });
+  if (count > 0) emu_run_wave(0, [&]() { jaco_physics_kernel_heavy_drain(A); });
   if (heavy_envs) *heavy_envs = count;
   return 0;
 }
+
+static int g_no_tier_return_fwd() { return g_no_tier_return; }

@@ -27,7 +27,8 @@ def lib():
         fp, ip, up = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint)
         L.emu_physics_step.argtypes = [ctypes.c_char_p, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int, fp, fp, fp, fp, fp, up, ip, fp, ctypes.c_int, ip]
         L.emu_env_call.argtypes = [ctypes.c_char_p, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_ulonglong,
-                                   fp, fp, fp, fp, up, ip, fp, fp, fp, fp, fp, fp, ctypes.POINTER(ctypes.c_ubyte), ip]
+                                   fp, fp, fp, fp, up, ip, fp, fp, fp, fp, fp, fp, ctypes.POINTER(ctypes.c_ubyte), fp, ip]
+        L.emu_marker_rest.argtypes = [ctypes.c_char_p, ctypes.c_long, fp]
         _lib = L
     return _lib
 
@@ -76,6 +77,9 @@ class EmuJacoEnv(EmuEnv):
         self.reward = np.zeros(nenv, np.float32)
         self.done = np.zeros(nenv, np.uint8)
         self.task[:, 0] = 0.6; self.task[:, 16] = 0.6
+        rest = np.zeros(24, np.float32)
+        assert self.L.emu_marker_rest(self.blob, len(self.blob), rest.ctypes.data_as(ctypes.POINTER(ctypes.c_float))) == 0
+        self.marker = np.tile(rest, (nenv, 1))   # ["hand", "subgoal_reach"] x (position, rotation): parked at the XML pose
 
     def _call(self, mode, action=None, noise=None):
         fp = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_float)) if a is not None else None
@@ -84,7 +88,7 @@ class EmuJacoEnv(EmuEnv):
                                  fp(self.qpos), fp(self.qvel), fp(self.qacc_ws), fp(self.sensordata),
                                  self.flags.ctypes.data_as(ctypes.POINTER(ctypes.c_uint)), self.stats.ctypes.data_as(ctypes.POINTER(ctypes.c_int)),
                                  fp(self.task), fp(self.cache), fp(action), fp(noise), fp(self.obs), fp(self.reward),
-                                 self.done.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)), ctypes.byref(hv))
+                                 self.done.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)), fp(self.marker), ctypes.byref(hv))
         assert rc == 0
         self.heavy_envs = hv.value
 

@@ -12,6 +12,13 @@ import glue  # noqa: E402
 from oracle_binding import Oracle  # noqa: E402
 
 
+def _mocap_id(names, body):
+    """mocap id = rank of the body among the mocap bodies, in body order (MuJoCo numbering); read from the compiled model."""
+    from mujoco_jaco_amd.modelc import blob
+    M = blob.load(os.path.join(ROOT, "mujoco_jaco_amd", "assets", "jaco2_curtain_torque.jacomdl"))
+    return int(M["body_mocapid"][names["body"].index(body)])
+
+
 class OracleEnv:
     def __init__(self, names, task="picking", frame_skip=50):
         self.o = Oracle()
@@ -20,6 +27,8 @@ class OracleEnv:
         self.obj = names["body"].index("object_body")
         self.ee_obj = names["body"].index("EE_obj") if "EE_obj" in names["body"] else -1
         self.base = np.array([0.0, 0.0, 0.157])
+        # mocap ids of the two markers _take_action moves (their contype-8 geoms collide with the EE axis sticks)
+        self.mk_hand, self.mk_sub = _mocap_id(names, "hand"), _mocap_id(names, "subgoal_reach")
         self.grip, self.steps, self.episodes = 0.6, 0, 0
         self.obj_goal, self.dest_goal = np.zeros(3), np.zeros(3)
 
@@ -43,8 +52,15 @@ class OracleEnv:
     def step(self, action, noise12):
         o = self.o
         pe, qe = self._ee()
+        # set_mocap_*("subgoal_reach", rule-based sub-goal), then the new target, then set_mocap_*("hand", target)
+        obj_y = o.get("xpos").reshape(-1, 3)[self.obj][1]
+        spos, sori = glue.rulebased_subgoal(self.task, pe, self.obj_goal, obj_y, self.dest_goal, np.asarray(noise12[:6], np.float64))
         target, grip, ramp = glue.take_action(pe, qe, action, self.grip, self.frame_skip)
         self.grip = grip
+        mp, mq = o.get("mocap_pos").reshape(-1, 3).copy(), o.get("mocap_quat").reshape(-1, 4).copy()
+        mp[self.mk_sub], mq[self.mk_sub] = spos, glue.quat_from_euler(*sori)
+        mp[self.mk_hand], mq[self.mk_hand] = target[:3], glue.quat_from_euler(*target[3:6])
+        o.set("mocap_pos", mp.reshape(-1)); o.set("mocap_quat", mq.reshape(-1))
         for k in range(self.frame_skip):
             q_dq = o.get("qvel")[:6]
             jp, jr = o.jac_body_com(self.ee)                       # stale: last forward pass

@@ -110,3 +110,30 @@ def test_placing_hold_matches_oracle(names, model_arrays):
     assert np.abs(e.qpos[0, :9] - oq[:9]).max() < 2e-4                         # arm + fingers after the hold
     assert e.qpos[0, 6:9].max() < q[6:9].min() - 0.003                         # the finger servos moved towards the 0.6 command
     assert e.task[0, 17] == 0 and e.task[0, 19] == 0                           # substep counter / pending flag cleared
+
+
+def test_tier_alternation(names, model_arrays):
+    """An env whose first substeps overflow the light capacities (hand spawned inside the pedestal at reset): light code ->
+    heavy code for the burst -> back to the light code for the rest of the step (flag 128), all inside one env step.
+    The result must not depend on where the env was stepped: same observation as with the hand-back disabled (env stays
+    on the heavy code), and both close to the fp64 oracle env, which knows no tiers (loose bound: the separation of
+    the interpenetrating bodies is violent and amplifies rounding differences)."""
+    from emu_binding import lib
+    seed = 108
+    rng = np.random.default_rng(seed)
+    a = rng.uniform(-1, 1, 7).astype(np.float32); a[:3] = np.sign(a[:3]) * np.maximum(np.abs(a[:3]), 0.5)
+    nz = np.full((1, 12), 0.5, np.float32)
+    out = {}
+    try:
+        for tier_return in (1, 0):
+            lib().emu_set_tier_return(tier_return)
+            e, oe = _pair(names, model_arrays, seed, 30)
+            e.forward(nz)
+            obs, rew, done = e.env_step(a, nz)
+            out[tier_return] = (obs[0].copy(), int(e.flags[0]), bool(done[0]))
+    finally:
+        lib().emu_set_tier_return(1)
+    assert out[1][1] & 32 and out[1][1] & 128 and not out[0][1] & 128
+    assert np.abs(out[1][0] - out[0][0]).max() < 1e-5
+    oo, orew, odone, _ = oe.step(a.astype(np.float64), nz[0].astype(np.float64))
+    assert out[1][2] == odone and out[1][0][0] == oo[0] and np.abs(out[1][0] - oo).max() < 3e-3

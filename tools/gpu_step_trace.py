@@ -11,16 +11,21 @@ genv = JacoBatchedEnv(num_envs=B, device=0, frame_skip=50, seed=1000, task="pick
 env = genv.sim
 dev = torch.device("cuda:0")
 if "--no-schedule" in sys.argv: env.set_option("schedule", 0)
+for opt in ("heavy_workers", "tier_return", "concurrent_heavy"):
+    if "--" + opt in sys.argv: env.set_option(opt, float(sys.argv[sys.argv.index("--" + opt) + 1]))
 genv.reset()
 gen = torch.Generator(device=dev); gen.manual_seed(2000)
 actions = [torch.rand(B, 7, device=dev, generator=gen) * 2 - 1 for _ in range(4)]
+tot = 0.0
 for i in range(n):
     env.clear_flags()
     torch.cuda.synchronize(); t = time.perf_counter()
     o, r, d, _ = genv.step(actions[i % 4])
     torch.cuda.synchronize(); dt = time.perf_counter() - t
+    if i >= 4: tot += dt
     st = env.stats().float()
     fl = env.flags()
     print("step %2d  %.2f ms  done %.4f  ncon mean %.2f max %d  nefc mean %.1f  iters mean %.3f  cand mean %.2f  heavy %.4f  singular %.4f" % (
         i, dt * 1e3, d.float().mean().item(), st[:, 0].mean().item(), int(st[:, 0].max().item()), st[:, 1].mean().item(), st[:, 2].mean().item(),
         (st[:, 3].long() & 0xffff).float().mean().item(), ((fl & 32) != 0).float().mean().item(), ((fl & 64) != 0).float().mean().item()))
+print("mean ms/step over steps 4..%d: %.2f" % (n - 1, tot / max(1, n - 4) * 1e3))

@@ -11,10 +11,11 @@ for f in glob.glob("$OUT/*/*kernel_trace.csv"):
     for r in csv.DictReader(open(f)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
-step = -1
+step, t0 = -1, 0
 for s, e, k in rows:
-    short = "order" if "order" in k else "heavy" if "heavy" in k else "light" if "jaco_physics_kernel" in k else None
+    short = "prepare" if "prepare" in k else "order" if "order" in k else "drain" if "drain" in k else "workers" if "heavy" in k else "light" if "jaco_physics_kernel" in k else None
     if short is None: continue
-    if short == "order": step += 1
-    print("launch %3d %-6s %8.3f ms" % (step, short, (e - s) * 1e-6))
+    if short == "prepare": step += 1; t0 = s
+    if short in ("prepare", "order"): continue
+    print("launch %3d %-8s start %8.3f ms  end %8.3f ms" % (step, short, (s - t0) * 1e-6, (e - t0) * 1e-6))
 PY
