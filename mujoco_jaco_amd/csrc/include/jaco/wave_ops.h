@@ -88,11 +88,25 @@ JDEV int wave_argmax(float v, int idx, float* best) {
 JDEV unsigned long long wave_clock() { return __builtin_amdgcn_s_memtime(); }   // free-running shader clock
 JDEV int grid_size() { return (int)gridDim.x; }
 JDEV int jaco_atomic_inc(int* p) { return atomicAdd(p, 1); }
-JDEV int jaco_atomic_dec(int* p) { return __hip_atomic_fetch_sub(p, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+// (release = this workgroup's earlier publications are visible to whoever reads the new count; costs an L2 write-back on
+// multi-XCD parts, so workgroups with nothing to publish use the relaxed form)
+JDEV int jaco_atomic_dec(int* p, bool release) {
+  return release ? __hip_atomic_fetch_sub(p, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) : __hip_atomic_fetch_sub(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 // device-scope publish / observe for the light -> heavy work list (the two tiers run concurrently in different workgroups)
+// Write-through stores (visible device-wide once acknowledged, no L2 write-back needed afterwards): used for the state of
+// an env that is handed to another workgroup.  dev_stores_done(): this lane's earlier stores have been acknowledged.
+JDEV void st_wt(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+JDEV void st_wt_i(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+JDEV void st_wt_u(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+JDEV void or_wt(unsigned* p, unsigned v) { atomicOr(p, v); }
+JDEV void dev_stores_done() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
 JDEV void dev_fence() { __threadfence(); }
 JDEV void dev_store_release(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
-JDEV int dev_load_acquire(const int* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); }
+// polling: coherent relaxed load (no cache invalidation -- an acquire per poll would keep flushing the XCD's L2 under the
+// light tier); one acquire fence once the awaited value has been seen
+JDEV int dev_load_relaxed(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+JDEV void dev_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
 JDEV void wave_sleep() { __builtin_amdgcn_s_sleep(127); }   // ~8k cycles
 
 // Pin three already-loaded values in VGPRs here: keeps the optimiser from sinking their loads into a (divergent) branch.

@@ -467,22 +467,30 @@ JDEV void stage_walk(const JacoModelDev* m, L& s, int lane) {
 
 // ---------------------------------------------------------------- stage G: geom poses, body inertias, RNE body forces
 template <class L>
-JDEV void stage_geoms_inertia(const JacoModelDev* m, L& s, int lane, const float* mk) {
-  if (lane < m->ngeom) {
-    int b = m->g_body[lane];
+JDEV void stage_static_geoms(const JacoModelDev* m, L& s, int lane, const float* mk) {
+  // world poses of the geoms that do not move during a launch: static geoms and the geoms on the two task-layer markers
+  // (set_mocap_xyz / set_mocap_orientation happen between env steps).  Written once, before the substep loop.
+  if (lane < m->ngeom && m->g_body[lane] < 0) {
     const int km = mk ? m->g_marker[lane] : -1;
-    if (km >= 0) {   // geom on a marker the task layer moved (set_mocap_xyz / set_mocap_orientation): static, per-env pose
+    if (km >= 0) {
       const float* P = mk + 12 * km;
       m3 R = ldm(P + 3);
       st3(s.gpos[lane], ld3(P) + mul(R, ld3(m->g_lpos[lane])));
       stm(s.gmat[lane], mul(R, ldm(m->g_lmat[lane])));
-    } else if (b >= 0) {
-      m3 R = ldm(s.xmat[b]);
-      st3(s.gpos[lane], ld3(s.xpos[b]) + mul(R, ld3(m->g_pos[lane])));
-      stm(s.gmat[lane], mul(R, ldm(m->g_mat[lane])));
     } else {
       st3(s.gpos[lane], ld3(m->g_pos[lane]));
       stm(s.gmat[lane], ldm(m->g_mat[lane]));
+    }
+  }
+}
+template <class L>
+JDEV void stage_geoms_inertia(const JacoModelDev* m, L& s, int lane) {
+  if (lane < m->ngeom) {
+    int b = m->g_body[lane];
+    if (b >= 0) {
+      m3 R = ldm(s.xmat[b]);
+      st3(s.gpos[lane], ld3(s.xpos[b]) + mul(R, ld3(m->g_pos[lane])));
+      stm(s.gmat[lane], mul(R, ldm(m->g_mat[lane])));
     }
   }
   if (lane < m->nbody) {
@@ -957,6 +965,8 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
     osc_target_quat(s, lane);
     wave_sync();
   }
+  stage_static_geoms(m, s, lane, A.marker ? A.marker + (size_t)env * 24 : nullptr);
+  wave_sync();
   JProfCtx pc;
   pc.row = nullptr;
   pc.tprev = 0;
@@ -992,7 +1002,7 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
     for (int i = lane; i < JNV * JNV; i += 64) s.M[i] = 0.f;
     wave_sync();
     JSTAMP(0);
-    stage_geoms_inertia(m, s, lane, A.marker ? A.marker + (size_t)env * 24 : nullptr);
+    stage_geoms_inertia(m, s, lane);
     wave_sync();
     JSTAMP(1);
     stage_accumulate(m, s, lane);
@@ -1109,8 +1119,13 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
     }
   }
   if (emode != 2) {
-    if (lane < nq) A.qpos[(size_t)env * nq + lane] = s.qpos[lane];
-    if (lane < nv) { A.qvel[(size_t)env * nv + lane] = s.qvel[lane]; A.qacc_ws[(size_t)env * nv + lane] = s.qacc_ws[lane]; }
+    if (LIGHT && left > 0) {   // handed over to a heavy-tier workgroup (possibly on another XCD): write-through stores
+      if (lane < nq) st_wt(&A.qpos[(size_t)env * nq + lane], s.qpos[lane]);
+      if (lane < nv) { st_wt(&A.qvel[(size_t)env * nv + lane], s.qvel[lane]); st_wt(&A.qacc_ws[(size_t)env * nv + lane], s.qacc_ws[lane]); }
+    } else {
+      if (lane < nq) A.qpos[(size_t)env * nq + lane] = s.qpos[lane];
+      if (lane < nv) { A.qvel[(size_t)env * nv + lane] = s.qvel[lane]; A.qacc_ws[(size_t)env * nv + lane] = s.qacc_ws[lane]; }
+    }
   }
   if (left == 0 && lane < ns && A.sensordata) A.sensordata[(size_t)env * ns + lane] = sens;
   if (emode) {
@@ -1174,13 +1189,13 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
     }
     if (left == 0 && emode == 3 && lane == 0) { s.task[JT_SUB] = 0.f; s.task[JT_PENDING] = 0.f; }
     wave_sync();
-    if (lane < JTASK_N) A.task[(size_t)env * JTASK_N + lane] = s.task[lane];
+    if (lane < JTASK_N) { if (LIGHT && left > 0) st_wt(&A.task[(size_t)env * JTASK_N + lane], s.task[lane]); else A.task[(size_t)env * JTASK_N + lane] = s.task[lane]; }
   }
   unsigned long long anyf = wave_ballot(flags != 0);
   if (anyf) {
     unsigned f = flags;
     for (int o = 1; o < 64; o <<= 1) f |= (unsigned)wave_shfl_i((int)f, lane ^ o);
-    if (lane == 0 && A.flags) A.flags[env] |= f;
+    if (lane == 0 && A.flags) { if (LIGHT && left > 0) or_wt(&A.flags[env], f); else A.flags[env] |= f; }
   }
   if (left == 0 && lane == 0 && A.stats) {
     A.stats[4 * env] = s.ncon; A.stats[4 * env + 1] = s.nefc; A.stats[4 * env + 2] = iters; A.stats[4 * env + 3] = s.ncand | (nls_last << 16);
@@ -1197,19 +1212,20 @@ __global__ __launch_bounds__(64, 2) void jaco_physics_kernel(JacoStepArgs A) {
   const int env = A.order ? A.order[env_id()] : env_id();
   const unsigned long long t_start = wave_clock();
   int left = run_env<JacoLight, true>(A, s, env, A.nsub, lane);
-  if (lane == 0 && A.cost) A.cost[env] = (unsigned)((wave_clock() - t_start) >> 4);
-  // hand-off: the env's state is in global memory (run_env wrote it); publish it device-wide, then append the env to
-  // the heavy tier's work list.  Heavy-tier workgroups run concurrently (jaco_env.hip) and poll the list.
+  if (lane == 0 && A.cost) { unsigned c = (unsigned)((wave_clock() - t_start) >> 4); if (left > 0) st_wt_u(&A.cost[env], c); else A.cost[env] = c; }
+  // hand-off: the env's state went to memory with write-through stores (run_env); once they are acknowledged the env
+  // is appended to the heavy tier's work list.  Heavy-tier workgroups run concurrently (jaco_env.hip) and poll the list.
   if (left > 0) {
-    dev_fence();
+    if (lane == 0) st_wt_i(&A.remaining[env], left);
+    dev_stores_done();
     wave_sync();
     if (lane == 0) {
-      A.remaining[env] = left;
       int slot = jaco_atomic_inc(A.heavy_count);
-      dev_store_release(&A.heavy_list[slot], env);
+      st_wt_i(&A.heavy_list[slot], env);
+      dev_stores_done();   // (the entry is out before the count of running light workgroups drops)
     }
   }
-  if (lane == 0 && A.light_left) jaco_atomic_dec(A.light_left);
+  if (lane == 0 && A.light_left) jaco_atomic_dec(A.light_left, false);
 }
 // One handed-over env on a heavy-tier workgroup: the heavy code runs while the overflow lasts, the light code in between
 // (a heavy wave has its SIMD to itself, so both run at solo speed), until the env's step is complete.
@@ -1243,15 +1259,19 @@ __global__ __launch_bounds__(64) void jaco_physics_kernel_heavy(JacoStepArgs A) 
     if (i >= A.nenv) return;
     int env = -1, last_left = -1, idle = 0;
     for (;;) {
-      env = wave_uniform_i(dev_load_acquire(&A.heavy_list[i]));
+      env = wave_uniform_i(dev_load_relaxed(&A.heavy_list[i]));
       if (env >= 0) break;
-      const int ll = wave_uniform_i(dev_load_acquire(A.light_left));
-      if (ll <= 0 && i >= wave_uniform_i(dev_load_acquire(A.heavy_count))) return;   // nothing more will be published
+      const int ll = wave_uniform_i(dev_load_relaxed(A.light_left));
+      if (ll <= 0) {   // the light tier is done: one last, ordered look (every publication happened before the final decrement)
+        dev_acquire();
+        if (i >= wave_uniform_i(dev_load_relaxed(A.heavy_count))) return;   // nothing more will be published
+      }
       idle = ll == last_left ? idle + 1 : 0;
       last_left = ll;
       if (idle > JACO_WORKER_PATIENCE) return;   // (a slot claimed here and filled later is served by the drain launch)
       wave_sleep();
     }
+    dev_acquire();   // the env's state, written by the light workgroup before it published the entry
     if (lane == 0) A.heavy_list[i] = -2;   // taken
     run_env_tiers(A, u, env, lane);
     wave_sync();

@@ -20,9 +20,15 @@ JDEV int emu_post_i(int v) { int p = emu_cnt[emu_cur_lane]++ & 1; emu_x[p][emu_c
 
 JDEV float wave_bcast(float v, int src) { int p = emu_post_f(v); emu_collective(); return emu_x[p][src].f; }
 JDEV int wave_bcast_i(int v, int src) { int p = emu_post_i(v); emu_collective(); return emu_x[p][src].i; }
+JDEV void st_wt(float* p, float v) { *p = v; }
+JDEV void st_wt_i(int* p, int v) { *p = v; }
+JDEV void st_wt_u(unsigned* p, unsigned v) { *p = v; }
+JDEV void or_wt(unsigned* p, unsigned v) { *p |= v; }
+JDEV void dev_stores_done() {}
 JDEV void dev_fence() {}
 JDEV void dev_store_release(int* p, int v) { *p = v; }
-JDEV int dev_load_acquire(const int* p) { return *p; }
+JDEV int dev_load_relaxed(const int* p) { return *p; }
+JDEV void dev_acquire() {}
 JDEV void wave_sleep() {}
 JDEV unsigned long long wave_clock() { return 0ull; }
 JDEV int wave_uniform_i(int v) { return wave_bcast_i(v, 0); }
@@ -86,7 +92,7 @@ JDEV int wave_argmax(float v, int idx, float* best) {
 extern int emu_grid;
 JDEV int grid_size() { return emu_grid; }
 JDEV int jaco_atomic_inc(int* p) { return (*p)++; }
-JDEV int jaco_atomic_dec(int* p) { return (*p)--; }
+JDEV int jaco_atomic_dec(int* p, bool) { return (*p)--; }
 
 template <class T>
 JDEV const T* opaque_ptr(const T* p) {
