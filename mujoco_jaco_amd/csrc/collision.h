@@ -635,6 +635,12 @@ JDEV bool ray_hits_site(int type, float sx, float sy, float sz, v3 p, v3 d) {
 template <class L>
 JDEV void stage_touch(const JacoModelDev* m, L& s, int lane, float* sens) {
   int ncon = wave_uniform_i(s.ncon);
+  {   // no contact on a body that carries a touch site (the common case: only object/pedestal/floor contacts): all zero
+    const unsigned long long sb = ((unsigned long long)m->sens_bodymask[1] << 32) | m->sens_bodymask[0];
+    bool mine = false;
+    if (lane < ncon) { int obs = s.c_ob[lane]; mine = (((sb >> (obs & 0xFF)) | (sb >> ((obs >> 16) & 0xFF))) & 1ull) != 0ull; }
+    if (!wave_ballot(mine)) { *sens = 0.f; return; }
+  }
   if (lane < ncon) {
     int cd = s.c_dim[lane];
     int nrow = cd == 1 ? 1 : 2 * (cd - 1), r0 = s.c_efc[lane];

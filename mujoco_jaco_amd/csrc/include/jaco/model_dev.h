@@ -69,6 +69,7 @@ struct JacoModelDev {
   // touch sites, one per sensor, in sensordata order
   int s_body[JNSENS], s_type[JNSENS], s_origbody[JNSENS];
   float s_pos[JNSENS][3], s_mat[JNSENS][9], s_size[JNSENS][3];
+  unsigned sens_bodymask[2];   // bit b (of 64): original body b carries a touch site (contacts elsewhere cannot reach a sensor)
 
   // named frames the task layer reads: body id + local pos + local rotation
   int ee_body, eeobj_body;
