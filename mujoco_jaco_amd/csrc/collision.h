@@ -245,7 +245,7 @@ JDEV void collide_box_box(const JacoModelDev* m, L& s, int g1, int g2, int pair,
 // ---------------------------------------------------------------- MPR (all lanes run the same serial control flow)
 struct Sup { v3 v, v1, v2; };
 // Everything a support query needs about one geom, fetched once per candidate pair.
-struct MprGeom { GeomPose P; v3 size; int type, adr, nvert; };
+struct MprGeom { GeomPose P; v3 size; int type, adr, nvert, cellR, celladr; };
 template <class L>
 JDEV MprGeom mpr_geom(const JacoModelDev* m, const L& s, int g, int type) {
   MprGeom G;
@@ -254,7 +254,22 @@ JDEV MprGeom mpr_geom(const JacoModelDev* m, const L& s, int g, int type) {
   G.type = type;
   G.adr = type == JG_MESH ? m->g_vertadr[g] : 0;
   G.nvert = type == JG_MESH ? m->g_vertnum[g] : 0;
+  G.cellR = type == JG_MESH ? m->g_cellR[g] : 0;
+  G.celladr = type == JG_MESH ? m->g_celladr[g] : 0;
   return G;
+}
+// Cube-map cell of a (wave-uniform) direction; same rule as modelc/supportmap.py:cube_cell.
+JDEV int cube_cell(v3 d, int R) {
+  float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+  const bool fx = ax >= ay && ax >= az, fy = !fx && ay >= az;
+  int face = fx ? (d.x > 0.f ? 0 : 1) : (fy ? (d.y > 0.f ? 2 : 3) : (d.z > 0.f ? 4 : 5));
+  float mx = fx ? ax : (fy ? ay : az);
+  mx = mx < 1e-30f ? 1.f : mx;
+  float u = (fx ? d.y : d.x) / mx, v = ((fx || fy) ? d.z : d.y) / mx;
+  int iu = (int)floorf((u + 1.f) * 0.5f * (float)R), iv = (int)floorf((v + 1.f) * 0.5f * (float)R);
+  iu = iu < 0 ? 0 : (iu > R - 1 ? R - 1 : iu);
+  iv = iv < 0 ? 0 : (iv > R - 1 ? R - 1 : iv);
+  return (face * R + iu) * R + iv;
 }
 JDEV v3 support_prim(const MprGeom& G, v3 l) {   // box / sphere, local frame
   if (G.type == JG_BOX) return mk3(l.x > 0.f ? G.size.x : -G.size.x, l.y > 0.f ? G.size.y : -G.size.y, l.z > 0.f ? G.size.z : -G.size.z);
@@ -267,17 +282,30 @@ JDEV v3 support_prim(const MprGeom& G, v3 l) {   // box / sphere, local frame
 // memory.  Lowest vertex index wins ties (a serial first-max scan), as in support_geom.
 JDEV Sup mpr_support(const JacoStepArgs& A, const MprGeom& G1, const MprGeom& G2, v3 dir, int lane) {
   const v3 l1 = mulT(G1.P.R, dir), l2 = mulT(G2.P.R, -dir);
-  const int n1 = G1.nvert, n2 = G2.nvert, nmax = n1 > n2 ? n1 : n2;
+  // hulls with a support table (modelc/supportmap.py): the cell of the direction lists every vertex that can be the
+  // maximiser, one slot per lane -> one 16-byte load instead of a scan; the others are scanned (both hulls in one loop)
+  const bool tab1 = G1.cellR > 0, tab2 = G2.cellR > 0;
+  const int n1 = G1.nvert, n2 = G2.nvert, s1 = tab1 ? 0 : n1, s2 = tab2 ? 0 : n2, nmax = s1 > s2 ? s1 : s2;
   float best1 = -3.0e38f, best2 = -3.0e38f;
   int bi1 = 0x7fffffff, bi2 = 0x7fffffff;
   v3 c1 = mk3(0.f, 0.f, 0.f), c2 = mk3(0.f, 0.f, 0.f);
+  if (tab1) {
+    const v4 e = ld4(A.hull + 4 * ((size_t)G1.celladr + (size_t)cube_cell(l1, G1.cellR) * 64 + lane));
+    const int id = __builtin_bit_cast(int, e.w);
+    if (id >= 0) { best1 = e.x * l1.x + e.y * l1.y + e.z * l1.z; bi1 = id; c1 = mk3(e.x, e.y, e.z); }
+  }
+  if (tab2) {
+    const v4 e = ld4(A.hull + 4 * ((size_t)G2.celladr + (size_t)cube_cell(l2, G2.cellR) * 64 + lane));
+    const int id = __builtin_bit_cast(int, e.w);
+    if (id >= 0) { best2 = e.x * l2.x + e.y * l2.y + e.z * l2.z; bi2 = id; c2 = mk3(e.x, e.y, e.z); }
+  }
   for (int i = lane; i < nmax; i += 64) {
-    if (i < n1) {
+    if (i < s1) {
       const v4 v = ld4(A.hull + 4 * (size_t)(G1.adr + i));
       float t = v.x * l1.x + v.y * l1.y + v.z * l1.z;
       if (t > best1) { best1 = t; bi1 = i; c1 = mk3(v.x, v.y, v.z); }
     }
-    if (i < n2) {
+    if (i < s2) {
       const v4 v = ld4(A.hull + 4 * (size_t)(G2.adr + i));
       float t = v.x * l2.x + v.y * l2.y + v.z * l2.z;
       if (t > best2) { best2 = t; bi2 = i; c2 = mk3(v.x, v.y, v.z); }
@@ -286,12 +314,14 @@ JDEV Sup mpr_support(const JacoStepArgs& A, const MprGeom& G1, const MprGeom& G2
   v3 sp1, sp2;
   if (n1 > 0) {
     float bv;
-    const int wl = wave_argmax(best1, bi1, &bv) & 63;   // vertex i was scanned by lane i % 64
+    const int win = wave_argmax(best1, bi1, &bv);
+    const int wl = ffs64(wave_ballot(bi1 == win));   // the lane that holds the winning vertex
     sp1 = mk3(wave_bcast(c1.x, wl), wave_bcast(c1.y, wl), wave_bcast(c1.z, wl));
   } else sp1 = support_prim(G1, l1);
   if (n2 > 0) {
     float bv;
-    const int wl = wave_argmax(best2, bi2, &bv) & 63;
+    const int win = wave_argmax(best2, bi2, &bv);
+    const int wl = ffs64(wave_ballot(bi2 == win));
     sp2 = mk3(wave_bcast(c2.x, wl), wave_bcast(c2.y, wl), wave_bcast(c2.z, wl));
   } else sp2 = support_prim(G2, l2);
   Sup r;
@@ -475,6 +505,9 @@ JDEV void stage_collision(const JacoStepArgs& A, const JacoModelDev* m, L& s, in
       float depth;
       v3 dir, pos;
       bool hit = mpr_penetration(A, m, s, g1, t1, g2, t2, lane, &depth, &dir, &pos);
+#ifdef JACO_TRACE_MPR
+      if (lane == 0) printf("mpr g1 %d g2 %d hit %d depth %g\n", g1, g2, (int)hit, hit ? depth : 0.f);
+#endif
       push_contacts(s, hit && lane == 0, -depth, pos, dir, pk, ncon, flags, 1);
     }
     if (ncon > before) {   // dof chain masks of the two bodies, cached for the row builder

@@ -55,6 +55,7 @@ struct JacoModelDev {
 
   // collidable geoms; body -1 = static (g_pos/g_mat are then world poses)
   int g_body[JMAXGEOM], g_type[JMAXGEOM], g_vertadr[JMAXGEOM], g_vertnum[JMAXGEOM], g_origbody[JMAXGEOM], g_mocap[JMAXGEOM];
+  int g_cellR[JMAXGEOM], g_celladr[JMAXGEOM];   // hull support table: cube-map resolution (0 = none) and first entry (float4 units)
   float g_pos[JMAXGEOM][3], g_mat[JMAXGEOM][9], g_size[JMAXGEOM][3], g_rbound[JMAXGEOM], g_invweight[JMAXGEOM][2];
 
   // geoms riding on the two markers the task layer moves every env step ("hand" = 0, "subgoal_reach" = 1): g_marker is the

@@ -243,6 +243,37 @@ int jaco_model_from_blob(const void* buf, size_t size, JacoModelDev* m, std::vec
   m->nhullvert = nvert;
   hull->assign((size_t)4 * nvert, 0.f);
   for (int i = 0; i < nvert; i++) for (int k = 0; k < 3; k++) (*hull)[4 * i + k] = (float)mv[3 * i + k];
+  // ---- direction-indexed support tables (modelc/supportmap.py), appended to the vertex buffer: per cube-map cell 64 slots
+  // of (x, y, z, vertex index as raw bits; -1 = empty).  g_celladr is in float4 units from the start of the buffer.
+  for (int g = 0; g < ng; g++) { m->g_cellR[g] = 0; m->g_celladr[g] = 0; }
+  if (B.has("f_hullmap_cnt") && B.has("f_geom_cellR")) {
+    const int32_t *cr = B.i32("f_geom_cellR", ng), *c0 = B.i32("f_geom_cell0", ng), *cnt = B.i32("f_hullmap_cnt"), *ids = B.i32("f_hullmap_ids");
+    if (!cr || !c0 || !cnt || !ids) FAIL(B.err);
+    const int ncell = B.count("f_hullmap_cnt"), nid = B.count("f_hullmap_ids");
+    std::vector<int> start(ncell + 1, 0);
+    for (int c = 0; c < ncell; c++) { if (cnt[c] < 0 || cnt[c] > 64) FAIL("support table: bad cell count"); start[c + 1] = start[c] + cnt[c]; }
+    if (start[ncell] > nid) FAIL("support table: index list too short");
+    const size_t base = hull->size() / 4;   // first table entry, in float4 units
+    bool any = false;
+    for (int g = 0; g < ng; g++) any = any || cr[g] > 0;
+    if (any) {
+      hull->resize(4 * (base + (size_t)ncell * 64), 0.f);
+      for (int g = 0; g < ng; g++) {
+        if (cr[g] <= 0) continue;
+        const int cells = 6 * cr[g] * cr[g];
+        if (c0[g] < 0 || c0[g] + cells > ncell) FAIL("support table: cell range outside the table");
+        m->g_cellR[g] = cr[g]; m->g_celladr[g] = (int)(base + (size_t)c0[g] * 64);
+        for (int c = c0[g]; c < c0[g] + cells; c++)
+          for (int j = 0; j < 64; j++) {
+            float* e = hull->data() + 4 * (base + (size_t)c * 64 + j);
+            int32_t id = j < cnt[c] ? ids[start[c] + j] : -1;
+            if (id >= m->g_vertnum[g]) FAIL("support table: vertex index outside the hull");
+            if (id >= 0) for (int k = 0; k < 3; k++) e[k] = (*hull)[4 * (size_t)(m->g_vertadr[g] + id) + k];
+            memcpy(e + 3, &id, 4);
+          }
+      }
+    }
+  }
   if (!B.err.empty()) FAIL(B.err);
 #undef FAIL
   return 0;

@@ -16,7 +16,7 @@ import sys
 
 import numpy as np
 
-from . import blob, kin, mjcf, rot
+from . import supportmap, blob, kin, mjcf, rot
 
 REF_ASSETS = "/root/reference/env_script/assets/jaco2"
 OUT_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "assets")
@@ -233,6 +233,25 @@ def fuse(M, names, pairs):
     F["f_geom_rbound"] = f64([M["geom_rbound"][g] for g in used])
     F["f_geom_vertadr"] = i32([M["mesh_vertadr"][M["geom_dataid"][g]] if M["geom_dataid"][g] >= 0 else 0 for g in used])
     F["f_geom_vertnum"] = i32([M["mesh_vertnum"][M["geom_dataid"][g]] if M["geom_dataid"][g] >= 0 else 0 for g in used])
+    # direction-indexed support tables of the hulls (supportmap.py), CSR over the cube-map cells of every mesh; the loader
+    # expands them to 64 padded (x, y, z, index) slots per cell.  f_geom_cellR = 0: no table, the kernels scan the hull.
+    used_mesh = sorted({int(M["geom_dataid"][g]) for g in used if M["geom_dataid"][g] >= 0})
+    mesh_R, mesh_cell0, cnts, ids = {}, {}, [], []
+    mv = M["mesh_vert"].reshape(-1, 3)
+    for k in used_mesh:
+        Vk = mv[M["mesh_vertadr"][k]:M["mesh_vertadr"][k] + M["mesh_vertnum"][k]]
+        R, table = supportmap.build(Vk)
+        mesh_R[k], mesh_cell0[k] = R, len(cnts)
+        if R:
+            nbad, _ = supportmap.verify(Vk, R, table)
+            assert nbad == 0, "support table of mesh %d disagrees with the full scan" % k
+            tid = table[:, 3].copy().view(np.int32).reshape(-1, supportmap.SLOTS)
+            for row in tid:
+                row = row[row >= 0]
+                cnts.append(len(row)); ids.extend(row.tolist())
+    F["f_hullmap_cnt"], F["f_hullmap_ids"] = i32(cnts if cnts else [0]), i32(ids if ids else [0])
+    F["f_geom_cellR"] = i32([mesh_R[int(M["geom_dataid"][g])] if M["geom_dataid"][g] >= 0 else 0 for g in used])
+    F["f_geom_cell0"] = i32([mesh_cell0[int(M["geom_dataid"][g])] if M["geom_dataid"][g] >= 0 else 0 for g in used])
     F["f_geom_invweight"] = f64([biw[M["geom_bodyid"][g]] for g in used])
 
     # ---- pair table with pre-mixed parameters
