@@ -314,14 +314,16 @@ JDEV Sup mpr_support(const JacoStepArgs& A, const MprGeom& G1, const MprGeom& G2
   v3 sp1, sp2;
   if (n1 > 0) {
     float bv;
-    const int win = wave_argmax(best1, bi1, &bv);
-    const int wl = ffs64(wave_ballot(bi1 == win));   // the lane that holds the winning vertex
+    int wl;
+    if (tab1) { bv = wave_max(best1); wl = ffs64(wave_ballot(best1 == bv && bi1 != 0x7fffffff)); }   // slots are in index order: lowest lane = lowest index
+    else { const int win = wave_argmax(best1, bi1, &bv); wl = ffs64(wave_ballot(bi1 == win)); }      // the lane that holds the winning vertex
     sp1 = mk3(wave_bcast(c1.x, wl), wave_bcast(c1.y, wl), wave_bcast(c1.z, wl));
   } else sp1 = support_prim(G1, l1);
   if (n2 > 0) {
     float bv;
-    const int win = wave_argmax(best2, bi2, &bv);
-    const int wl = ffs64(wave_ballot(bi2 == win));
+    int wl;
+    if (tab2) { bv = wave_max(best2); wl = ffs64(wave_ballot(best2 == bv && bi2 != 0x7fffffff)); }
+    else { const int win = wave_argmax(best2, bi2, &bv); wl = ffs64(wave_ballot(bi2 == win)); }
     sp2 = mk3(wave_bcast(c2.x, wl), wave_bcast(c2.y, wl), wave_bcast(c2.z, wl));
   } else sp2 = support_prim(G2, l2);
   Sup r;
