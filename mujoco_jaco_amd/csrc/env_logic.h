@@ -211,6 +211,25 @@ JDEV float gj_inverse6(float (&A)[6], float (&B)[6], int lane) {
   return det;
 }
 
+// Same elimination with a single right-hand side: returns det, b becomes (A^-1 b)[lane].
+JDEV float gj_solve6(float (&A)[6], float& b, int lane) {
+  float det = 1.f;
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    float piv = wave_bcast(A[k], k);
+    det *= piv;
+    float inv = 1.f / piv, sc = lane == k ? inv : 1.f;
+#pragma unroll
+    for (int j = 0; j < 6; j++) A[j] *= sc;
+    b *= sc;
+    float f = lane == k ? 0.f : A[k];
+#pragma unroll
+    for (int j = 0; j < 6; j++) A[j] -= f * wave_bcast(A[j], k);
+    b -= f * wave_bcast(b, k);
+  }
+  return det;
+}
+
 // Pseudo-inverse of a symmetric PSD 6x6 matrix X (LDS, destroyed) with abr_control's rule "singular values < 0.005 are
 // dropped" (np.linalg.svd branch of OSC.generate): Jacobi eigen-decomposition, V accumulated in LDS, result in `out`.
 // Parallel (round-robin) ordering: each of the 5 rounds of a sweep applies 3 rotations on disjoint index pairs at once,
@@ -276,7 +295,6 @@ JDEV void osc_target_quat(L& s, int lane) {
 template <class L>
 JDEV void stage_osc(const JacoModelDev* m, L& s, int lane, unsigned& flags) {
   float* Jm = s.J;            // [6][6] J[r][c], rows: 3 translational, 3 rotational; columns: arm dofs
-  float* Mi = s.J + 36;       // M^-1
   float* T = s.J + 72;        // M^-1 J^T
   float* X = s.J + 108;       // J M^-1 J^T, then its (pseudo-)inverse Mx
   float* w = s.J + 144;       // Mx u_task
@@ -289,28 +307,21 @@ JDEV void stage_osc(const JacoModelDev* m, L& s, int lane, unsigned& flags) {
     Jm[0 * 6 + lane] = jp.x; Jm[1 * 6 + lane] = jp.y; Jm[2 * 6 + lane] = jp.z;
     Jm[3 * 6 + lane] = S.a.x; Jm[4 * 6 + lane] = S.a.y; Jm[5 * 6 + lane] = S.a.z;
   }
-  // M^-1 (lanes 0..5 own rows)
+  // T = M^-1 J^T by elimination on [M | J^T] (lanes 0..5 own rows; row i of J^T is this lane's own Jacobian column)
   float A[6], B[6];
   int i = lane < 6 ? lane : 0;
+  {
+    sv S = ldsv(s.cdof[i]);
+    v3 jp = S.b + cross(S.a, pe);
+    B[0] = jp.x; B[1] = jp.y; B[2] = jp.z; B[3] = S.a.x; B[4] = S.a.y; B[5] = S.a.z;
+  }
 #pragma unroll
-  for (int j = 0; j < 6; j++) { A[j] = s.M[i * JNV + j]; B[j] = (lane == j) ? 1.f : 0.f; }
+  for (int j = 0; j < 6; j++) A[j] = s.M[i * JNV + j];
   gj_inverse6(A, B, lane);
-  if (lane < 6) for (int j = 0; j < 6; j++) Mi[lane * 6 + j] = B[j];
-  wave_sync();
-  if (lane < 36) { float a = 0.f; for (int k = 0; k < 6; k++) a += Mi[r * 6 + k] * Jm[c * 6 + k]; T[lane] = a; }
+  if (lane < 6) for (int j = 0; j < 6; j++) T[lane * 6 + j] = B[j];
   wave_sync();
   if (lane < 36) { float a = 0.f; for (int k = 0; k < 6; k++) a += Jm[r * 6 + k] * T[k * 6 + c]; X[lane] = a; }
   wave_sync();
-#pragma unroll
-  for (int j = 0; j < 6; j++) { A[j] = X[i * 6 + j]; B[j] = (lane == j) ? 1.f : 0.f; }
-  float det = gj_inverse6(A, B, lane);
-  // abr_control: plain inverse when |det| >= 1e-3, else SVD pseudo-inverse dropping singular values < 0.005
-  if (fabsf(det) < 1e-3f) {
-    flags |= JFLAG_OSC_SINGULAR;   // informational
-    pinv6_jacobi(X, s.J + 150, s.J + 186, lane);
-#pragma unroll
-    for (int j = 0; j < 6; j++) B[j] = s.J[186 + i * 6 + j];
-  }
   // task-space error (uniform across lanes)
   const float* tg = s.task + JT_TARGET;
   float ut[6];
@@ -330,7 +341,22 @@ JDEV void stage_osc(const JacoModelDev* m, L& s, int lane, unsigned& flags) {
   const float sat_xyz = JOSC_VMAX_XYZ / JOSC_KP * JOSC_KV, sat_abg = JOSC_VMAX_ABG / JOSC_KO * JOSC_KV;
   float sx = nx > sat_xyz ? sat_xyz / nx : 1.f, sa = na > sat_abg ? sat_abg / na : 1.f;
   for (int k = 0; k < 3; k++) { ut[k] *= JOSC_KP * sx; ut[3 + k] *= JOSC_KO * sa; }
-  if (lane < 6) { float a = 0.f; for (int k = 0; k < 6; k++) a += B[k] * ut[k]; w[lane] = a; }   // row `lane` of Mx
+  // w = Mx u_task:  Mx = X^-1 as a solve when |det X| >= 1e-3 (abr_control's plain inverse), else the SVD pseudo-inverse
+  // that drops singular values < 0.005
+#pragma unroll
+  for (int j = 0; j < 6; j++) A[j] = X[i * 6 + j];
+  float wi = ut[0];
+#pragma unroll
+  for (int j = 1; j < 6; j++) wi = i == j ? ut[j] : wi;
+  float det = gj_solve6(A, wi, lane);
+  if (fabsf(det) < 1e-3f) {
+    flags |= JFLAG_OSC_SINGULAR;   // informational
+    pinv6_jacobi(X, s.J + 150, s.J + 186, lane);
+    wi = 0.f;
+#pragma unroll
+    for (int k = 0; k < 6; k++) wi += s.J[186 + i * 6 + k] * ut[k];
+  }
+  if (lane < 6) w[lane] = wi;
   wave_sync();
   if (lane < 6) {
     float u = s.bias[lane];

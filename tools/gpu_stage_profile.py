@@ -43,7 +43,7 @@ print("stats mean", st.mean(0), "max", st.max(0), "line-search iterations mean",
 tot = per.sum(1)
 for i, n in enumerate(names):
     if n == '-': continue
-    print("%-42s mean %9.0f cyc  (%4.1f%%)  p99 %9.0f" % (n, per[:, i].mean(), 100 * per[:, i].mean() / tot.mean(), np.percentile(per[:, i], 99)))
+    print("%-42s mean %9.0f cyc  (%4.1f%%)  p50 %9.0f  p99 %9.0f" % (n, per[:, i].mean(), 100 * per[:, i].mean() / tot.mean(), np.median(per[:, i]), np.percentile(per[:, i], 99)))
 if "--slow" in sys.argv:   # what the slowest 2 % of envs spend their time on
     slow = tot >= np.percentile(tot, 98)
     print("slowest 2 %% of envs: total mean %.0f" % tot[slow].mean())
