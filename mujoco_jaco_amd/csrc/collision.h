@@ -531,11 +531,21 @@ JDEV void stage_contact_rows(const JacoModelDev* m, L& s, int lane, unsigned& fl
   int dim = 0, nrow = 0;
   float mu0 = 0.f, mu1 = 0.f, mu2 = 0.f;
   unsigned cm1 = 0, cm2 = 0;
+  // per-contact row parameters (lane = contact), from the pair's pre-mixed constants: every row of a contact shares the
+  // regulariser (pyramidal: 2 mu^2 R of the first row, impratio = 1) and the position part of aref; only the velocity
+  // part differs per row.  aref_row = a0 - bcoef * vel_row,  D_row = dinv.
+  float a0 = 0.f, bcoef = 0.f, dinv = 0.f;
   if (lane < ncon) {
     const JacoPairParam& P = m->pair[s.c_pair[lane]];
     dim = s.c_dim[lane]; nrow = dim == 1 ? 1 : 2 * (dim - 1);
-    mu0 = P.mu[0]; mu1 = P.mu[2]; mu2 = P.mu[3];
+    mu0 = P.mu[0]; mu1 = P.mu[2]; mu2 = P.mu[3];   // (mu[1] == mu[0], mu[4] == mu[3]: one tangential, one rolling coefficient)
     cm1 = s.c_m1[lane]; cm2 = s.c_m2[lane];
+    const float pos = s.c_dist[lane] - P.margin, tran = P.tran;
+    float R, imp;
+    a0 = row_params(P.solref, P.solimp, pos, 0.f, dim == 1 ? tran : tran + mu0 * mu0 * tran, &R, &imp);
+    bcoef = 2.f / fmaxf(JMINVAL, fminf(0.9999f, fmaxf(0.0001f, P.solimp[1])) * P.solref[0]);
+    if (dim > 1) R = fmaxf(JMINVAL, 2.f * mu0 * mu0 * R);
+    dinv = 1.f / R;
   }
   int end = nlim + wave_scan_incl(nrow, lane);
   unsigned long long fm = wave_ballot(lane < ncon && end <= MAXEFC);
@@ -548,7 +558,10 @@ JDEV void stage_contact_rows(const JacoModelDev* m, L& s, int lane, unsigned& fl
     s.c_efc[lane] = r0;
     unsigned mm = cm1 | cm2;
     int blk = ((mm & ((1u << JB0) - 1u)) ? 1 : 0) | (((mm >> JB0) & ((1u << (JB1 - JB0)) - 1u)) ? 2 : 0) | ((mm >> JB1) ? 4 : 0);
-    for (int e = 0; e < nrow; e++) s.e_con[r0 + e] = lane | (e << 8) | (blk << 16);
+    for (int e = 0; e < nrow; e++) {
+      s.e_con[r0 + e] = lane | (e << 8) | (blk << 16);
+      s.e_f[r0 + e] = e < 4 ? mu0 : (e < 6 ? mu1 : mu2);   // friction of the row's pyramid edge (e_f is free until the solver runs)
+    }
   }
   // Jacobian rows: lane = (contact slot 0..2, dof); the slot's contact data is fetched from its owner lane
   const int cl = lane / JNV, k = lane - cl * JNV;
@@ -583,11 +596,15 @@ JDEV void stage_contact_rows(const JacoModelDev* m, L& s, int lane, unsigned& fl
   }
   wave_sync();  // every lane has read the incoming row / contact counts; J rows and e_con are visible
   if (lane == 0) { s.nefc = total; s.ncon = kept; }
+  // hand the per-contact parameters to the row lanes through LDS: the chain masks are dead now, c_fn is not yet in use
+  float* pa0 = reinterpret_cast<float*>(s.c_m1);
+  float* pbc = reinterpret_cast<float*>(s.c_m2);
+  if (lane < kept) { pa0[lane] = a0; pbc[lane] = bcoef; s.c_fn[lane] = dinv; }
+  wave_sync();
   // per-row parameters, lane = row
   for (int rr = nlim + lane; rr < total; rr += 64) {
     int ce = s.e_con[rr], c = ce & 255, e = (ce >> 8) & 255;
-    const JacoPairParam& P = m->pair[s.c_pair[c]];
-    int pd = P.condim;
+    int pd = s.c_dim[c];
     int kf = pd == 1 ? 0 : 1 + (e >> 1);
     // row velocity J_row . qvel, taken from the two bodies' spatial velocities: the contact-frame components of the relative
     // point velocity (k < 3) or relative angular velocity (k >= 3), combined as the pyramid edge  v_0 +- mu_k v_k
@@ -605,21 +622,11 @@ JDEV void stage_contact_rows(const JacoModelDev* m, L& s, int lane, unsigned& fl
       if (pd > 1) {
         int ax = kf < 3 ? kf : kf - 3;
         float comp = dot(ld3(fr + 3 * ax), kf < 3 ? dv : dw);
-        vel += ((e & 1) ? -1.f : 1.f) * P.mu[kf - 1] * comp;
+        vel += ((e & 1) ? -1.f : 1.f) * s.e_f[rr] * comp;
       }
     }
-    float tran = P.tran, rot = P.rot;
-    float pos = s.c_dist[c] - P.margin;
-    float mu = pd == 1 ? 0.f : P.mu[kf - 1];
-    float da = pd == 1 ? tran : tran + mu * mu * (kf < 3 ? tran : rot);
-    float R, imp;
-    float aref = row_params(P.solref, P.solimp, pos, vel, da, &R, &imp);
-    if (pd > 1) {  // pyramidal: every edge uses 2 mu^2 R of the contact's first row (impratio = 1)
-      float R0 = fmaxf(JMINVAL, (1.f - imp) * (tran + P.mu[0] * P.mu[0] * tran) / imp);
-      R = fmaxf(JMINVAL, 2.f * P.mu[0] * P.mu[0] * R0);
-    }
-    s.e_aref[rr] = aref;
-    s.e_D[rr] = 1.f / R;
+    s.e_aref[rr] = pa0[c] - pbc[c] * vel;
+    s.e_D[rr] = s.c_fn[c];
   }
 }
 
