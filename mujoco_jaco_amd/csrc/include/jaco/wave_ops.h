@@ -133,3 +133,9 @@ JDEV void acc_zero(acc32x32& c) {
   for (int i = 0; i < 16; i++) c.v[i] = 0.f;
 }
 JDEV void wave_mfma_32x32x2(float a, float b, acc32x32& c) { c.v = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c.v, 0, 0, 0); }
+// 16x16 f32 tile of v_mfma_f32_16x16x4_f32: element (row, col) lives in lane (col + 16 * (row >> 2)), register row & 3.
+// One call adds the rank-4 product A[16x4] * B[4x16]: lane l supplies a = A[l & 15][l >> 4] and b = B[l >> 4][l & 15].
+typedef float jaco_f32x4 __attribute__((ext_vector_type(4)));
+struct acc16x16 { jaco_f32x4 v; };
+JDEV void acc_zero(acc16x16& c) { c.v[0] = c.v[1] = c.v[2] = c.v[3] = 0.f; }
+JDEV void wave_mfma_16x16x4(float a, float b, acc16x16& c) { c.v = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c.v, 0, 0, 0); }

@@ -752,6 +752,39 @@ JDEV NewtonOut stage_newton(const JacoModelDev* m, L& s, const float (&mrow)[JNV
 #pragma unroll
     for (int q = 0; q < NR; q++) if (valid[q]) { s.e_f[lane + 64 * q] = x[q] < 0.f ? D[q] : 0.f; xs[lane + 64 * q] = x[q]; }
     wave_sync();
+    float h[JNV], jtf;
+    if ((rowblocks & 1) == 0) {
+      // rows only on the free bodies (dofs [JB0, JNV), 12 of them): the tile is 16 x 16 -- 12 dof columns + the -x column --
+      // and v_mfma_f32_16x16x4_f32 takes four constraint rows per issue (a quarter of the matrix-core time of the 32 x 32 form)
+      acc16x16 C;
+      acc_zero(C);
+      const int uq = lane >> 4, col = lane & 15;
+      for (int r0 = 0; r0 < ne; r0 += 16) {
+        float jv[4], wv[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          int r = r0 + 4 * u + uq;
+          bool ok = r < ne;
+          float xv = ok ? xs[r] : 0.f;
+          jv[u] = (ok && col < JNV - JB0) ? s.J[r * JLD + JB0 + col] : 0.f;
+          jv[u] = col == JNV - JB0 ? -xv : jv[u];
+          wv[u] = ok ? s.e_f[r] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) wave_mfma_16x16x4(jv[u], wv[u] * jv[u], C);
+      }
+      JSTAMP(12);
+      // symmetric tile: H[jd][c] = C[c][jd] sits in lane jd + 16 * (c >> 2), register c & 3 (jd = this lane's dof - JB0)
+      const int jd = (lane >= JB0 && lane < JNV) ? lane - JB0 : 0;
+#pragma unroll
+      for (int j2 = 0; j2 < JNV; j2++) {
+        float cv = 0.f;
+        if (j2 >= JB0) { const int c = j2 - JB0; cv = wave_shfl(C.v[c & 3], jd + 16 * (c >> 2)); }
+        h[j2] = lane < nv ? mrow[j2] + (lane >= JB0 ? cv : 0.f) : (lane == j2 ? 1.f : 0.f);
+      }
+      jtf = wave_shfl(C.v[(JNV - JB0) & 3], jd + 16 * ((JNV - JB0) >> 2));   // row 12: J^T f
+      jtf = lane >= JB0 ? jtf : 0.f;
+    } else {
     acc32x32 C;
     acc_zero(C);
     const int uh = lane >> 5, col = lane & 31;
@@ -771,18 +804,20 @@ JDEV NewtonOut stage_newton(const JacoModelDev* m, L& s, const float (&mrow)[JNV
     }
     JSTAMP(12);
     // C is symmetric: row j of the tile, column `lane`, is where lane `lane` finds H[lane][j]
-    float h[JNV];
 #pragma unroll
     for (int j2 = 0; j2 < JNV; j2++) {
       const int reg = (j2 & 3) + 4 * (j2 >> 3);
       float cv = ((j2 >> 2) & 1) ? wave_shfl(C.v[reg], (lane + 32) & 63) : C.v[reg];
       h[j2] = lane < nv ? mrow[j2] + cv : (lane == j2 ? 1.f : 0.f);
     }
-    float jtf = wave_shfl(C.v[(JNV & 3) + 4 * (JNV >> 3)], (lane + 32) & 63);   // row 21 sits in the upper lane half
+    jtf = wave_shfl(C.v[(JNV & 3) + 4 * (JNV >> 3)], (lane + 32) & 63);   // row 21 sits in the upper lane half
+    }
     float grad = Ma - (lane < nv ? jtf : 0.f);
     float gn = sqrtf(wave_sum(grad * grad));
     if (gn * scale < tol) break;
-    float p = full ? ldl_solve<true>(h, -grad, lane) : ldl_solve_blocks(h, -grad, lane, rowblocks);
+    // coupled rows: one factorisation over the coupled dofs -- the two free bodies alone ([JB0, JNV), e.g. object resting on
+    // the pedestal) when the arm block carries no row, else all 21
+    float p = !full ? ldl_solve_blocks(h, -grad, lane, rowblocks) : ((rowblocks & 1) == 0 ? ldl_block<JB0, JNV>(h, -grad, lane) : ldl_solve<true>(h, -grad, lane));
     p = lane < nv ? p : 0.f;
     JSTAMP(13);
     // exact line search on phi(al) = cost(a + al p)

@@ -100,6 +100,23 @@ JDEV const T* opaque_ptr(const T* p) {
   return p;
 }
 
+struct acc16x16 { float v[4]; };
+JDEV void acc_zero(acc16x16& c) { for (int i = 0; i < 4; i++) c.v[i] = 0.f; }
+JDEV void wave_mfma_16x16x4(float a, float b, acc16x16& c) {
+  int p = emu_post_f(a);
+  emu_collective();
+  float as[64];
+  for (int l = 0; l < 64; l++) as[l] = emu_x[p][l].f;
+  int q = emu_post_f(b);
+  emu_collective();
+  int lane = emu_cur_lane, col = lane & 15;
+  for (int reg = 0; reg < 4; reg++) {
+    int row = 4 * (lane >> 4) + reg;
+    float acc = c.v[reg];
+    for (int k = 0; k < 4; k++) acc = fmaf(as[row + 16 * k], emu_x[q][col + 16 * k].f, acc);
+    c.v[reg] = acc;
+  }
+}
 struct acc32x32 { float v[16]; };
 JDEV void acc_zero(acc32x32& c) { for (int i = 0; i < 16; i++) c.v[i] = 0.f; }
 JDEV void wave_mfma_32x32x2(float a, float b, acc32x32& c) {
