@@ -346,7 +346,7 @@ JDEV void load_rows(float (&h)[JNV], const float* M, int nv, int lane) {
 // K2 (lane = body): world frame = product of the ancestors' T, by pointer jumping: round r composes each body's partial
 //                   product with the one 2^r levels up (3 rounds cover the 7-body chain link1..link6, finger).
 // K2b (lane = dof): motion subspaces S_d and S_d * qvel_d.
-// K3 (lane = body): body velocity = sum of S_d qvel_d over the dofs that move it (own dofs, then the same pointer jumping);
+// K3 (lane = body): body velocity = sum of S_d qvel_d over the dofs that move it (bit mask of the body's dof chain);
 // K4 (lane = dof): S_d-dot * qvel_d with the velocity "before" that dof;  K5 (lane = body): bias acceleration = -gravity +
 //                   sum over the chain.
 // Scratch: s.cinert/s.crb (rebuilt right after) and the not-yet-built constraint-row area s.J.
@@ -361,17 +361,6 @@ JDEV void st_frame(float* T, const m3& R, v3 p) {
   c.y = p.x; c.z = p.y; c.w = p.z;
   *reinterpret_cast<v4*>(T) = a; *reinterpret_cast<v4*>(T + 4) = b; *reinterpret_cast<v4*>(T + 8) = c;
 }
-// P[b] = own[b] + sum over b's ancestors of own[.], for 6-vectors: pointer jumping through two scratch buffers into `out`.
-template <class L>
-JDEV void chain_prefix6(L& s, sv own, bool isb, int b, int a1, int a2, int a4, float* X, float* Y, float* out) {
-  if (isb) stsv(X + 6 * b, own);
-  wave_sync();
-  if (isb) { if (a1 >= 0) own = own + ldsv(X + 6 * a1); stsv(Y + 6 * b, own); }
-  wave_sync();
-  if (isb) { if (a2 >= 0) own = own + ldsv(Y + 6 * a2); stsv(X + 6 * b, own); }
-  wave_sync();
-  if (isb) { if (a4 >= 0) own = own + ldsv(X + 6 * a4); stsv(out + 6 * b, own); }
-}
 template <class L>
 JDEV void stage_walk(const JacoModelDev* m, L& s, int lane) {
   const int nb = m->nbody, nv = m->nv;
@@ -379,12 +368,11 @@ JDEV void stage_walk(const JacoModelDev* m, L& s, int lane) {
   float* TB = s.J + 256;         // [JNB][12] frames, pong  (the constraint-row area is free at this point)
   float* Sq = s.J;               // [JNV][6] S_d * qvel_d
   float* Sq2 = s.J + JNV * 6;    // [JNV][6] S_d-dot * qvel_d
-  float* VX = s.J + 400;         // [JNB][6] x 2: prefix-sum scratch
-  float* VY = s.J + 472;
   const bool isb = lane < nb;
   const int b = isb ? lane : 0;
   const int jt = s.mc.b_jtype[b], qa = s.mc.b_qadr[b], da = s.mc.b_dadr[b];
   const int a1 = s.mc.b_anc[b][0], a2 = s.mc.b_anc[b][1], a4 = s.mc.b_anc[b][2];
+  const unsigned chain = isb ? m->b_chainmask[b] : 0u;   // dofs that move this body (used two stages further down)
   m3 R; v3 pos;
   if (isb) {
     if (jt == JJ_HINGE) {
@@ -429,13 +417,10 @@ JDEV void stage_walk(const JacoModelDev* m, L& s, int lane) {
     stsv(Sq + 6 * d, S * s.qvel[d]);
   }
   wave_sync();
-  {   // body velocity: own dofs + all ancestors' dofs
+  if (isb) {   // body velocity: sum of S_d qvel_d over the dofs that move the body (own + all ancestors'), straight from the mask
     sv v; v.a = v.b = mk3(0, 0, 0);
-    if (isb) {
-      int nd = jt == JJ_HINGE ? 1 : 6;
-      for (int c = 0; c < nd; c++) v = v + ldsv(Sq + 6 * (da + c));
-    }
-    chain_prefix6(s, v, isb, b, a1, a2, a4, VX, VY, &s.cvel[0][0]);
+    for (unsigned mm = chain; mm; mm &= mm - 1u) v = v + ldsv(Sq + 6 * __builtin_ctz(mm));
+    stsv(s.cvel[b], v);
   }
   wave_sync();
   if (lane < nv) {   // S_d-dot * qvel_d, S_d-dot = (velocity before dof d) x_m S_d
@@ -453,15 +438,11 @@ JDEV void stage_walk(const JacoModelDev* m, L& s, int lane) {
     stsv(Sq2 + 6 * d, r);
   }
   wave_sync();
-  {
+  if (isb) {   // bias acceleration: -gravity + sum of S_d-dot qvel_d over the same dofs
     sv a; a.a = mk3(0, 0, 0);
-    // -gravity enters once per chain: root bodies carry it, the others inherit it through the prefix
-    a.b = a1 < 0 ? mk3(-m->gravity[0], -m->gravity[1], -m->gravity[2]) : mk3(0, 0, 0);
-    if (isb) {
-      int nd = jt == JJ_HINGE ? 1 : 6;
-      for (int c = 0; c < nd; c++) a = a + ldsv(Sq2 + 6 * (da + c));
-    }
-    chain_prefix6(s, a, isb, b, a1, a2, a4, VX, VY, &s.cacc[0][0]);
+    a.b = mk3(-m->gravity[0], -m->gravity[1], -m->gravity[2]);
+    for (unsigned mm = chain; mm; mm &= mm - 1u) a = a + ldsv(Sq2 + 6 * __builtin_ctz(mm));
+    stsv(s.cacc[b], a);
   }
 }
 
