@@ -362,7 +362,13 @@ JDEV void st_frame(float* T, const m3& R, v3 p) {
   *reinterpret_cast<v4*>(T) = a; *reinterpret_cast<v4*>(T + 4) = b; *reinterpret_cast<v4*>(T + 8) = c;
 }
 template <class L>
-JDEV void stage_walk(const JacoModelDev* m, L& s, int lane) {
+JDEV void stage_walk(const JacoModelDev* m, L& s, int lane, JProfCtx* wpc = nullptr) {
+#ifdef JACO_WALK_PROFILE   // diagnostic: split this stage over profile slots 9..14 (their usual owners are wrong in such a build)
+#define JWSTAMP(i) if (wpc) jprof_stamp(*wpc, (i), lane)
+#else
+#define JWSTAMP(i)
+#endif
+  (void)wpc;
   const int nb = m->nbody, nv = m->nv;
   float* TA = &s.cinert[0][0];   // [JNB][12] frames, ping  (cinert+crb are contiguous: 2 * JNB * 10 floats)
   float* TB = s.J + 256;         // [JNB][12] frames, pong  (the constraint-row area is free at this point)
@@ -374,6 +380,9 @@ JDEV void stage_walk(const JacoModelDev* m, L& s, int lane) {
   const int a1 = s.mc.b_anc[b][0], a2 = s.mc.b_anc[b][1], a4 = s.mc.b_anc[b][2];
   const unsigned chain = isb ? m->b_chainmask[b] : 0u;   // dofs that move this body (used two stages further down)
   m3 R; v3 pos;
+  float io[10];
+#pragma unroll
+  for (int k = 0; k < 10; k++) io[k] = 0.f;
   if (isb) {
     if (jt == JJ_HINGE) {
       R = mul(ldm(s.mc.b_mat[b]), axis_rot(ld3(s.mc.b_axis[b]), s.qpos[qa] - s.mc.b_qpos0[b]));
@@ -388,6 +397,7 @@ JDEV void stage_walk(const JacoModelDev* m, L& s, int lane) {
     st_frame(TA + 12 * b, R, pos);
   }
   wave_sync();
+  JWSTAMP(9);
   if (isb) {
     if (a1 >= 0) { m3 Rp; v3 pp; ld_frame(TA + 12 * a1, Rp, pp); pos = pp + mul(Rp, pos); R = mul(Rp, R); }
     st_frame(TB + 12 * b, R, pos);
@@ -402,9 +412,38 @@ JDEV void stage_walk(const JacoModelDev* m, L& s, int lane) {
     if (a4 >= 0) { m3 Rp; v3 pp; ld_frame(TA + 12 * a4, Rp, pp); pos = pp + mul(Rp, pos); R = mul(Rp, R); }
     st3(s.xpos[b], pos);
     stm(s.xmat[b], R);
-    st3(s.xipos[b], pos + mul(R, ld3(s.mc.b_com[b])));
+    const v3 c = pos + mul(R, ld3(s.mc.b_com[b]));
+    st3(s.xipos[b], c);
+    // spatial inertia about the world origin [m, m c, I_O], from the frame still in registers
+    const float* I = m->b_inertia[b];
+    m3 Il;
+    Il.m[0] = I[0]; Il.m[4] = I[1]; Il.m[8] = I[2];
+    Il.m[1] = Il.m[3] = I[3]; Il.m[2] = Il.m[6] = I[4]; Il.m[5] = Il.m[7] = I[5];
+    m3 T = mul(R, Il), Iw;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) Iw.m[3 * i + j] = T.m[3 * i] * R.m[3 * j] + T.m[3 * i + 1] * R.m[3 * j + 1] + T.m[3 * i + 2] * R.m[3 * j + 2];
+    const float mass = m->b_mass[b], cc = dot(c, c);
+    io[0] = mass; io[1] = mass * c.x; io[2] = mass * c.y; io[3] = mass * c.z;
+    io[4] = Iw.m[0] + mass * (cc - c.x * c.x); io[5] = Iw.m[4] + mass * (cc - c.y * c.y); io[6] = Iw.m[8] + mass * (cc - c.z * c.z);
+    io[7] = Iw.m[1] - mass * c.x * c.y; io[8] = Iw.m[2] - mass * c.x * c.z; io[9] = Iw.m[5] - mass * c.y * c.z;
   }
-  wave_sync();   // TA is dead from here on (cinert / crb get rebuilt by stage G)
+  wave_sync();   // the frame scratch TA (= cinert / crb) is dead from here on
+  JWSTAMP(10);
+  // one interval for everything that only needs the body frames: inertias out of the registers, moving geom poses, S_d
+  if (isb) {
+#pragma unroll
+    for (int k = 0; k < 10; k++) { s.cinert[b][k] = io[k]; s.crb[b][k] = io[k]; }
+  }
+  if (lane < m->ngeom) {
+    const int gb = m->g_body[lane];
+    if (gb >= 0) {
+      m3 Rg = ldm(s.xmat[gb]);
+      st3(s.gpos[lane], ld3(s.xpos[gb]) + mul(Rg, ld3(m->g_pos[lane])));
+      stm(s.gmat[lane], mul(Rg, ldm(m->g_mat[lane])));
+    }
+  }
   if (lane < nv) {   // S_d: hinge -> world axis through the body origin; free joint -> 3 world translations, 3 body-frame rotations
     const int d = lane, bd = s.mc.d_body[d], k = d - s.mc.b_dadr[bd];
     const bool hinge = s.mc.b_jtype[bd] == JJ_HINGE, rotational = hinge || k >= 3;
@@ -417,12 +456,14 @@ JDEV void stage_walk(const JacoModelDev* m, L& s, int lane) {
     stsv(Sq + 6 * d, S * s.qvel[d]);
   }
   wave_sync();
+  JWSTAMP(11);
   if (isb) {   // body velocity: sum of S_d qvel_d over the dofs that move the body (own + all ancestors'), straight from the mask
     sv v; v.a = v.b = mk3(0, 0, 0);
     for (unsigned mm = chain; mm; mm &= mm - 1u) v = v + ldsv(Sq + 6 * __builtin_ctz(mm));
     stsv(s.cvel[b], v);
   }
   wave_sync();
+  JWSTAMP(12);
   if (lane < nv) {   // S_d-dot * qvel_d, S_d-dot = (velocity before dof d) x_m S_d
     int d = lane, bd = s.mc.d_body[d], pb = s.mc.b_parent[bd];
     sv vb; vb.a = vb.b = mk3(0, 0, 0);
@@ -438,15 +479,19 @@ JDEV void stage_walk(const JacoModelDev* m, L& s, int lane) {
     stsv(Sq2 + 6 * d, r);
   }
   wave_sync();
-  if (isb) {   // bias acceleration: -gravity + sum of S_d-dot qvel_d over the same dofs
+  JWSTAMP(13);
+  if (isb) {   // bias acceleration: -gravity + sum of S_d-dot qvel_d over the same dofs; then the body's RNE force right away
     sv a; a.a = mk3(0, 0, 0);
     a.b = mk3(-m->gravity[0], -m->gravity[1], -m->gravity[2]);
     for (unsigned mm = chain; mm; mm &= mm - 1u) a = a + ldsv(Sq2 + 6 * __builtin_ctz(mm));
-    stsv(s.cacc[b], a);
+    const sv v = ldsv(s.cvel[b]);
+    const sv f = inert_mul(s.cinert[b], a) + cross_force(v, inert_mul(s.cinert[b], v));
+    stsv(s.cfrc[b], f);
+    stsv(s.cacc[b], f);   // subtree force sum, completed for bodies with children by stage_accumulate
   }
 }
 
-// ---------------------------------------------------------------- stage G: geom poses, body inertias, RNE body forces
+// ---------------------------------------------------------------- stage G: static geom poses (moving geoms, body inertias and RNE body forces live in stage K)
 template <class L>
 JDEV void stage_static_geoms(const JacoModelDev* m, L& s, int lane, const float* mk) {
   // world poses of the geoms that do not move during a launch: static geoms and the geoms on the two task-layer markers
@@ -464,43 +509,6 @@ JDEV void stage_static_geoms(const JacoModelDev* m, L& s, int lane, const float*
     }
   }
 }
-template <class L>
-JDEV void stage_geoms_inertia(const JacoModelDev* m, L& s, int lane) {
-  if (lane < m->ngeom) {
-    int b = m->g_body[lane];
-    if (b >= 0) {
-      m3 R = ldm(s.xmat[b]);
-      st3(s.gpos[lane], ld3(s.xpos[b]) + mul(R, ld3(m->g_pos[lane])));
-      stm(s.gmat[lane], mul(R, ldm(m->g_mat[lane])));
-    }
-  }
-  if (lane < m->nbody) {
-    int b = lane;
-    m3 R = ldm(s.xmat[b]);
-    const float* I = m->b_inertia[b];
-    m3 Il;
-    Il.m[0] = I[0]; Il.m[4] = I[1]; Il.m[8] = I[2];
-    Il.m[1] = Il.m[3] = I[3]; Il.m[2] = Il.m[6] = I[4]; Il.m[5] = Il.m[7] = I[5];
-    m3 T = mul(R, Il), Iw;
-#pragma unroll
-    for (int i = 0; i < 3; i++)
-#pragma unroll
-      for (int j = 0; j < 3; j++) Iw.m[3 * i + j] = T.m[3 * i] * R.m[3 * j] + T.m[3 * i + 1] * R.m[3 * j + 1] + T.m[3 * i + 2] * R.m[3 * j + 2];
-    v3 c = ld3(s.xipos[b]);
-    float mass = m->b_mass[b], cc = dot(c, c);
-    float* o = s.cinert[b];
-    o[0] = mass; o[1] = mass * c.x; o[2] = mass * c.y; o[3] = mass * c.z;
-    o[4] = Iw.m[0] + mass * (cc - c.x * c.x); o[5] = Iw.m[4] + mass * (cc - c.y * c.y); o[6] = Iw.m[8] + mass * (cc - c.z * c.z);
-    o[7] = Iw.m[1] - mass * c.x * c.y; o[8] = Iw.m[2] - mass * c.x * c.z; o[9] = Iw.m[5] - mass * c.y * c.z;
-#pragma unroll
-    for (int k = 0; k < 10; k++) s.crb[b][k] = o[k];
-    sv v = ldsv(s.cvel[b]), a = ldsv(s.cacc[b]);
-    sv f = inert_mul(o, a) + cross_force(v, inert_mul(o, v));
-    stsv(s.cfrc[b], f);
-    stsv(s.cacc[b], f);   // subtree force sum, completed for bodies with children by stage_accumulate
-  }
-}
-
 // Subtree sums for the bodies that have children (leaves keep their own values from stage G): composite inertias
 // crb[a] = sum of cinert over a's subtree (lane = (a, component), 10 components) and RNE forces cacc[a] = sum of cfrc over
 // the subtree (6 components; cacc is dead as an acceleration by now and doubles as the summed force).  Sources and
@@ -1023,12 +1031,14 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
         wave_sync();
       }
     }
+#ifdef JACO_WALK_PROFILE
+    stage_walk(m, s, lane, &pc);
+#else
     stage_walk(m, s, lane);
+#endif
     for (int i = lane; i < JNV * JNV; i += 64) s.M[i] = 0.f;
     wave_sync();
     JSTAMP(0);
-    stage_geoms_inertia(m, s, lane);
-    wave_sync();
     JSTAMP(1);
     stage_accumulate(m, s, lane);
     wave_sync();
