@@ -170,3 +170,47 @@ def test_placing_hold_parity_150(model_arrays, names):
         oq = oe.o.get("qpos")
         assert np.abs(q1[k, :9] - oq[:9]).max() < 1e-3, (k, np.abs(q1[k, :9] - oq[:9]).max())
         assert np.abs(q1[k, 9:12] - oq[9:12]).max() < 1e-5
+
+
+def test_frame_skip4_with_termination_masking(model_arrays, names):
+    """BASELINE config 4: 4-substep frame skip + early-termination masking.  Half of the envs are one step away from the
+    700-step time-out; after it they must freeze (done = 1, reward 0, state untouched) while the others keep matching
+    the fp64 oracle env step for step."""
+    from mujoco_jaco_amd import workload
+    from mujoco_jaco_amd.env import JacoBatchedEnv
+    from oracle_env import OracleEnv
+    B, fs, nstep = 8, 4, 12
+    q = workload.reset_states(model_arrays["qpos0"], B, seed=91)
+    env = JacoBatchedEnv(num_envs=B, task="picking", frame_skip=fs)
+    dev = env.device
+    env.sim.set_state(torch.tensor(q, dtype=torch.float32, device=dev), torch.zeros(B, 21, device=dev), torch.zeros(B, 21, device=dev))
+    t = env.task_state(); t[:] = 0; t[:, 0] = 0.6; t[:, 16] = 0.6
+    t[:, 4:7] = torch.tensor(q[:, 9:12], dtype=torch.float32); t[:, 7:9] = torch.tensor(q[:, 16:18], dtype=torch.float32); t[:, 9] = 0.3468
+    t[::2, 1] = 698                                           # even envs: current_steps one before the time-out
+    env.set_task_state(t)
+    oes = []
+    for k in range(B):
+        oe = OracleEnv(names, frame_skip=fs); oe.obj_goal = q[k, 9:12].astype(np.float32).astype(np.float64)
+        oe.dest_goal = np.array([q[k, 16], q[k, 17], 0.3468]).astype(np.float32).astype(np.float64)
+        oe.steps = 698 if k % 2 == 0 else 0
+        oe.set_state(q[k].astype(np.float32).astype(np.float64)); oes.append(oe)
+    rng = np.random.default_rng(17)
+    nz = rng.uniform(size=(B, 12)).astype(np.float32)
+    env.set_noise(torch.tensor(nz)); env.make_observation()
+    frozen_q = None
+    for s in range(nstep):
+        a = rng.uniform(-1, 1, (B, 7)).astype(np.float32); nz = rng.uniform(size=(B, 12)).astype(np.float32)
+        env.set_noise(torch.tensor(nz))
+        obs, rew, done, _ = env.step(torch.tensor(a))
+        obs, rew, done = obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()
+        qn = env.sim.get_state()[0].cpu().numpy()
+        for k in range(B):
+            if k % 2 == 0 and s >= 2:                          # timed out at s == 1: frozen from then on
+                assert done[k] and rew[k] == 0 and np.array_equal(qn[k], frozen_q[k])
+                continue
+            oo, orew, odone, _ = oes[k].step(a[k].astype(np.float64), nz[k].astype(np.float64))
+            assert bool(done[k]) == odone, (s, k)
+            assert np.abs(obs[k] - oo).max() < 2e-4 and obs[k, 0] == oo[0]
+        if s == 1:
+            assert done[::2].all() and not done[1::2].any() and (rew[::2] < -9).all()
+            frozen_q = qn.copy()
