@@ -127,7 +127,7 @@ int jaco_set_frame_skip(JacoHandle* h, int frame_skip);
 /* Solver / collision options, MuJoCo <option> names: "iterations", "tolerance", "ls_iterations",
  * "disable_contact" (contact flag), "mpr_iterations", "mpr_tolerance".
  * Execution options (no effect on results): "schedule" (1: launch expensive envs first), "concurrent_heavy" (1: heavy-tier
- * workgroups resident next to the light grid), "heavy_workers" (their number, default 128), "tier_return" (1: a heavy-tier
+ * workgroups resident next to the light grid), "heavy_workers" (their maximum, default 192; the resident number follows the previous step's hand-overs), "tier_return" (1: a heavy-tier
  * env goes back to the light code when its overflow is over). */
 int jaco_set_option(JacoHandle* h, const char* name, double value);
 

@@ -28,7 +28,7 @@ struct JacoHandle {
   int *remaining = nullptr, *heavy_list = nullptr, *heavy_count = nullptr;   // heavy_count[0..2]: appended, claimed, light workgroups left
   hipStream_t side = nullptr;                 // heavy-tier workers run here, concurrently with the light tier
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  int concurrent = 1, workers = 128, tier_return = 1;           // options "concurrent_heavy", "heavy_workers"
+  int concurrent = 1, workers = 192, tier_return = 1;           // options "concurrent_heavy", "heavy_workers"
   float *task_rows = nullptr, *cache = nullptr;
   float* marker = nullptr;    // [num_envs][2][12] poses of the "hand" / "subgoal_reach" markers (mocap bodies the task layer moves)
   unsigned* cost = nullptr;   // per env: shader-clock ticks its last step took (>> 4)
@@ -264,11 +264,17 @@ __global__ __launch_bounds__(1024) void jaco_order_kernel(const unsigned* cost, 
   }
 }
 
-// work-list reset before every launch: counters = {0 appended, 0 claimed, nenv light workgroups to go}, entries = -1
-__global__ void jaco_prepare_kernel(int* ctl, int* list, int n) {
+// work-list reset before every launch: counters = {0 appended, 0 claimed, nenv light workgroups to go}, entries = -1;
+// ctl[3] = how many of the launched heavy-tier workers stay resident: about one per two envs the previous launch handed
+// over (an idle worker still occupies a SIMD the light tier could use), at least 16
+__global__ void jaco_prepare_kernel(int* ctl, int* list, int n, int max_workers) {
   int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   if (i < n) list[i] = -1;
-  if (i == 0) { ctl[0] = 0; ctl[1] = 0; ctl[2] = n; }
+  if (i == 0) {
+    int want = 16 + ctl[0] / 2;
+    ctl[3] = want < max_workers ? want : max_workers;
+    ctl[0] = 0; ctl[1] = 0; ctl[2] = n;
+  }
 }
 
 static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t st, float* dbg, int dbg_env, const EnvIO& io = EnvIO()) {
@@ -278,7 +284,7 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
   A.ctrl = ctrl ? ctrl : h->qvel;   // env modes compute ctrl in-kernel; the pointer only has to be readable
   A.sensordata = h->sensordata; A.flags = h->flags; A.stats = h->stats; A.nenv = h->num_envs; A.nsub = nsub;
   A.disable_contact = h->disable_contact; A.no_tier_return = !h->tier_return; A.dbg = dbg; A.dbg_env = dbg_env; A.prof = h->prof;
-  A.remaining = h->remaining; A.heavy_list = h->heavy_list; A.heavy_count = h->heavy_count; A.heavy_taken = h->heavy_count + 1; A.light_left = h->heavy_count + 2;
+  A.remaining = h->remaining; A.heavy_list = h->heavy_list; A.heavy_count = h->heavy_count; A.heavy_taken = h->heavy_count + 1; A.light_left = h->heavy_count + 2; A.worker_limit = h->heavy_count + 3;
   A.env_mode = io.mode; A.task_id = h->task; A.nact = h->task == JACO_TASK_REACHING ? 6 : 7; A.seed = h->seed;
   A.task = h->task_rows; A.cache = h->cache; A.action = io.action; A.noise = h->noise; A.obs = io.obs; A.reward = io.reward; A.done = io.done; A.mask = io.mask; A.marker = h->marker;
   A.cost = h->cost;
@@ -299,7 +305,7 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
   // grid they are resident from the beginning (a heavy wave needs a SIMD of its own and would otherwise starve behind the
   // light grid, leaving a serial tail of several ms per env step).  The drain launch that follows in stream order
   // serves whatever the workers did not (all of it when concurrency is off).
-  hipLaunchKernelGGL(jaco_prepare_kernel, dim3((unsigned)((h->num_envs + 255) / 256)), dim3(256), 0, st, h->heavy_count, h->heavy_list, h->num_envs);
+  hipLaunchKernelGGL(jaco_prepare_kernel, dim3((unsigned)((h->num_envs + 255) / 256)), dim3(256), 0, st, h->heavy_count, h->heavy_list, h->num_envs, h->workers);
   HIPCHK(h, hipGetLastError());
   if (reorder) {
     hipLaunchKernelGGL(jaco_order_kernel, dim3(1), dim3(1024), 0, st, h->cost, h->order, h->num_envs);

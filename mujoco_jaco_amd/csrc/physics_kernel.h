@@ -76,6 +76,7 @@ struct JacoStepArgs {
   int* heavy_count;    // [1] entries appended to heavy_list
   int* heavy_taken;    // [1] entries claimed by heavy-tier workgroups
   int* light_left;     // [1] light-tier workgroups still running (0: no further entries will appear)
+  const int* worker_limit;  // [1] heavy-tier workers beyond this index leave at once (sized from the previous launch's hand-overs), or nullptr
   int nenv, nsub, disable_contact;
   int no_tier_return;  // 1: an env handed to the heavy tier stays there for the rest of the launch (option "tier_return" = 0)
   // env-level mode (jaco_step / jaco_reset): nsub = frame_skip
@@ -1287,6 +1288,7 @@ JDEV void run_env_tiers(const JacoStepArgs& A, JacoTierLDS& u, int env, int lane
 __global__ __launch_bounds__(64) void jaco_physics_kernel_heavy(JacoStepArgs A) {
   __shared__ JacoTierLDS u;
   const int lane = lane_id();
+  if (A.worker_limit && env_id() >= *A.worker_limit) return;
   for (;;) {
     int i = 0;
     if (lane == 0) i = jaco_atomic_inc(A.heavy_taken);
