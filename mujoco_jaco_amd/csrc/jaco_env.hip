@@ -178,6 +178,7 @@ extern "C" int jaco_num_envs(const JacoHandle* h) { return h ? h->num_envs : JAC
 
 extern "C" int jaco_set_state(JacoHandle* h, const float* qpos, const float* qvel, const float* qacc_ws, void* stream) {
   if (!h) return JACO_EINVAL;
+  HIPCHK(h, hipSetDevice(h->device));   // the handle's kernels and streams live on its own GPU, whatever the caller's current device
   hipStream_t st = (hipStream_t)stream;
   size_t B = h->num_envs;
   if (qpos) HIPCHK(h, hipMemcpyAsync(h->qpos, qpos, B * h->model_host.nq * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -187,6 +188,7 @@ extern "C" int jaco_set_state(JacoHandle* h, const float* qpos, const float* qve
 }
 extern "C" int jaco_get_state(JacoHandle* h, float* qpos, float* qvel, float* qacc_ws, void* stream) {
   if (!h) return JACO_EINVAL;
+  HIPCHK(h, hipSetDevice(h->device));   // the handle's kernels and streams live on its own GPU, whatever the caller's current device
   hipStream_t st = (hipStream_t)stream;
   size_t B = h->num_envs;
   if (qpos) HIPCHK(h, hipMemcpyAsync(qpos, h->qpos, B * h->model_host.nq * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -201,6 +203,7 @@ __global__ void jaco_fill_rows_kernel(float* dst, const float* row, int n, int n
 }
 extern "C" int jaco_reset_state(JacoHandle* h, void* stream) {
   if (!h) return JACO_EINVAL;
+  HIPCHK(h, hipSetDevice(h->device));   // the handle's kernels and streams live on its own GPU, whatever the caller's current device
   hipStream_t st = (hipStream_t)stream;
   const JacoModelDev& m = h->model_host;
   size_t B = h->num_envs;
@@ -279,6 +282,7 @@ __global__ void jaco_prepare_kernel(int* ctl, int* list, int n, int max_workers)
 
 static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t st, float* dbg, int dbg_env, const EnvIO& io = EnvIO()) {
   if ((!ctrl && io.mode == 0) || nsub <= 0) { h->err = "jaco_physics_step: bad arguments"; return JACO_EINVAL; }
+  HIPCHK(h, hipSetDevice(h->device));   // the handle's kernels and streams live on its own GPU, whatever the caller's current device
   JacoStepArgs A{};
   A.model = h->model_dev; A.hull = h->hull_dev; A.qpos = h->qpos; A.qvel = h->qvel; A.qacc_ws = h->qacc_ws;
   A.ctrl = ctrl ? ctrl : h->qvel;   // env modes compute ctrl in-kernel; the pointer only has to be readable
@@ -408,22 +412,26 @@ extern "C" int jaco_set_noise(JacoHandle* h, const float* noise_dev) {
 }
 extern "C" int jaco_get_task_state(JacoHandle* h, float* out_dev, void* stream) {
   if (!h || !out_dev) return JACO_EINVAL;
+  HIPCHK(h, hipSetDevice(h->device));   // the handle's kernels and streams live on its own GPU, whatever the caller's current device
   HIPCHK(h, hipMemcpyAsync(out_dev, h->task_rows, (size_t)h->num_envs * JTASK_N * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return JACO_OK;
 }
 extern "C" int jaco_set_task_state(JacoHandle* h, const float* in_dev, void* stream) {
   if (!h || !in_dev) return JACO_EINVAL;
+  HIPCHK(h, hipSetDevice(h->device));   // the handle's kernels and streams live on its own GPU, whatever the caller's current device
   HIPCHK(h, hipMemcpyAsync(h->task_rows, in_dev, (size_t)h->num_envs * JTASK_N * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return JACO_OK;
 }
 extern "C" int jaco_task_row_floats(void) { return JTASK_N; }
 extern "C" int jaco_get_markers(JacoHandle* h, float* out_dev, void* stream) {
   if (!h || !out_dev) return JACO_EINVAL;
+  HIPCHK(h, hipSetDevice(h->device));   // the handle's kernels and streams live on its own GPU, whatever the caller's current device
   HIPCHK(h, hipMemcpyAsync(out_dev, h->marker, (size_t)h->num_envs * 24 * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return JACO_OK;
 }
 extern "C" int jaco_set_markers(JacoHandle* h, const float* in_dev, void* stream) {
   if (!h || !in_dev) return JACO_EINVAL;
+  HIPCHK(h, hipSetDevice(h->device));   // the handle's kernels and streams live on its own GPU, whatever the caller's current device
   HIPCHK(h, hipMemcpyAsync(h->marker, in_dev, (size_t)h->num_envs * 24 * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return JACO_OK;
 }
@@ -446,21 +454,25 @@ extern "C" int jaco_physics_step_debug(JacoHandle* h, const float* ctrl_dev, int
 
 extern "C" int jaco_get_sensordata(JacoHandle* h, float* out, void* stream) {
   if (!h || !out) return JACO_EINVAL;
+  HIPCHK(h, hipSetDevice(h->device));   // the handle's kernels and streams live on its own GPU, whatever the caller's current device
   HIPCHK(h, hipMemcpyAsync(out, h->sensordata, (size_t)h->num_envs * h->model_host.nsensor * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return JACO_OK;
 }
 extern "C" int jaco_get_flags(JacoHandle* h, uint32_t* out, void* stream) {
   if (!h || !out) return JACO_EINVAL;
+  HIPCHK(h, hipSetDevice(h->device));   // the handle's kernels and streams live on its own GPU, whatever the caller's current device
   HIPCHK(h, hipMemcpyAsync(out, h->flags, (size_t)h->num_envs * sizeof(unsigned), hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return JACO_OK;
 }
 extern "C" int jaco_clear_flags(JacoHandle* h, void* stream) {
   if (!h) return JACO_EINVAL;
+  HIPCHK(h, hipSetDevice(h->device));   // the handle's kernels and streams live on its own GPU, whatever the caller's current device
   HIPCHK(h, hipMemsetAsync(h->flags, 0, (size_t)h->num_envs * sizeof(unsigned), (hipStream_t)stream));
   return JACO_OK;
 }
 extern "C" int jaco_get_stats(JacoHandle* h, int32_t* out, void* stream) {
   if (!h || !out) return JACO_EINVAL;
+  HIPCHK(h, hipSetDevice(h->device));   // the handle's kernels and streams live on its own GPU, whatever the caller's current device
   HIPCHK(h, hipMemcpyAsync(out, h->stats, (size_t)h->num_envs * 4 * sizeof(int), hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return JACO_OK;
 }
