@@ -17,7 +17,7 @@ import torch
 from . import _lib
 from .physics import BatchedMujoco, JacoError
 
-TASK_IDS = {"picking": 0, "placing": 1, "reaching": 2}
+TASK_IDS = {"picking": 0, "placing": 1}   # the tasks that run end to end in the reference
 
 
 class Box:
@@ -39,7 +39,8 @@ class JacoBatchedEnv:
     def __init__(self, num_envs=1, device=0, frame_skip=50, seed=0, **kwargs):
         self.task = kwargs.get("task", "picking")
         if self.task not in TASK_IDS:
-            # the reference's other task branches return 3-tuples that env_mujoco.py:125 cannot unpack
+            # the reference's other task branches (reaching, grasping, ...) return 3-tuples from _get_terminal_inspection
+            # (env_mujoco_util.py:504-536,585-600) that env_mujoco.py:125 cannot unpack: they cannot run there either
             raise NotImplementedError("task %r: only the reference's live tasks picking / placing are supported" % self.task)
         self.n_robots = kwargs.get("n_robots", 1)
         if self.n_robots != 1:
