@@ -47,7 +47,7 @@ struct JacoModelDev {
   // dofs
   int d_body[JNV], d_parent[JNV];
   float d_damping[JNV], d_invweight[JNV];
-  int has_damping;
+  int has_damping;   // 0 none, 1 finger joints only (dofs 6..8: the shared-elimination Euler solve applies), 2 anywhere in block 0
 
   // actuators: force = position ? kp*(clamp(ctrl) - qpos) : ctrl, then clamped (xml:341-349)
   int a_dof[JNU], a_qadr[JNU], a_position[JNU], a_ctrllimited[JNU], a_forcelimited[JNU];

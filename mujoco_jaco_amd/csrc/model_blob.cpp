@@ -112,7 +112,7 @@ int jaco_model_from_blob(const void* buf, size_t size, JacoModelDev* m, std::vec
   }
   for (int d = 0; d < nv; d++) {
     m->d_parent[d] = dpar[d]; m->d_damping[d] = (float)ddamp[d]; m->d_invweight[d] = (float)diw[d];
-    if (ddamp[d] > 0) m->has_damping = 1;
+    if (ddamp[d] > 0) m->has_damping = (d < 6 || m->has_damping == 2) ? 2 : 1;   // 1: only the finger joints (dofs >= 6), see ldl_block0_dual
     if (ddamp[d] > 0 && d >= JB0) FAIL("joint damping outside the arm/finger dof block is not supported by the kernels");
   }
   for (int b = 0; b < nb; b++) {   // the kernels' block-diagonal solves assume this dof layout (one block per kinematic tree)

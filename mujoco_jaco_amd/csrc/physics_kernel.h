@@ -328,6 +328,56 @@ JDEV float ldl_solve_blocks(float (&h)[JNV], float b, int lane, int mask) {
   if (mask & 4) x += ldl_block<JB1, JNV>(h, b, lane);
   return x;
 }
+// Arm/finger block [0, JB0) with implicit joint damping: x = M^-1 b and xd = (M + diag(hd))^-1 b from ONE elimination where
+// the two matrices agree.  hd is non-zero only on the last JB0 - NSH dofs (the finger joints, leaves of the arm's tree), so
+// the first NSH pivots, their multipliers and the forward-substituted right-hand side are identical; only the trailing
+// (JB0 - NSH) x (JB0 - NSH) Schur complement differs (by hd on its diagonal).  Returns x, *xd_out = xd (0 outside the block).
+#define JLDL_NSH 6
+JDEV float ldl_block0_dual(float (&h)[JNV], float b, float hd, int lane, float* xd_out) {
+  float dinv = 1.f;
+#pragma unroll
+  for (int k = 0; k < JLDL_NSH; k++) {
+    float dk = wave_bcast(h[k], k);
+    float inv = 1.f / dk;
+    dinv = lane == k ? inv : dinv;
+    float lik = (lane > k && lane < JB0) ? h[k] * inv : 0.f;
+#pragma unroll
+    for (int j = k + 1; j < JB0; j++) h[j] -= lik * wave_bcast(h[j], k);
+    b -= lik * wave_bcast(b, k);
+  }
+  // trailing block, twice: plain (h, b, dinv) and damped (g, bd, dinvd)
+  float g[JB0 - JLDL_NSH], bd = b, dinvd = dinv;
+#pragma unroll
+  for (int j = JLDL_NSH; j < JB0; j++) g[j - JLDL_NSH] = h[j] + (lane == j ? hd : 0.f);
+#pragma unroll
+  for (int k = JLDL_NSH; k < JB0; k++) {
+    float dk = wave_bcast(h[k], k), dkd = wave_bcast(g[k - JLDL_NSH], k);
+    float inv = 1.f / dk, invd = 1.f / dkd;
+    dinv = lane == k ? inv : dinv;
+    dinvd = lane == k ? invd : dinvd;
+    const bool below = lane > k && lane < JB0;
+    float lik = below ? h[k] * inv : 0.f, likd = below ? g[k - JLDL_NSH] * invd : 0.f;
+#pragma unroll
+    for (int j = k + 1; j < JB0; j++) { h[j] -= lik * wave_bcast(h[j], k); g[j - JLDL_NSH] -= likd * wave_bcast(g[j - JLDL_NSH], k); }
+    b -= lik * wave_bcast(b, k);
+    bd -= likd * wave_bcast(bd, k);
+  }
+  // back-substitution: h[k > lane] = d_lane * L[k][lane] (shared for k < NSH columns... rows < NSH use h for both systems)
+  float z = b * dinv, zd = bd * dinvd, acc = 0.f, accd = 0.f, x = 0.f, xd = 0.f;
+#pragma unroll
+  for (int k = JB0 - 1; k >= 0; k--) {
+    x = lane == k ? z - dinv * acc : x;
+    xd = lane == k ? zd - dinvd * accd : xd;
+    float xk = wave_bcast(x, k), xdk = wave_bcast(xd, k);
+    // multiplier of row k in column `lane`: the damped system's differs only inside the trailing block
+    float mult = lane < k ? h[k] : 0.f;
+    float multd = (lane < k) ? ((k >= JLDL_NSH && lane >= JLDL_NSH) ? g[k - JLDL_NSH] : h[k]) : 0.f;
+    acc += mult * xk;
+    accd += multd * xdk;
+  }
+  *xd_out = lane < JB0 ? xd : 0.f;
+  return lane < JB0 ? x : 0.f;
+}
 // inclusive prefix sum over lanes (6 ds_bpermute steps)
 JDEV int wave_scan_incl(int v, int lane) {
 #pragma unroll
@@ -624,7 +674,7 @@ JDEV void stage_limit_rows(const JacoModelDev* m, L& s, int lane) {
 
 // ---------------------------------------------------------------- stage S: primal Newton solver
 // Lane k < nv owns element k of every dof vector and row k of M / H; lane r owns constraint rows r + 64 q.
-struct NewtonOut { float qacc, qfrc_con; int iters; };
+struct NewtonOut { float qacc, qfrc_con, qdamped; int iters; bool have_qdamped; };
 #define JDAMPED_BLOCKS 1   // implicit joint damping only exists on the finger dofs (block 0); checked by the host loader
 
 // out[q] = sum_k J[row(q)][k] * v[k] for the lane's NR rows; v distributed one element per lane.
@@ -676,12 +726,12 @@ JDEV float jt_vec(const float* J, const float (&f)[NR], int ne, int lane, int nv
 }
 
 template <class L>
-JDEV NewtonOut stage_newton(const JacoModelDev* m, L& s, const float (&mrow)[JNV], float smooth, int lane, JProfCtx& pc) {
+JDEV NewtonOut stage_newton(const JacoModelDev* m, L& s, const float (&mrow)[JNV], float smooth, float hd, int lane, JProfCtx& pc) {
   (void)pc;
   constexpr int NR = L::Caps::NR, MAXEFC = L::Caps::MAXEFC;
   NewtonOut out;
   int nv = m->nv, ne = wave_uniform_i(s.nefc);
-  out.qfrc_con = 0.f; out.iters = 0;
+  out.qfrc_con = 0.f; out.iters = 0; out.qdamped = 0.f; out.have_qdamped = false;
   float h0[JNV];
 #pragma unroll
   for (int j = 0; j < JNV; j++) h0[j] = lane < nv ? mrow[j] : (lane == j ? 1.f : 0.f);
@@ -712,7 +762,14 @@ JDEV NewtonOut stage_newton(const JacoModelDev* m, L& s, const float (&mrow)[JNV
   for (int q = 0; q < NR; q++) rowblk |= blk[q];
   const int rowblocks = (wave_ballot(rowblk & 1) ? 1 : 0) | (wave_ballot(rowblk & 2) ? 2 : 0) | (wave_ballot(rowblk & 4) ? 4 : 0);
   const bool mine = lane < nv && ((lane < JB0 ? 1 : (lane < JB1 ? 2 : 4)) & rowblocks) != 0;
-  float afree = ldl_solve_blocks(h0, smooth, lane, ~rowblocks & 7);
+  float afree;
+  if ((rowblocks & 1) == 0 && m->has_damping == 1) {   // (1: damping on the finger joints only, dofs >= JLDL_NSH)
+    // the arm/finger block carries no row: its acceleration is M^-1 qfrc_smooth, and the Euler step's implicitly damped
+    // (M + h D)^-1 qfrc_smooth comes out of the same elimination (qfrc_constraint is zero on these dofs)
+    afree = ldl_block0_dual(h0, smooth, hd, lane, &out.qdamped);
+    out.have_qdamped = true;
+    afree += ldl_solve_blocks(h0, smooth, lane, ~rowblocks & 6);
+  } else afree = ldl_solve_blocks(h0, smooth, lane, ~rowblocks & 7);
   // Primal problem in terms of qfrc_smooth (same optimum as MuJoCo's (a - a_s)' M (a - a_s) form, no M^-1 needed for
   // the blocks that carry rows):  minimise 1/2 a'Ma - a'qfrc_smooth + sum_i 1/2 D_i min(0, J_i a - aref_i)^2.
   // Start: warm start on the row-carrying blocks (MuJoCo additionally compares it with the unconstrained point; with
@@ -1051,9 +1108,9 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
       wave_sync();
     }
     stage_actuation(m, s, lane);
-    wave_sync();
     JSTAMP(2);
-    // constraint rows first: nothing below is live across the (register-hungry) collision code
+    // constraint rows first: nothing below is live across the (register-hungry) collision code.  (Actuation and the limit
+    // rows touch disjoint LDS arrays: one synchronisation for both.)
     stage_limit_rows(m, s, lane);
     wave_sync();
     JSTAMP(3);
@@ -1085,7 +1142,8 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
     float smooth = lane < nv ? s.smooth[lane] : 0.f;
     float qas = 0.f;   // (qacc_smooth is no longer formed; kept in the dump layout)
     wave_sync();
-    NewtonOut nw = stage_newton(m, s, mrow, smooth, lane, pc);
+    const float hdamp = (m->has_damping && lane < nv) ? m->timestep * m->d_damping[lane] : 0.f;
+    NewtonOut nw = stage_newton(m, s, mrow, smooth, hdamp, lane, pc);
     JSTAMP(6);
     iters = nw.iters & 255;
     int nls_dbg = nw.iters >> 8;
@@ -1097,10 +1155,13 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
     // Euler with implicit joint damping
     float total = smooth + nw.qfrc_con, qacc_e = nw.qacc;
     if (m->has_damping) {   // (M + h D) qacc = total; blocks without damping keep the solver's qacc (M qacc = total there)
-      float hd = lane < nv ? m->timestep * m->d_damping[lane] : 0.f;
+      float qd;
+      if (nw.have_qdamped) qd = nw.qdamped;   // (already solved next to M^-1 qfrc_smooth: the block carried no row)
+      else {
 #pragma unroll
-      for (int j = 0; j < JNV; j++) h[j] = (lane < nv ? mrow[j] : 0.f) + (lane == j ? (lane < nv ? hd : 1.f) : 0.f);
-      float qd = ldl_solve_blocks(h, total, lane, JDAMPED_BLOCKS);
+        for (int j = 0; j < JNV; j++) h[j] = (lane < nv ? mrow[j] : 0.f) + (lane == j ? (lane < nv ? hdamp : 1.f) : 0.f);
+        qd = ldl_solve_blocks(h, total, lane, JDAMPED_BLOCKS);
+      }
       qacc_e = lane < JB0 ? qd : nw.qacc;
     }
     if (A.dbg && env == A.dbg_env && sub == nsub - 1) {
