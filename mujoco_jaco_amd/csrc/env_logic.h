@@ -155,7 +155,10 @@ JDEV float reward_picking(v3 ee, const float* eul, v3 obj, int touch) {
   v3 d = obj - ee;
   float dn = norm(d);
   v3 u = d * (1.f / dn);
-  float pitch = -acosf(u.z), yaw = -acosf(-u.x / sqrtf(1.f - u.z * u.z));
+  // (arguments clamped to [-1, 1]: in fp32 the EE straight above / beside the object puts them an ulp outside in ~3e-4 of
+  // all steps, which numpy's arccos would turn into a NaN reward; the reference's fp64 hits that window ~1e-8 of the time)
+  float pitch = -acosf(fminf(1.f, fmaxf(-1.f, u.z)));
+  float yaw = -acosf(fminf(1.f, fmaxf(-1.f, -u.x / sqrtf(fmaxf(1e-30f, 1.f - u.z * u.z)))));
   // rot_ee^T (0,0,1) with roll = 0: third row of Ry(pitch) Rz(yaw)
   float cpi = cosf(pitch), spi = sinf(pitch), cya = cosf(yaw), sya = sinf(yaw);
   v3 tv = mk3(-spi * cya, spi * sya, -cpi);   // (z already negated: target_vec[2] *= -1)

@@ -33,6 +33,7 @@ struct JacoHandle {
   float* marker = nullptr;    // [num_envs][2][12] poses of the "hand" / "subgoal_reach" markers (mocap bodies the task layer moves)
   unsigned* cost = nullptr;   // per env: shader-clock ticks its last step took (>> 4)
   int* order = nullptr;       // launch order of the env-level light kernel: expensive envs first
+  unsigned* order_ctl = nullptr;   // histogram / cursors / cost sum / bucket reference of the ordering passes
   int schedule = 1;           // option "schedule": 0 = launch envs in index order
   const float* noise = nullptr;
   unsigned long long* prof = nullptr;
@@ -116,6 +117,8 @@ extern "C" int jaco_create(const JacoConfig* cfg, JacoHandle** out) {
   CREATECHK(hipMalloc(&h->marker, B * 24 * sizeof(float)));
   CREATECHK(hipMalloc(&h->cost, B * sizeof(unsigned)));
   CREATECHK(hipMalloc(&h->order, B * sizeof(int)));
+  CREATECHK(hipMalloc(&h->order_ctl, 72 * sizeof(unsigned)));
+  CREATECHK(hipMemset(h->order_ctl, 0, 72 * sizeof(unsigned)));
   CREATECHK(hipMemset(h->cost, 0, B * sizeof(unsigned)));
   CREATECHK(hipMalloc(&h->task_rows, B * JTASK_N * sizeof(float)));
   CREATECHK(hipMalloc(&h->cache, B * JCACHE_N * sizeof(float)));
@@ -158,7 +161,7 @@ extern "C" int jaco_destroy(JacoHandle* h) {
   if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
-  void* ptrs[] = {h->model_dev, h->hull_dev, h->qpos, h->qvel, h->qacc_ws, h->sensordata, h->flags, h->stats, h->dbg, h->prof, h->remaining, h->heavy_list, h->heavy_count, h->task_rows, h->cache, h->cost, h->order, h->marker};
+  void* ptrs[] = {h->model_dev, h->hull_dev, h->qpos, h->qvel, h->qacc_ws, h->sensordata, h->flags, h->stats, h->dbg, h->prof, h->remaining, h->heavy_list, h->heavy_count, h->task_rows, h->cache, h->cost, h->order, h->marker, h->order_ctl};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   delete h;
   return JACO_OK;
@@ -228,51 +231,78 @@ struct EnvIO { int mode = 0; const float* action = nullptr; float* obs = nullptr
 // 1/8 of the mean cost).  An env step is ~1.5 ms of one wavefront and the expensive ones (hull-hull narrowphase, the
 // controller's pseudo-inverse branch) take 2-8x the mean; started last they would leave the chip idle behind them.
 // Costs persist from step to step (contact state, arm configuration), so last step's cost predicts this step's.
-// One workgroup; wave-aggregated LDS atomics.  The order within a bucket is arbitrary: envs are independent.
-__global__ __launch_bounds__(1024) void jaco_order_kernel(const unsigned* cost, int* order, int n) {
-  __shared__ unsigned hist[32], base[32];
-  __shared__ unsigned long long total;
-  const int tid = (int)threadIdx.x, lane = tid & 63;
-  if (tid < 32) hist[tid] = 0;
-  if (tid == 0) total = 0;
+// Two small multi-block passes over the cost array (histogram, then scatter), wave-aggregated global atomics; the bucket
+// width comes from the mean cost of the launch before (one launch stale).  The order within a bucket is arbitrary: envs
+// are independent.  Scratch `oc` (unsigned[72]): [0..31] histogram, [32..63] scatter cursors, [64..65] cost sum of this
+// launch (u64), [66] mean cost used as the bucket reference; [0..65] are zeroed by jaco_prepare_kernel.
+static __device__ __forceinline__ unsigned jaco_cost_bucket(unsigned c, unsigned ref) {
+  unsigned long long q = (unsigned long long)c * 8ull / ref;
+  return q > 31ull ? 31u : (unsigned)q;
+}
+__global__ __launch_bounds__(1024) void jaco_order_hist_kernel(const unsigned* cost, unsigned* oc, int n) {
+  __shared__ unsigned lh[32];
+  __shared__ unsigned long long lsum;
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x), lane = (int)threadIdx.x & 63;
+  if (threadIdx.x < 32) lh[threadIdx.x] = 0u;
+  if (threadIdx.x == 0) lsum = 0ull;
   __syncthreads();
-  unsigned long long loc = 0;
-  for (int i = tid; i < n; i += 1024) loc += cost[i];
-  for (int o = 32; o > 0; o >>= 1) loc += __shfl_xor(loc, o, 64);
-  if (lane == 0) atomicAdd(&total, loc);
-  __syncthreads();
-  const unsigned ref = (unsigned)(total / (unsigned long long)n) + 1u;
-  for (int pass = 0; pass < 2; pass++) {
-    for (int i0 = 0; i0 < n; i0 += 1024) {
-      const int i = i0 + tid;
-      const bool valid = i < n;
-      unsigned b = 0;
-      if (valid) { unsigned long long q = (unsigned long long)cost[i] * 8ull / ref; b = q > 31ull ? 31u : (unsigned)q; }
-      unsigned long long todo = __ballot(valid);
-      while (todo) {   // one atomic per distinct bucket in the wave
-        const int leader = __ffsll((long long)todo) - 1;
-        const unsigned lb = (unsigned)__shfl((int)b, leader, 64);
-        const unsigned long long same = __ballot(valid && b == lb);
-        const int cnt = __popcll(same);
-        unsigned pos = 0;
-        if (lane == leader) pos = pass == 0 ? atomicAdd(&hist[lb], (unsigned)cnt) : atomicAdd(&base[lb], (unsigned)cnt);
-        pos = (unsigned)__shfl((int)pos, leader, 64);
-        if (pass == 1 && valid && b == lb) order[pos + __popcll(same & ((1ull << lane) - 1ull))] = i;
-        todo &= ~same;
-      }
-    }
-    __syncthreads();
-    if (pass == 0 && tid == 0) { unsigned p = 0; for (int b = 31; b >= 0; b--) { base[b] = p; p += hist[b]; } }
-    __syncthreads();
+  const bool valid = i < n;
+  const unsigned ref = oc[66] + 1u;
+  const unsigned c = valid ? cost[i] : 0u;
+  const unsigned b = jaco_cost_bucket(c, ref);
+  unsigned long long sum = c;
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+  if (lane == 0) atomicAdd(&lsum, sum);
+  unsigned long long todo = __ballot(valid);
+  while (todo) {   // one LDS atomic per distinct bucket in the wave
+    const int leader = __ffsll((long long)todo) - 1;
+    const unsigned lb = (unsigned)__shfl((int)b, leader, 64);
+    const unsigned long long same = __ballot(valid && b == lb);
+    if (lane == leader) atomicAdd(&lh[lb], (unsigned)__popcll(same));
+    todo &= ~same;
   }
+  __syncthreads();
+  if (threadIdx.x < 32 && lh[threadIdx.x]) atomicAdd(&oc[threadIdx.x], lh[threadIdx.x]);   // one global atomic per bucket per block
+  if (threadIdx.x == 32) atomicAdd(reinterpret_cast<unsigned long long*>(oc + 64), lsum);
+}
+__global__ __launch_bounds__(1024) void jaco_order_scatter_kernel(const unsigned* cost, unsigned* oc, int* order, int n) {
+  __shared__ unsigned base[32], lh[32], gb[32];
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x), lane = (int)threadIdx.x & 63;
+  if (threadIdx.x < 32) lh[threadIdx.x] = 0u;
+  if (threadIdx.x == 0) { unsigned p = 0; for (int b = 31; b >= 0; b--) { base[b] = p; p += oc[b]; } }   // most expensive bucket first
+  __syncthreads();
+  const bool valid = i < n;
+  const unsigned ref = oc[66] + 1u;
+  const unsigned b = jaco_cost_bucket(valid ? cost[i] : 0u, ref);
+  unsigned off = 0;   // position of this env among the block's members of its bucket
+  unsigned long long todo = __ballot(valid);
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const unsigned lb = (unsigned)__shfl((int)b, leader, 64);
+    const unsigned long long same = __ballot(valid && b == lb);
+    unsigned pos = 0;
+    if (lane == leader) pos = atomicAdd(&lh[lb], (unsigned)__popcll(same));
+    pos = (unsigned)__shfl((int)pos, leader, 64);
+    if (valid && b == lb) off = pos + __popcll(same & ((1ull << lane) - 1ull));
+    todo &= ~same;
+  }
+  __syncthreads();
+  if (threadIdx.x < 32) gb[threadIdx.x] = lh[threadIdx.x] ? base[threadIdx.x] + atomicAdd(&oc[32 + threadIdx.x], lh[threadIdx.x]) : 0u;   // reserve the block's range
+  __syncthreads();
+  if (valid) order[gb[b] + off] = i;
+}
+__global__ void jaco_order_finish_kernel(unsigned* oc, int n) {
+  const unsigned long long total = *reinterpret_cast<unsigned long long*>(oc + 64);
+  oc[66] = (unsigned)(total / (unsigned long long)(n > 0 ? n : 1));
 }
 
 // work-list reset before every launch: counters = {0 appended, 0 claimed, nenv light workgroups to go}, entries = -1;
 // ctl[3] = how many of the launched heavy-tier workers stay resident: about one per two envs the previous launch handed
 // over (an idle worker still occupies a SIMD the light tier could use), at least 16
-__global__ void jaco_prepare_kernel(int* ctl, int* list, int n, int max_workers) {
+__global__ void jaco_prepare_kernel(int* ctl, int* list, int n, int max_workers, unsigned* oc) {
   int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   if (i < n) list[i] = -1;
+  if (i < 66) oc[i] = 0u;
   if (i == 0) {
     int want = 16 + ctl[0] / 2;
     ctl[3] = want < max_workers ? want : max_workers;
@@ -309,10 +339,13 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
   // grid they are resident from the beginning (a heavy wave needs a SIMD of its own and would otherwise starve behind the
   // light grid, leaving a serial tail of several ms per env step).  The drain launch that follows in stream order
   // serves whatever the workers did not (all of it when concurrency is off).
-  hipLaunchKernelGGL(jaco_prepare_kernel, dim3((unsigned)((h->num_envs + 255) / 256)), dim3(256), 0, st, h->heavy_count, h->heavy_list, h->num_envs, h->workers);
+  hipLaunchKernelGGL(jaco_prepare_kernel, dim3((unsigned)((h->num_envs + 255) / 256)), dim3(256), 0, st, h->heavy_count, h->heavy_list, h->num_envs, h->workers, h->order_ctl);
   HIPCHK(h, hipGetLastError());
   if (reorder) {
-    hipLaunchKernelGGL(jaco_order_kernel, dim3(1), dim3(1024), 0, st, h->cost, h->order, h->num_envs);
+    const unsigned ob = (unsigned)((h->num_envs + 1023) / 1024);
+    hipLaunchKernelGGL(jaco_order_hist_kernel, dim3(ob), dim3(1024), 0, st, h->cost, h->order_ctl, h->num_envs);
+    hipLaunchKernelGGL(jaco_order_scatter_kernel, dim3(ob), dim3(1024), 0, st, h->cost, h->order_ctl, h->order, h->num_envs);
+    hipLaunchKernelGGL(jaco_order_finish_kernel, dim3(1), dim3(1), 0, st, h->order_ctl, h->num_envs);
     HIPCHK(h, hipGetLastError());
     A.order = h->order;
   }

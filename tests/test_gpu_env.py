@@ -214,3 +214,24 @@ def test_frame_skip4_with_termination_masking(model_arrays, names):
         if s == 1:
             assert done[::2].all() and not done[1::2].any() and (rew[::2] < -9).all()
             frozen_q = qn.copy()
+
+
+def test_launch_order_does_not_change_results():
+    """The cost-ordered launch (a permutation of the envs built on the device every step) must step every env exactly
+    once: identical states and observations with the ordering on and off, for a batch large enough to enable it."""
+    from mujoco_jaco_amd.env import JacoBatchedEnv
+    B = 8192
+    outs = []
+    for schedule in (1, 0):
+        env = JacoBatchedEnv(num_envs=B, task="picking", seed=21)
+        env.sim.set_option("schedule", schedule)
+        env.reset()
+        gen = torch.Generator(device=env.device); gen.manual_seed(5)
+        for s in range(4):
+            a = torch.rand(B, 7, device=env.device, generator=gen) * 2 - 1
+            obs, rew, done, _ = env.step(a)
+        q, v, _ = env.sim.get_state()
+        outs.append((q.clone(), v.clone(), obs.clone(), rew.clone(), done.clone()))
+        del env
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
