@@ -93,8 +93,8 @@ int jaco_get_stats(JacoHandle* h, int32_t* out_dev, void* stream);
 
 /* ---- env level: JacoMujocoEnv.reset / step (env_script/env_mujoco.py:99-139), batched -------------------------
  * jaco_reset: _reset (env_mujoco_util.py:92-174) for the envs whose mask byte is non-zero (NULL = all): counter-based
- *   RNG draws of the per-task initial state (Appendix A of SURVEY.md), sim.forward(), then _get_observation for every
- *   env into obs_dev [num_envs][26].  Task `placing` runs jaco_placing_hold(mask, 150) between the draws and the observation.
+ *   RNG draws of the per-task initial state (Appendix A of SURVEY.md), sim.forward(), then _get_observation for those
+ *   envs into their rows of obs_dev [num_envs][26] (rows of the other envs are left as they are).  Task `placing` runs jaco_placing_hold(mask, 150) between the draws and the observation.
  * jaco_placing_hold: the object part of the placing reset (env_mujoco_util.py:106-117): object to the grasp frame EE_obj
  *   (4 cm back along its x axis), EE target = current EE pose, then nsub x { OSC torque from the current state's M, J, bias
  *   (each iteration follows a sim.forward()), sim.step() with gripper command 0.6, set_obj_xyz: object re-pinned, velocities

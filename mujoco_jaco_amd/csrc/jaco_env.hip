@@ -430,8 +430,9 @@ extern "C" int jaco_reset(JacoHandle* h, const uint8_t* mask_dev, float* obs_dev
     int rc = jaco_placing_hold(h, mask_dev, JACO_PLACING_HOLD_SUBSTEPS, stream);
     if (rc) return rc;
   }
-  // sim.forward() + _get_observation for every env (unmasked envs recompute the same cache and observation)
-  return jaco_forward(h, obs_dev, stream);
+  // sim.forward() + _get_observation for the reset envs (the others keep their observation row and controller cache)
+  EnvIO io; io.mode = 2; io.obs = obs_dev; io.mask = mask_dev;
+  return launch_step(h, nullptr, 1, st, nullptr, -1, io);
 }
 extern "C" int jaco_step(JacoHandle* h, const float* action_dev, float* obs_dev, float* reward_dev, uint8_t* done_dev, void* stream) {
   if (!h || !action_dev || !obs_dev || !reward_dev || !done_dev) return JACO_EINVAL;

@@ -82,7 +82,7 @@ struct JacoStepArgs {
   // env-level mode (jaco_step / jaco_reset): nsub = frame_skip
   int env_mode;              // 0 ctrl-level, 1 env step, 2 forward only (reset: fill cache + observation),
                              // 3 placing reset: nsub controlled substeps with the object pinned in the hand (env_mujoco_util.py:106-117)
-  const unsigned char* mask; // mode 3: envs to run (nullptr = all)
+  const unsigned char* mask; // modes 2 and 3: envs to run (nullptr = all)
   float* marker;             // [nenv][2][12] poses (position, rotation) of the "hand" / "subgoal_reach" markers, or nullptr = XML rest pose
   int task_id, nact;
   unsigned long long seed;
@@ -969,7 +969,7 @@ template <class C, bool LIGHT>
 JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int lane, bool handback = false) {
   const JacoModelDev* m = opaque_ptr(A.model);
   const int nq = m->nq, nv = m->nv, nu = m->nu, ns = m->nsensor;
-  if (A.env_mode == 3 && A.mask && !A.mask[env]) return 0;
+  if ((A.env_mode == 3 || A.env_mode == 2) && A.mask && !A.mask[env]) return 0;   // masked reset: the other envs are not touched
   if (lane < nq) s.qpos[lane] = A.qpos[(size_t)env * nq + lane];
   if (lane < nv) { s.qvel[lane] = A.qvel[(size_t)env * nv + lane]; s.qacc_ws[lane] = A.qacc_ws[(size_t)env * nv + lane]; }
   if (lane < nu) s.ctrl[lane] = A.ctrl[(size_t)env * nu + lane];
@@ -1011,8 +1011,12 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
           const float* tg = s.task + JT_TARGET;
           v3 mp = km == 0 ? ld3(tg) : mk3(spos[0], spos[1], spos[2]);
           m3 MR = euler_rxyz_to_mat(km == 0 ? tg[3] : sori[0], km == 0 ? tg[4] : sori[1], km == 0 ? tg[5] : sori[2]);
+          // write-through: if this env is handed to a heavy-tier workgroup later in the step, that workgroup (possibly on
+          // another XCD) reads the pose from memory
           float* P = A.marker + (size_t)env * 24 + 12 * km;
-          st3(P, mp); stm(P + 3, MR);
+          st_wt(P + 0, mp.x); st_wt(P + 1, mp.y); st_wt(P + 2, mp.z);
+#pragma unroll
+          for (int k = 0; k < 9; k++) st_wt(P + 3 + k, MR.m[k]);
         }
       }
       if (lane == 0) s.task[JT_RNG] = __uint_as_float(cnt0 + 6u);
@@ -1041,7 +1045,7 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
       float pin[7] = {po.x, po.y, po.z, q[0], q[1], q[2], q[3]};
 #pragma unroll
       for (int k = 0; k < 7; k++) if (lane == 9 + k) pinv = pin[k];
-      if (lane >= 9 && lane < 16) PIN[lane - 9] = pinv;
+      if (lane >= 9 && lane < 16) st_wt(&PIN[lane - 9], pinv);   // (write-through: read back by the heavy tier after a hand-off)
       if (lane == 0) {
         float* t = s.task;
         t[JT_TARGET + 0] = pe.x; t[JT_TARGET + 1] = pe.y; t[JT_TARGET + 2] = pe.z;
