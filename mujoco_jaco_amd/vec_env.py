@@ -1,0 +1,57 @@
+"""Learner-side adapter: the batched env behind the vectorised-env protocol that SB-style loops
+drive (the reference trains through `model.learn(...)` on a single `JacoMujocoEnv`, main.py:172-178).
+
+`JacoVecEnv.step(actions)` returns `(obs [B,26], rewards [B], dones [B], infos)`; envs that finished are reset inside the
+call (masked `jaco_reset`), their returned observation is the first one of the new episode and the last observation of
+the finished episode is kept in `infos["terminal_observation"]` rows, as SB's VecEnv does.  Everything stays on the GPU
+(`torch` tensors); `to_numpy=True` copies the four outputs to host arrays for learners that want numpy.
+"""
+import torch
+
+from .env import JacoBatchedEnv
+
+
+class JacoVecEnv:
+    def __init__(self, num_envs, to_numpy=False, **kwargs):
+        assert int(num_envs) >= 2, "the vectorised adapter is for batches; JacoBatchedEnv(num_envs=1) is the reference's single-env surface"
+        self.env = JacoBatchedEnv(num_envs=num_envs, **kwargs)
+        self.num_envs = int(num_envs)
+        self.observation_space, self.action_space = self.env.observation_space, self.env.action_space
+        self.to_numpy = bool(to_numpy)
+        self._actions = None
+        self.episode_returns = torch.zeros(self.num_envs, device=self.env.device)
+        self.episode_lengths = torch.zeros(self.num_envs, dtype=torch.int64, device=self.env.device)
+
+    def _out(self, *ts):
+        return tuple(t.cpu().numpy() for t in ts) if self.to_numpy else ts
+
+    def reset(self):
+        self.episode_returns.zero_(); self.episode_lengths.zero_()
+        obs = self.env.reset()
+        return self._out(obs.clone())[0]
+
+    def step_async(self, actions):
+        self._actions = actions
+
+    def step_wait(self):
+        obs, rew, done, _ = self.env.step(self._actions)
+        obs, rew, done = obs.clone(), rew.clone(), done.clone()
+        self.episode_returns += rew; self.episode_lengths += 1
+        infos = {"terminal_observation": None, "episode_return": None, "episode_length": None, "is_success": None}
+        if bool(done.any()):
+            infos["terminal_observation"] = obs[done].clone()
+            infos["episode_return"] = self.episode_returns[done].clone()
+            infos["episode_length"] = self.episode_lengths[done].clone()
+            infos["is_success"] = self.env.task_state()[:, 29][done] > 0.5   # JT_SUCC of the terminal step
+            new_obs = self.env.reset(done)
+            obs[done] = new_obs[done]
+            self.episode_returns[done] = 0; self.episode_lengths[done] = 0
+        o, r, d = self._out(obs, rew, done)
+        return o, r, d, infos
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    def close(self):
+        self.env.close()

@@ -235,3 +235,24 @@ def test_launch_order_does_not_change_results():
         del env
     for x, y in zip(*outs):
         assert torch.equal(x, y)
+
+
+def test_vec_env_adapter_autoreset():
+    """Learner-side adapter: SB-style step() with in-call reset of finished envs, terminal observation kept in infos."""
+    from mujoco_jaco_amd.vec_env import JacoVecEnv
+    B = 64
+    venv = JacoVecEnv(B, task="picking", frame_skip=2, seed=9)
+    obs0 = venv.reset()
+    assert obs0.shape == (B, 26) and torch.isfinite(obs0).all()
+    t = venv.env.task_state(); t[:16, 1] = 698; venv.env.set_task_state(t)      # 16 envs one step before the time-out
+    z = torch.zeros(B, 7)
+    o, r, d, info = venv.step(z); assert not d.any() and info["terminal_observation"] is None
+    o, r, d, info = venv.step(z)
+    assert d[:16].all() and not d[16:].any() and (r[:16] < -9).all()
+    assert info["terminal_observation"].shape == (16, 26) and not info["is_success"].any()
+    assert (info["episode_length"] == 2).all()
+    t = venv.env.task_state()
+    assert (t[:16, 1] == 0).all() and (t[16:, 1] == 2).all()                   # counters of the reset envs start over
+    assert torch.isfinite(o).all() and (o[:16, 7] + 1).abs().max() < 1e-6       # fresh episodes: gripper command back at 0.6
+    o2, r2, d2, _ = venv.step(z); assert not d2.any()                           # ... and they run again
+    venv.close()
