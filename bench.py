@@ -164,7 +164,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "jaco_physics_kernel", "kernel_ms": kern_ms, "launches": launches,
                          "algorithmic_bytes_per_env_launch": bytes_per_env,
-                         "note": "latency/occupancy-bound by design (SURVEY 8d): algorithmic traffic is ~1 KB per env per launch"},
+                         "note": "latency/occupancy-bound by design (SURVEY 8d): algorithmic traffic is ~1 KB per env per launch; `traffic` = L2 fabric-side bytes per launch from profiles/r01_pmc_traffic.json (FETCH_SIZE + WRITE_SIZE, Infinity-Cache hits included): 95 % of it are register-spill lines (6 MB per XCD against a 4 MB L2) cycling between L2 and the Infinity Cache, the env state is 0.1 GB"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.model, fs)
