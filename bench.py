@@ -47,7 +47,7 @@ def cpu_baseline(model, frame_skip, budget_s=15.0):
         done += nenv * nsub
     dt = time.time() - t
     return {"value": done / dt / frame_skip, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": "%d envs x %d substeps of the same workload, fp64 C oracle, OpenMP over %d threads, %.1f s; frame_skip %d"
+            "sample": "%d envs x %d physics substeps of the same workload (random torques; the controller / observation glue is not timed), fp64 C oracle, OpenMP over %d threads, %.1f s; frame_skip %d"
                       % (nenv, done // nenv, cores, dt, frame_skip)}
 
 
