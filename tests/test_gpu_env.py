@@ -256,3 +256,37 @@ def test_vec_env_adapter_autoreset():
     assert torch.isfinite(o).all() and (o[:16, 7] + 1).abs().max() < 1e-6       # fresh episodes: gripper command back at 0.6
     o2, r2, d2, _ = venv.step(z); assert not d2.any()                           # ... and they run again
     venv.close()
+
+
+def test_markers_follow_take_action(model_arrays):
+    """set_mocap_xyz / set_mocap_orientation of _take_action (env_mujoco_util.py:613-615,644-646): after a step the "hand" marker
+    sits at the new EE target, the "subgoal_reach" marker at the rule-based sub-goal; reset parks both at their XML pose."""
+    import glue
+    from mujoco_jaco_amd.env import JacoBatchedEnv
+    B = 8
+    env = JacoBatchedEnv(num_envs=B, task="picking", seed=4)
+    nz = np.random.default_rng(1).uniform(size=(B, 12)).astype(np.float32)
+    env.set_noise(torch.tensor(nz))
+    env.reset()
+    rest = env.markers().cpu().numpy()
+    assert np.allclose(rest[:, :, 2], -0.15) and np.allclose(rest[:, :, 3:], np.tile(np.eye(3).reshape(-1), (B, 2, 1)))   # xml:52,72
+    obs0 = env.make_observation().cpu().numpy()
+    a = np.random.default_rng(2).uniform(-1, 1, (B, 7)).astype(np.float32)
+    env.step(torch.tensor(a))
+    mk = env.markers().cpu().numpy()
+    t = env.task_state().cpu().numpy()
+    for k in range(B):
+        target = t[k, 10:16]
+        assert np.abs(mk[k, 0, :3] - target[:3]).max() < 1e-6
+        R = glue.quat_to_mat(glue.quat_from_euler(*target[3:6]))
+        assert np.abs(mk[k, 0, 3:].reshape(3, 3) - R).max() < 1e-5
+        # sub-goal marker: the rule-based sub-goal of the pre-step observation state with the first six draws
+        ee = obs0[k, 1:4].astype(np.float64); obj = obs0[k, 8:11].astype(np.float64)
+        spos, sori = glue.rulebased_subgoal("picking", ee, t[k, 4:7].astype(np.float64), obj[1], t[k, 7:10].astype(np.float64), nz[k, :6].astype(np.float64))
+        assert np.abs(mk[k, 1, :3] - spos).max() < 1e-5
+        assert np.abs(mk[k, 1, 3:].reshape(3, 3) - glue.quat_to_mat(glue.quat_from_euler(*sori))).max() < 1e-4
+    m2 = torch.tensor(mk); m2[:, 0, 0] += 0.5
+    env.set_markers(m2)
+    assert torch.equal(env.markers().cpu(), m2)
+    env.reset()
+    assert np.array_equal(env.markers().cpu().numpy(), rest)
