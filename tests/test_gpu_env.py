@@ -217,24 +217,31 @@ def test_frame_skip4_with_termination_masking(model_arrays, names):
 
 
 def test_launch_order_does_not_change_results():
-    """The cost-ordered launch (a permutation of the envs built on the device every step) must step every env exactly
-    once: identical states and observations with the ordering on and off, for a batch large enough to enable it."""
+    """The cost-ordered launch (a permutation of the envs built on the device every step) and the concurrent heavy tier
+    (hand-off between workgroups on different XCDs, tier alternation) must not change any result: identical states and
+    outputs with both on and both off, for a batch large enough to enable them.  Small actions keep the "hand" marker's
+    sticks on the EE's sticks, which sends several per cent of the envs through the hand-off every step."""
     from mujoco_jaco_amd.env import JacoBatchedEnv
     B = 8192
-    outs = []
-    for schedule in (1, 0):
-        env = JacoBatchedEnv(num_envs=B, task="picking", seed=21)
-        env.sim.set_option("schedule", schedule)
-        env.reset()
-        gen = torch.Generator(device=env.device); gen.manual_seed(5)
-        for s in range(4):
-            a = torch.rand(B, 7, device=env.device, generator=gen) * 2 - 1
-            obs, rew, done, _ = env.step(a)
-        q, v, _ = env.sim.get_state()
-        outs.append((q.clone(), v.clone(), obs.clone(), rew.clone(), done.clone()))
-        del env
-    for x, y in zip(*outs):
-        assert torch.equal(x, y)
+    for scale in (1.0, 0.05):
+        outs, heavy = [], 0
+        for on in (1, 0):
+            env = JacoBatchedEnv(num_envs=B, task="picking", seed=21)
+            env.sim.set_option("schedule", on); env.sim.set_option("concurrent_heavy", on)
+            env.reset()
+            gen = torch.Generator(device=env.device); gen.manual_seed(5)
+            for s in range(4):
+                a = (torch.rand(B, 7, device=env.device, generator=gen) * 2 - 1) * scale
+                if s == 3: env.sim.clear_flags()
+                obs, rew, done, _ = env.step(a)
+            q, v, _ = env.sim.get_state()
+            heavy = max(heavy, int(((env.sim.flags() & 32) != 0).sum()))
+            outs.append((q.clone(), v.clone(), obs.clone(), rew.clone(), done.clone()))
+            del env
+        for x, y in zip(*outs):
+            assert torch.equal(x, y)
+        if scale < 1.0:
+            assert heavy > B // 200          # the hand-off path really was exercised
 
 
 def test_vec_env_adapter_autoreset():
