@@ -1,14 +1,15 @@
 import sys, torch
 sys.path.insert(0, "/root/repo")
 from mujoco_jaco_amd.env import JacoBatchedEnv
-B = 8192
+import os
+B = int(os.environ.get('PERM_B', 8192)); SCALE = float(os.environ.get('PERM_SCALE', 1.0))
 def run(schedule, conc=1):
     env = JacoBatchedEnv(num_envs=B, task="picking", seed=21)
     env.sim.set_option("schedule", schedule); env.sim.set_option("concurrent_heavy", conc)
     env.reset()
     gen = torch.Generator(device=env.device); gen.manual_seed(5)
     for s in range(4):
-        a = torch.rand(B, 7, device=env.device, generator=gen) * 2 - 1
+        a = (torch.rand(B, 7, device=env.device, generator=gen) * 2 - 1) * SCALE
         obs, rew, done, _ = env.step(a)
     q, v, _ = env.sim.get_state()
     return q.clone(), obs.clone(), env.sim.flags().clone(), v.clone(), rew.clone(), done.clone()

@@ -15,7 +15,8 @@ for opt in ("heavy_workers", "tier_return", "concurrent_heavy"):
     if "--" + opt in sys.argv: env.set_option(opt, float(sys.argv[sys.argv.index("--" + opt) + 1]))
 genv.reset()
 gen = torch.Generator(device=dev); gen.manual_seed(2000)
-actions = [torch.rand(B, 7, device=dev, generator=gen) * 2 - 1 for _ in range(4)]
+scale = float(sys.argv[sys.argv.index("--action-scale") + 1]) if "--action-scale" in sys.argv else 1.0
+actions = [(torch.rand(B, 7, device=dev, generator=gen) * 2 - 1) * scale for _ in range(4)]
 tot = 0.0
 for i in range(n):
     env.clear_flags()
