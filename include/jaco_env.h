@@ -36,7 +36,7 @@ extern "C" {
 #define JACO_FLAG_CAND_OVERFLOW 4u  /* more broadphase survivors than the candidate buffer */
 #define JACO_FLAG_NAN 8u            /* non-finite velocity: env should be reset */
 #define JACO_FLAG_SOLVER_MAXITER 16u
-#define JACO_FLAG_HEAVY_TIER 32u     /* informational: stepped by the 256-row tier at least once (not an error) */
+#define JACO_FLAG_HEAVY_TIER 32u     /* informational: stepped by the 128- or 256-row tier at least once (not an error) */
 #define JACO_FLAG_TIER_RETURN 128u   /* informational: the heavy tier gave the env back to the light code in mid-step (overflow was transient) */
 #define JACO_FLAG_OSC_SINGULAR 64u   /* informational: |det(J M^-1 J^T)| < 1e-3, the controller used its pseudo-inverse branch */
 
@@ -127,7 +127,7 @@ int jaco_set_frame_skip(JacoHandle* h, int frame_skip);
 /* Solver / collision options, MuJoCo <option> names: "iterations", "tolerance", "ls_iterations",
  * "disable_contact" (contact flag), "mpr_iterations", "mpr_tolerance".
  * Execution options (no effect on results): "schedule" (1: launch expensive envs first), "concurrent_heavy" (1: heavy-tier
- * workgroups resident next to the light grid), "heavy_workers" (their maximum, default 192; the resident number follows the previous step's hand-overs), "tier_return" (1: a heavy-tier
+ * workgroups resident next to the light grid), "heavy_workers" (their maximum, default 512; the resident number follows the previous step's hand-overs), "tier_return" (1: a heavy-tier
  * env goes back to the light code when its overflow is over). */
 int jaco_set_option(JacoHandle* h, const char* name, double value);
 

@@ -25,10 +25,11 @@ struct JacoHandle {
   float *qpos = nullptr, *qvel = nullptr, *qacc_ws = nullptr, *sensordata = nullptr, *dbg = nullptr;
   unsigned* flags = nullptr;
   int* stats = nullptr;
-  int *remaining = nullptr, *heavy_list = nullptr, *heavy_count = nullptr;   // heavy_count[0..2]: appended, claimed, light workgroups left
+  int *remaining = nullptr, *heavy_list = nullptr, *heavy_count = nullptr;   // heavy_count[0..4]: appended, claimed, light workgroups left, resident workers, passed on to the heavy tier
+  int* heavy2_list = nullptr;   // envs the medium tier passed on to the heavy tier
   hipStream_t side = nullptr;                 // heavy-tier workers run here, concurrently with the light tier
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  int concurrent = 1, workers = 192, tier_return = 1;           // options "concurrent_heavy", "heavy_workers"
+  int concurrent = 1, workers = 512, tier_return = 1;           // options "concurrent_heavy", "heavy_workers"
   float *task_rows = nullptr, *cache = nullptr;
   float* marker = nullptr;    // [num_envs][2][12] poses of the "hand" / "subgoal_reach" markers (mocap bodies the task layer moves)
   unsigned* cost = nullptr;   // per env: shader-clock ticks its last step took (>> 4)
@@ -104,8 +105,9 @@ extern "C" int jaco_create(const JacoConfig* cfg, JacoHandle** out) {
   CREATECHK(hipMalloc(&h->dbg, JDBG_SIZE * sizeof(float)));
   CREATECHK(hipMalloc(&h->remaining, B * sizeof(int)));
   CREATECHK(hipMalloc(&h->heavy_list, B * sizeof(int)));
-  CREATECHK(hipMalloc(&h->heavy_count, 4 * sizeof(int)));
-  CREATECHK(hipMemset(h->heavy_count, 0, 4 * sizeof(int)));
+  CREATECHK(hipMalloc(&h->heavy_count, 8 * sizeof(int)));
+  CREATECHK(hipMemset(h->heavy_count, 0, 8 * sizeof(int)));
+  CREATECHK(hipMalloc(&h->heavy2_list, B * sizeof(int)));
   {
     int lo = 0, hi = 0;
     CREATECHK(hipDeviceGetStreamPriorityRange(&lo, &hi));   // (hi = numerically lowest = highest priority)
@@ -161,7 +163,7 @@ extern "C" int jaco_destroy(JacoHandle* h) {
   if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
-  void* ptrs[] = {h->model_dev, h->hull_dev, h->qpos, h->qvel, h->qacc_ws, h->sensordata, h->flags, h->stats, h->dbg, h->prof, h->remaining, h->heavy_list, h->heavy_count, h->task_rows, h->cache, h->cost, h->order, h->marker, h->order_ctl};
+  void* ptrs[] = {h->model_dev, h->hull_dev, h->qpos, h->qvel, h->qacc_ws, h->sensordata, h->flags, h->stats, h->dbg, h->prof, h->remaining, h->heavy_list, h->heavy_count, h->task_rows, h->cache, h->cost, h->order, h->marker, h->order_ctl, h->heavy2_list};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   delete h;
   return JACO_OK;
@@ -297,16 +299,16 @@ __global__ void jaco_order_finish_kernel(unsigned* oc, int n) {
 }
 
 // work-list reset before every launch: counters = {0 appended, 0 claimed, nenv light workgroups to go}, entries = -1;
-// ctl[3] = how many of the launched heavy-tier workers stay resident: about one per two envs the previous launch handed
-// over (an idle worker still occupies a SIMD the light tier could use), at least 16
+// ctl[3] = how many of the launched medium-tier workers stay resident: about one per ten envs the previous launch handed
+// over (a worker serves an env in ~1/20 of a step; an idle one still holds LDS the light tier could use), at least 16
 __global__ void jaco_prepare_kernel(int* ctl, int* list, int n, int max_workers, unsigned* oc) {
   int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   if (i < n) list[i] = -1;
   if (i < 66) oc[i] = 0u;
   if (i == 0) {
-    int want = 16 + ctl[0] / 2;
+    int want = 16 + ctl[0] / 10;
     ctl[3] = want < max_workers ? want : max_workers;
-    ctl[0] = 0; ctl[1] = 0; ctl[2] = n;
+    ctl[0] = 0; ctl[1] = 0; ctl[2] = n; ctl[4] = 0;
   }
 }
 
@@ -318,7 +320,7 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
   A.ctrl = ctrl ? ctrl : h->qvel;   // env modes compute ctrl in-kernel; the pointer only has to be readable
   A.sensordata = h->sensordata; A.flags = h->flags; A.stats = h->stats; A.nenv = h->num_envs; A.nsub = nsub;
   A.disable_contact = h->disable_contact; A.no_tier_return = !h->tier_return; A.dbg = dbg; A.dbg_env = dbg_env; A.prof = h->prof;
-  A.remaining = h->remaining; A.heavy_list = h->heavy_list; A.heavy_count = h->heavy_count; A.heavy_taken = h->heavy_count + 1; A.light_left = h->heavy_count + 2; A.worker_limit = h->heavy_count + 3;
+  A.remaining = h->remaining; A.heavy_list = h->heavy_list; A.heavy_count = h->heavy_count; A.heavy_taken = h->heavy_count + 1; A.light_left = h->heavy_count + 2; A.worker_limit = h->heavy_count + 3; A.heavy2_count = h->heavy_count + 4; A.heavy2_list = h->heavy2_list;
   A.env_mode = io.mode; A.task_id = h->task; A.nact = h->task == JACO_TASK_REACHING ? 6 : 7; A.seed = h->seed;
   A.task = h->task_rows; A.cache = h->cache; A.action = io.action; A.noise = h->noise; A.obs = io.obs; A.reward = io.reward; A.done = io.done; A.mask = io.mask; A.marker = h->marker;
   A.cost = h->cost;
@@ -334,11 +336,12 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
     ev = &h->events[h->events_used++];
     HIPCHK(h, hipEventRecord(ev->first, st));
   }
-  // Light tier for every env.  An env that overflows the light capacities is handed over (work list) to the heavy tier,
-  // whose few persistent workgroups run concurrently on a second, higher-priority stream: started just before the light
-  // grid they are resident from the beginning (a heavy wave needs a SIMD of its own and would otherwise starve behind the
-  // light grid, leaving a serial tail of several ms per env step).  The drain launch that follows in stream order
-  // serves whatever the workers did not (all of it when concurrency is off).
+  // Light tier for every env.  An env that overflows the light capacities is handed over (work list) to the medium tier,
+  // whose persistent workgroups run concurrently on a second, higher-priority stream: started just before the light grid
+  // they are resident from the beginning (a bigger workgroup needs more LDS than a finishing light workgroup frees and
+  // would otherwise starve behind the light grid, leaving a serial tail of several ms per env step).  The medium drain
+  // that follows in stream order serves whatever the workers did not (all of it when concurrency is off: a full grid,
+  // which is also what carries the load when most envs overflow); the heavy drain serves what outgrew the medium tier.
   hipLaunchKernelGGL(jaco_prepare_kernel, dim3((unsigned)((h->num_envs + 255) / 256)), dim3(256), 0, st, h->heavy_count, h->heavy_list, h->num_envs, h->workers, h->order_ctl);
   HIPCHK(h, hipGetLastError());
   if (reorder) {
@@ -353,14 +356,16 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
   if (conc) {
     HIPCHK(h, hipEventRecord(h->ev_fork, st));
     HIPCHK(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
-    hipLaunchKernelGGL(jaco_physics_kernel_heavy, dim3((unsigned)h->workers), dim3(64), 0, h->side, A);
+    hipLaunchKernelGGL(jaco_physics_kernel_medium, dim3((unsigned)h->workers), dim3(64), 0, h->side, A);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(h->ev_join, h->side));
   }
   hipLaunchKernelGGL(jaco_physics_kernel, dim3((unsigned)h->num_envs), dim3(64), 0, st, A);
   HIPCHK(h, hipGetLastError());
   if (conc) HIPCHK(h, hipStreamWaitEvent(st, h->ev_join, 0));
-  unsigned hg = (unsigned)(h->num_envs < 1024 ? h->num_envs : 1024);
+  unsigned mg = (unsigned)(h->num_envs < 1280 ? h->num_envs : 1280), hg = (unsigned)(h->num_envs < 1024 ? h->num_envs : 1024);
+  hipLaunchKernelGGL(jaco_physics_kernel_medium_drain, dim3(mg), dim3(64), 0, st, A);
+  HIPCHK(h, hipGetLastError());
   hipLaunchKernelGGL(jaco_physics_kernel_heavy_drain, dim3(hg), dim3(64), 0, st, A);
   HIPCHK(h, hipGetLastError());
   if (ev) HIPCHK(h, hipEventRecord(ev->second, st));

@@ -17,15 +17,17 @@
 #include <jaco/model_dev.h>
 #include <jaco/wave_ops.h>
 
-// Two capacity tiers of the same kernel (DESIGN.md "Two tiers"):
+// Three capacity tiers of the same kernel (DESIGN.md "Tiers"):
 //   light: <= 64 rows / 32 contacts / 64 candidates -> 1 constraint row per lane, ~17 KB LDS, the common case;
-//   heavy: <= 256 rows / 64 contacts / 128 candidates -> 4 rows per lane, ~39 KB LDS, for envs that overflow light.
+//   medium: <= 128 rows / 48 contacts -> 2 rows per lane, ~28 KB LDS, for envs that overflow light (marker-stick contacts);
+//   heavy: <= 256 rows / 64 contacts -> 4 rows per lane, ~43 KB LDS, for envs that overflow medium.
 // A light wave that meets an overflow hands its env (state untouched for that substep) to the heavy launch.
 template <int MAXEFC_, int MAXCON_, int MAXCAND_>
 struct JacoCaps {
   static constexpr int MAXEFC = MAXEFC_, MAXCON = MAXCON_, MAXCAND = MAXCAND_, NR = MAXEFC_ / 64;
 };
 typedef JacoCaps<64, 32, 128> JacoLight;   // (candidates = bounding-sphere survivors: closed fingers alone contribute > 64)
+typedef JacoCaps<128, 48, 128> JacoMedium;  // 2 rows per lane: the EE axis sticks resting on the "hand" marker's sticks add ~36 rows to the usual 32
 typedef JacoCaps<256, 64, 256> JacoHeavy;
 #define JDBG_MAXCON 64
 #define JDBG_MAXEFC 256
@@ -74,6 +76,8 @@ struct JacoStepArgs {
   int* remaining;      // [nenv] substeps left for the heavy tier (written by the light tier)
   int* heavy_list;     // [nenv] env ids handed to the heavy tier
   int* heavy_count;    // [1] entries appended to heavy_list
+  int* heavy2_list;    // [nenv] env ids the medium tier handed on to the heavy tier
+  int* heavy2_count;   // [1]
   int* heavy_taken;    // [1] entries claimed by heavy-tier workgroups
   int* light_left;     // [1] light-tier workgroups still running (0: no further entries will appear)
   const int* worker_limit;  // [1] heavy-tier workers beyond this index leave at once (sized from the previous launch's hand-overs), or nullptr
@@ -965,8 +969,12 @@ JDEV void stage_integrate_pos(const JacoModelDev* m, L& s, int lane) {
 
 // ---------------------------------------------------------------- the kernels
 // One substep loop for one env; returns the number of substeps NOT done (light tier bail-out) or 0.
-template <class C, bool LIGHT>
-JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int lane, bool handback = false) {
+// TIER: 0 light, 1 medium, 2 heavy.  Tiers below 2 stop at a capacity overflow (*why = 1) and leave the env to the next tier;
+// tiers above 0 can give the env back to the light code once it would fit again (handback; *why = 2).
+template <class C, int TIER>
+JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int lane, bool handback = false, int* why = nullptr) {
+  constexpr bool LIGHT = TIER == 0;
+  bool bailed = false;
   const JacoModelDev* m = opaque_ptr(A.model);
   const int nq = m->nq, nv = m->nv, nu = m->nu, ns = m->nsensor;
   if ((A.env_mode == 3 || A.env_mode == 2) && A.mask && !A.mask[env]) return 0;   // masked reset: the other envs are not touched
@@ -1131,8 +1139,9 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
       wave_sync();
     }
     if (!LIGHT) calm = (s.ncon <= JacoLight::MAXCON && s.nefc <= JacoLight::MAXEFC && s.ncand <= JacoLight::MAXCAND / 2) ? calm + 1 : 0;
-    if (LIGHT && cflags) {   // capacity exceeded: leave this substep (and the rest) to the heavy tier; nothing was mutated
+    if (TIER < 2 && cflags) {   // capacity exceeded: leave this substep (and the rest) to the next tier; nothing was mutated
       left = nsub - sub;
+      bailed = true;
       if (emode == 1 || emode == 3) {
         if (lane < nu) s.task[JT_CTRL + lane] = s.ctrl[lane];
         if (lane == 0) { s.task[JT_PENDING] = 1.f; s.task[JT_SUB] = (float)sub; }
@@ -1220,7 +1229,7 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
     }
   }
   if (emode != 2) {
-    if (LIGHT && left > 0) {   // handed over to a heavy-tier workgroup (possibly on another XCD): write-through stores
+    if (bailed) {   // handed over to another workgroup (possibly on another XCD): write-through stores
       if (lane < nq) st_wt(&A.qpos[(size_t)env * nq + lane], s.qpos[lane]);
       if (lane < nv) { st_wt(&A.qvel[(size_t)env * nv + lane], s.qvel[lane]); st_wt(&A.qacc_ws[(size_t)env * nv + lane], s.qacc_ws[lane]); }
     } else {
@@ -1230,7 +1239,7 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
   }
   if (left == 0 && lane < ns && A.sensordata) A.sensordata[(size_t)env * ns + lane] = sens;
   if (emode) {
-    if ((left == 0 && emode != 3) || (!LIGHT && left > 0 && emode == 1)) {
+    if ((left == 0 && emode != 3) || (!LIGHT && left > 0 && !bailed && emode == 1)) {
       // what the controller reads one substep late, for the next launch -- or, on a heavy -> light hand-back in the middle
       // of a step, for the light code's next substep
       float* CW = A.cache + (size_t)env * JCACHE_N;
@@ -1290,18 +1299,19 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
     }
     if (left == 0 && emode == 3 && lane == 0) { s.task[JT_SUB] = 0.f; s.task[JT_PENDING] = 0.f; }
     wave_sync();
-    if (lane < JTASK_N) { if (LIGHT && left > 0) st_wt(&A.task[(size_t)env * JTASK_N + lane], s.task[lane]); else A.task[(size_t)env * JTASK_N + lane] = s.task[lane]; }
+    if (lane < JTASK_N) { if (bailed) st_wt(&A.task[(size_t)env * JTASK_N + lane], s.task[lane]); else A.task[(size_t)env * JTASK_N + lane] = s.task[lane]; }
   }
   unsigned long long anyf = wave_ballot(flags != 0);
   if (anyf) {
     unsigned f = flags;
     for (int o = 1; o < 64; o <<= 1) f |= (unsigned)wave_shfl_i((int)f, lane ^ o);
-    if (lane == 0 && A.flags) { if (LIGHT && left > 0) or_wt(&A.flags[env], f); else A.flags[env] |= f; }
+    if (lane == 0 && A.flags) { if (bailed) or_wt(&A.flags[env], f); else A.flags[env] |= f; }
   }
   if (left == 0 && lane == 0 && A.stats) {
     A.stats[4 * env] = s.ncon; A.stats[4 * env + 1] = s.nefc; A.stats[4 * env + 2] = iters; A.stats[4 * env + 3] = s.ncand | (nls_last << 16);
   }
   wave_sync();
+  if (why) *why = left <= 0 ? 0 : (bailed ? 1 : 2);
   return left;
 }
 
@@ -1312,7 +1322,7 @@ __global__ __launch_bounds__(64, 2) void jaco_physics_kernel(JacoStepArgs A) {
   if (env_id() >= A.nenv) return;
   const int env = A.order ? A.order[env_id()] : env_id();
   const unsigned long long t_start = wave_clock();
-  int left = run_env<JacoLight, true>(A, s, env, A.nsub, lane);
+  int left = run_env<JacoLight, 0>(A, s, env, A.nsub, lane);
   if (lane == 0 && A.cost) { unsigned c = (unsigned)((wave_clock() - t_start) >> 4); if (left > 0) st_wt_u(&A.cost[env], c); else A.cost[env] = c; }
   // hand-off: the env's state went to memory with write-through stores (run_env); once they are acknowledged the env
   // is appended to the heavy tier's work list.  Heavy-tier workgroups run concurrently (jaco_env.hip) and poll the list.
@@ -1328,30 +1338,42 @@ __global__ __launch_bounds__(64, 2) void jaco_physics_kernel(JacoStepArgs A) {
   }
   if (lane == 0 && A.light_left) jaco_atomic_dec(A.light_left, false);
 }
-// One handed-over env on a heavy-tier workgroup: the heavy code runs while the overflow lasts, the light code in between
-// (a heavy wave has its SIMD to itself, so both run at solo speed), until the env's step is complete.
-union JacoTierLDS { JacoLDS<JacoHeavy> heavy; JacoLDS<JacoLight> light; };
-JDEV void run_env_tiers(const JacoStepArgs& A, JacoTierLDS& u, int env, int lane) {
+// One handed-over env on a bigger-tier workgroup: the big code (medium: TB = 1, heavy: TB = 2) runs while the overflow
+// lasts, the light code in between, until the env's step is complete.  Returns 0, or -- medium only -- the substeps left
+// when the env overflowed the medium capacities too (the caller passes it on to the heavy tier).
+template <class BIG, int TB, class U>
+JDEV int run_env_tiers(const JacoStepArgs& A, U& u, int env, int lane) {
   const unsigned long long t_start = wave_clock();
   const bool stepmode = A.env_mode == 1 || A.env_mode == 3;
-  int left = stepmode ? A.nsub : A.remaining[env];
+  int left = stepmode ? A.nsub : A.remaining[env], why = 0;
   for (;;) {
-    left = run_env<JacoHeavy, false>(A, u.heavy, env, stepmode ? A.nsub : left, lane, !A.no_tier_return);
-    if (left <= 0) break;
+    left = run_env<BIG, TB>(A, u.big, env, stepmode ? A.nsub : left, lane, !A.no_tier_return, &why);
+    if (left <= 0 || why == 1) break;
     wave_sync();
-    left = run_env<JacoLight, true>(A, u.light, env, stepmode ? A.nsub : left, lane);
+    left = run_env<JacoLight, 0>(A, u.light, env, stepmode ? A.nsub : left, lane);
     if (left <= 0) break;
     wave_sync();
   }
   if (lane == 0 && A.cost) A.cost[env] += (unsigned)((wave_clock() - t_start) >> 4);
+  return left > 0 ? left : 0;
 }
-// heavy tier, concurrent with the light tier: persistent workgroups claim entries of the work list.  Entries are -1 until the light tier publishes them;
-// a worker leaves when the light tier has finished and every published entry is claimed, or (safety) when the light tier
-// makes no progress for ~JACO_WORKER_PATIENCE polls, e.g. because the two launches were serialised; whatever is left is
-// picked up by the drain launch that follows the light tier in stream order.
+union JacoMediumLDS { JacoLDS<JacoMedium> big; JacoLDS<JacoLight> light; };
+union JacoHeavyLDS { JacoLDS<JacoHeavy> big; JacoLDS<JacoLight> light; };
+// medium tier: an env that outgrew it as well goes on the heavy tier's list (served after the medium tier, in stream order)
+JDEV void medium_env(const JacoStepArgs& A, JacoMediumLDS& u, int env, int lane) {
+  int left = run_env_tiers<JacoMedium, 1>(A, u, env, lane);
+  if (left > 0 && lane == 0) {
+    A.remaining[env] = left;
+    A.heavy2_list[jaco_atomic_inc(A.heavy2_count)] = env;
+  }
+}
+// medium tier, concurrent with the light tier: persistent workgroups claim entries of the work list.  Entries are -1 until the
+// light tier publishes them; a worker leaves when the light tier has finished and every published entry is claimed, or
+// (safety) when the light tier makes no progress for ~JACO_WORKER_PATIENCE polls, e.g. because the two launches were
+// serialised; whatever is left is picked up by the drain launch that follows the light tier in stream order.
 #define JACO_WORKER_PATIENCE 6000
-__global__ __launch_bounds__(64) void jaco_physics_kernel_heavy(JacoStepArgs A) {
-  __shared__ JacoTierLDS u;
+__global__ __launch_bounds__(64, 2) void jaco_physics_kernel_medium(JacoStepArgs A) {
+  __shared__ JacoMediumLDS u;
   const int lane = lane_id();
   if (A.worker_limit && env_id() >= *A.worker_limit) return;
   for (;;) {
@@ -1375,19 +1397,29 @@ __global__ __launch_bounds__(64) void jaco_physics_kernel_heavy(JacoStepArgs A) 
     }
     dev_acquire();   // the env's state, written by the light workgroup before it published the entry
     if (lane == 0) A.heavy_list[i] = -2;   // taken
-    run_env_tiers(A, u, env, lane);
+    medium_env(A, u, env, lane);
     wave_sync();
   }
 }
-// drain: after the light tier and the workers have finished (stream order), serve whatever entry is still pending
-__global__ __launch_bounds__(64) void jaco_physics_kernel_heavy_drain(JacoStepArgs A) {
-  __shared__ JacoTierLDS u;
+// drains: after the light tier and the workers have finished (stream order), serve whatever entry is still pending on the
+// medium list, then the envs the medium tier passed on
+__global__ __launch_bounds__(64, 2) void jaco_physics_kernel_medium_drain(JacoStepArgs A) {
+  __shared__ JacoMediumLDS u;
   const int lane = lane_id();
   const int count = *A.heavy_count;
   for (int i = env_id(); i < count; i += grid_size()) {
     int env = A.heavy_list[i];
     if (env < 0) continue;
-    run_env_tiers(A, u, env, lane);
+    medium_env(A, u, env, lane);
+    wave_sync();
+  }
+}
+__global__ __launch_bounds__(64) void jaco_physics_kernel_heavy_drain(JacoStepArgs A) {
+  __shared__ JacoHeavyLDS u;
+  const int lane = lane_id();
+  const int count = *A.heavy2_count;
+  for (int i = env_id(); i < count; i += grid_size()) {
+    run_env_tiers<JacoHeavy, 2>(A, u, A.heavy2_list[i], lane);
     wave_sync();
   }
 }

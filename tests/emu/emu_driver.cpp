@@ -13,6 +13,7 @@ void emu_run_wave(int block, std::function<void()> body);
 extern "C" int emu_dbg_size() { return JDBG_SIZE; }
 extern "C" int emu_lds_bytes() { return (int)sizeof(JacoLDS<JacoLight>); }
 extern "C" int emu_lds_bytes_heavy() { return (int)sizeof(JacoLDS<JacoHeavy>); }
+extern "C" int emu_lds_bytes_medium() { return (int)sizeof(JacoLDS<JacoMedium>); }
 
 static JacoModelDev g_model;
 static std::vector<float> g_hull;
@@ -21,14 +22,17 @@ static int emu_launch(JacoStepArgs A, int* heavy_envs) {
   A.no_tier_return = g_no_tier_return_fwd();
   std::vector<int> remaining(A.nenv, 0), list(A.nenv, 0);
   std::fill(list.begin(), list.end(), -1);
-  int count = 0, taken = 0, light_left = A.nenv;
+  std::vector<int> list2(A.nenv, -1);
+  int count = 0, taken = 0, light_left = A.nenv, count2 = 0;
   A.remaining = remaining.data(); A.heavy_list = list.data(); A.heavy_count = &count; A.heavy_taken = &taken; A.light_left = &light_left;
+  A.heavy2_list = list2.data(); A.heavy2_count = &count2;
   emu_grid = A.nenv;
   for (int e = 0; e < A.nenv; e++) emu_run_wave(e, [&]() { jaco_physics_kernel(A); });
   emu_grid = 1;
-  // the worker form of the heavy tier (here after the light tier: every entry is already published), then the drain
-  if (count > 0) emu_run_wave(0, [&]() { jaco_physics_kernel_heavy(A); });
-  if (count > 0) emu_run_wave(0, [&]() { jaco_physics_kernel_heavy_drain(A); });
+  // the worker form of the medium tier (here after the light tier: every entry is already published), then the drains
+  if (count > 0) emu_run_wave(0, [&]() { jaco_physics_kernel_medium(A); });
+  if (count > 0) emu_run_wave(0, [&]() { jaco_physics_kernel_medium_drain(A); });
+  if (count2 > 0) emu_run_wave(0, [&]() { jaco_physics_kernel_heavy_drain(A); });
   if (heavy_envs) *heavy_envs = count;
   return 0;
 }
@@ -66,13 +70,16 @@ extern "C" int emu_physics_step(const void* blob, long blob_size, int nenv, int 
   A.model = &model; A.hull = hull.data(); A.qpos = qpos; A.qvel = qvel; A.qacc_ws = qacc_ws; A.ctrl = ctrl; A.sensordata = sensordata;
   A.flags = flags; A.stats = stats; A.nenv = nenv; A.nsub = nsub; A.disable_contact = disable_contact; A.dbg = dbg; A.dbg_env = dbg_env;
   std::vector<int> remaining(nenv, 0), list(nenv, -1);
-  int count = 0, taken = 0, light_left = nenv;
+  std::vector<int> list2(nenv, -1);
+  int count = 0, taken = 0, light_left = nenv, count2 = 0;
   A.remaining = remaining.data(); A.heavy_list = list.data(); A.heavy_count = &count; A.heavy_taken = &taken; A.light_left = &light_left;
+  A.heavy2_list = list2.data(); A.heavy2_count = &count2;
   emu_grid = nenv;
   for (int e = 0; e < nenv; e++) emu_run_wave(e, [&]() { jaco_physics_kernel(A); });
   emu_grid = 1;
-  if (count > 0) emu_run_wave(0, [&]() { jaco_physics_kernel_heavy(A); });
-  if (count > 0) emu_run_wave(0, [&]() { jaco_physics_kernel_heavy_drain(A); });
+  if (count > 0) emu_run_wave(0, [&]() { jaco_physics_kernel_medium(A); });
+  if (count > 0) emu_run_wave(0, [&]() { jaco_physics_kernel_medium_drain(A); });
+  if (count2 > 0) emu_run_wave(0, [&]() { jaco_physics_kernel_heavy_drain(A); });
   if (heavy_envs) *heavy_envs = count;
   return 0;
 }
