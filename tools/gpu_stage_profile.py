@@ -19,7 +19,8 @@ if envlevel:
     env = genv.sim
     genv.reset()
     gen = torch.Generator(device=env.device); gen.manual_seed(2000)
-    acts = [torch.rand(B, 7, device=env.device, generator=gen) * 2 - 1 for _ in range(4)]
+    ascale = float(sys.argv[sys.argv.index("--action-scale") + 1]) if "--action-scale" in sys.argv else 1.0
+    acts = [(torch.rand(B, 7, device=env.device, generator=gen) * 2 - 1) * ascale for _ in range(4)]
     for i in range(presteps): genv.step(acts[i % 4])
     torch.cuda.synchronize()
     env._chk(env.L.jaco_stage_profile(env.h, prof.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), 1))
