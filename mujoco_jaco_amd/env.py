@@ -42,6 +42,10 @@ class JacoBatchedEnv:
             # the reference's other task branches (reaching, grasping, ...) return 3-tuples from _get_terminal_inspection
             # (env_mujoco_util.py:504-536,585-600) that env_mujoco.py:125 cannot unpack: they cannot run there either
             raise NotImplementedError("task %r: only the reference's live tasks picking / placing are supported" % self.task)
+        # observation / marker branch: the rule-based sub-goal (env_mujoco_util.py:240-254,607-609) is the one main.py:44-45,
+        # 183-184,223-224 always selects and the only one built here
+        if kwargs.get("subgoal_obs", False) or kwargs.get("rulebased_subgoal", True) is False:
+            raise NotImplementedError("only subgoal_obs=False, rulebased_subgoal=True (what the reference's main.py sets) is supported")
         self.n_robots = kwargs.get("n_robots", 1)
         if self.n_robots != 1:
             raise NotImplementedError("n_robots != 1")
