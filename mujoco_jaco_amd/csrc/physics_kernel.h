@@ -1138,7 +1138,10 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
       if (lane == 0) { s.ncon = 0; s.ncand = 0; }
       wave_sync();
     }
-    if (!LIGHT) calm = (s.ncon <= JacoLight::MAXCON && s.nefc <= JacoLight::MAXEFC && s.ncand <= JacoLight::MAXCAND / 2) ? calm + 1 : 0;
+    if (!LIGHT) {   // would the tier below have coped with this substep?  (heavy -> medium, medium -> light)
+      constexpr int LCON = TIER == 2 ? JacoMedium::MAXCON : JacoLight::MAXCON, LEFC = TIER == 2 ? JacoMedium::MAXEFC : JacoLight::MAXEFC;
+      calm = (s.ncon <= LCON && s.nefc <= LEFC && s.ncand <= JacoLight::MAXCAND / 2) ? calm + 1 : 0;
+    }
     if (TIER < 2 && cflags) {   // capacity exceeded: leave this substep (and the rest) to the next tier; nothing was mutated
       left = nsub - sub;
       bailed = true;
@@ -1358,7 +1361,6 @@ JDEV int run_env_tiers(const JacoStepArgs& A, U& u, int env, int lane) {
   return left > 0 ? left : 0;
 }
 union JacoMediumLDS { JacoLDS<JacoMedium> big; JacoLDS<JacoLight> light; };
-union JacoHeavyLDS { JacoLDS<JacoHeavy> big; JacoLDS<JacoLight> light; };
 // medium tier: an env that outgrew it as well goes on the heavy tier's list (served after the medium tier, in stream order)
 JDEV void medium_env(const JacoStepArgs& A, JacoMediumLDS& u, int env, int lane) {
   int left = run_env_tiers<JacoMedium, 1>(A, u, env, lane);
@@ -1368,8 +1370,8 @@ JDEV void medium_env(const JacoStepArgs& A, JacoMediumLDS& u, int env, int lane)
   }
 }
 // medium tier, concurrent with the light tier: persistent workgroups claim entries of the work list.  Entries are -1 until the
-// light tier publishes them; a worker leaves when the light tier has finished and every published entry is claimed, or
-// (safety) when the light tier makes no progress for ~JACO_WORKER_PATIENCE polls, e.g. because the two launches were
+// light tier publishes them; a worker leaves as soon as the light tier has finished (the rest of the list goes to the drain's
+// full grid), or (safety) when the light tier makes no progress for ~JACO_WORKER_PATIENCE polls, e.g. because the two launches were
 // serialised; whatever is left is picked up by the drain launch that follows the light tier in stream order.
 #define JACO_WORKER_PATIENCE 6000
 __global__ __launch_bounds__(64, 2) void jaco_physics_kernel_medium(JacoStepArgs A) {
@@ -1383,13 +1385,12 @@ __global__ __launch_bounds__(64, 2) void jaco_physics_kernel_medium(JacoStepArgs
     if (i >= A.nenv) return;
     int env = -1, last_left = -1, idle = 0;
     for (;;) {
+      const int ll = wave_uniform_i(dev_load_relaxed(A.light_left));
+      // The light tier is done: whatever is still on the list (this slot included: it is not marked as taken) belongs to
+      // the drain launch, which brings a full grid instead of these few workgroups.
+      if (ll <= 0) return;
       env = wave_uniform_i(dev_load_relaxed(&A.heavy_list[i]));
       if (env >= 0) break;
-      const int ll = wave_uniform_i(dev_load_relaxed(A.light_left));
-      if (ll <= 0) {   // the light tier is done: one last, ordered look (every publication happened before the final decrement)
-        dev_acquire();
-        if (i >= wave_uniform_i(dev_load_relaxed(A.heavy_count))) return;   // nothing more will be published
-      }
       idle = ll == last_left ? idle + 1 : 0;
       last_left = ll;
       if (idle > JACO_WORKER_PATIENCE) return;   // (a slot claimed here and filled later is served by the drain launch)
@@ -1414,12 +1415,28 @@ __global__ __launch_bounds__(64, 2) void jaco_physics_kernel_medium_drain(JacoSt
     wave_sync();
   }
 }
+// heavy tier: heavy code while the env needs more than the medium capacities, then medium <-> light as above
+union JacoAllLDS { JacoLDS<JacoHeavy> heavy; JacoMediumLDS ml; };
 __global__ __launch_bounds__(64) void jaco_physics_kernel_heavy_drain(JacoStepArgs A) {
-  __shared__ JacoHeavyLDS u;
+  __shared__ JacoAllLDS u;
   const int lane = lane_id();
   const int count = *A.heavy2_count;
+  const bool stepmode = A.env_mode == 1 || A.env_mode == 3;
   for (int i = env_id(); i < count; i += grid_size()) {
-    run_env_tiers<JacoHeavy, 2>(A, u, A.heavy2_list[i], lane);
+    const int env = A.heavy2_list[i];
+    const unsigned long long t_start = wave_clock();
+    int left = stepmode ? A.nsub : A.remaining[env], why = 0;
+    for (;;) {
+      left = run_env<JacoHeavy, 2>(A, u.heavy, env, stepmode ? A.nsub : left, lane, !A.no_tier_return, &why);
+      if (left <= 0) break;
+      wave_sync();
+      if (!stepmode && lane == 0) A.remaining[env] = left;   // (ctrl level: run_env_tiers reads the substeps left from here)
+      wave_sync();
+      left = run_env_tiers<JacoMedium, 1>(A, u.ml, env, lane);
+      if (left <= 0) break;
+      wave_sync();
+    }
+    if (lane == 0 && A.cost) A.cost[env] += (unsigned)((wave_clock() - t_start) >> 4);
     wave_sync();
   }
 }

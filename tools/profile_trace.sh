@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/ktrace
 rm -rf $OUT && mkdir -p $OUT
-rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/tools/gpu_step_trace.py 65536 ${1:-30} > $OUT/run.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/tools/gpu_step_trace.py 65536 ${1:-30} ${@:2} > $OUT/run.log 2>&1
 python3 - <<PY
 import csv, glob
 rows = []
@@ -13,7 +13,7 @@ for f in glob.glob("$OUT/*/*kernel_trace.csv"):
 rows.sort()
 step, t0 = -1, 0
 for s, e, k in rows:
-    short = "prepare" if "prepare" in k else "order" if "order" in k else "drain" if "drain" in k else "workers" if "heavy" in k else "light" if "jaco_physics_kernel" in k else None
+    short = "prepare" if "prepare" in k else "order" if "order" in k else "mdrain" if "medium_drain" in k else "hdrain" if "heavy_drain" in k else "workers" if "medium" in k else "light" if "jaco_physics_kernel" in k else None
     if short is None: continue
     if short == "prepare": step += 1; t0 = s
     if short in ("prepare", "order"): continue
