@@ -24,6 +24,7 @@
 // A light wave that meets an overflow hands its env (state untouched for that substep) to the heavy launch.
 template <int MAXEFC_, int MAXCON_, int MAXCAND_>
 struct JacoCaps {
+  static_assert(MAXEFC_ % 64 == 0, "rows are dealt out 64 at a time (one per lane): the row capacity must be a multiple of 64");
   static constexpr int MAXEFC = MAXEFC_, MAXCON = MAXCON_, MAXCAND = MAXCAND_, NR = MAXEFC_ / 64;
 };
 typedef JacoCaps<64, 32, 128> JacoLight;   // (candidates = bounding-sphere survivors: closed fingers alone contribute > 64)
