@@ -1,57 +1,44 @@
 #!/usr/bin/env python
-"""Headline benchmark: env-steps/sec of the batched Jaco physics step (BASELINE.json metric).
+"""Headline benchmark: env-steps/sec of the batched Jaco environment step (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
 
-Workload: 65 536 environments per GPU, full Jaco + 3-finger gripper +
-table/object contacts, states drawn from the reference's `picking` reset distribution, inputs resident in HBM.
-Default `--level env`: one "step" = one JacoMujocoEnv.step (env_mujoco.py:116-139) for every env of the batch:
-random actions U(-1,1)^7 -> _take_action, `--frame-skip` (default 50 = the reference, env_mujoco.py:24) substeps of
-operational-space control + physics, observation, reward, termination (jaco_step).  `--level ctrl` times the ctrl-level
-entry jaco_physics_step (random motor torques, `--frame-skip` substeps per step, default 1) used for oracle parity.
-Environments are independent, so ranks shard them with no data-path collective; the only collective is
-the per-step all_gather of the observation rows, as the north star prescribes.
-Also reports: roofline of the physics kernel (algorithmic bytes / HIP-event kernel time vs 8 TB/s) and,
-on rank 0 at N=1, the fp64 oracle timed on the host cores as a CPU baseline ("port").
+N > 1 without a torch.distributed launcher: this process spawns N fresh rank processes itself BEFORE anything touches a
+GPU (never an exec of a process that initialised HIP) and forwards rank 0's JSON line; under `torch.distributed.run`
+(WORLD_SIZE set) it is a rank.
+
+Workload: 65 536 environments per GPU, full Jaco + 3-finger gripper + table/object
+contacts, the reference's `picking` reset distribution, inputs resident in HBM.
+Default `--level env`: one "step" = one JacoMujocoEnv.step (env_mujoco.py:116-139) for every env of the batch: a fresh
+random action U(-1,1)^7 x --action-scale -> _take_action, `--frame-skip` (default 50 = the reference, env_mujoco.py:24)
+substeps of operational-space control + physics, observation, reward, termination (jaco_step), then a masked jaco_reset
+of the envs that finished -- inside the timed region, no host synchronisation.  The batch is first rolled `--preroll`
+untimed steps (with the same masked resets, episode ages staggered over [0, 700)) so the timed window sees a rollout in
+progress, not the 25 steps after a global reset.  `--level ctrl` times the ctrl-level entry jaco_physics_step (random motor
+torques, `--frame-skip` substeps per step, default 1) used for oracle parity.
+Environments are independent, so ranks shard them with no data-path collective; the only collective is the per-step
+all_gather of the observation rows, as the north star prescribes.
+Also reported: the roofline of the physics kernel (algorithmic bytes / HIP-event kernel time vs 8 TB/s), VALU issue rate
+(from the committed PMC pass), throughput at small action scales, and -- on rank 0 at N = 1 -- the fp64 oracle timed on the
+host cores as a CPU baseline ("port") together with the 1 000-substep drift of the HIP path against that same oracle run.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+HBM_PEAK_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2   # wave-instructions/s: 1 024 SIMD-32 units, one wave64 VALU instruction per 2 cycles, 2.4 GHz
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc.json")
 
 
-def cpu_baseline(model, frame_skip, budget_s=15.0):
-    """fp64 oracle (oracle/, test infrastructure) on the host cores: a reported baseline, not the target."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import numpy as np
-    from mujoco_jaco_amd import workload
-    from mujoco_jaco_amd.modelc import blob
-    from oracle_binding import Oracle
-    cores = os.cpu_count() or 1
-    M = blob.load(os.path.join(ROOT, "mujoco_jaco_amd", "assets", model + ".jacomdl"))
-    o = Oracle(model)
-    nenv, nsub = 64 * cores, 25
-    q = workload.reset_states(M["qpos0"], nenv, seed=123)
-    v = np.zeros((nenv, o.nv)); w = np.zeros((nenv, o.nv))
-    c = workload.random_ctrl(nenv, seed=124, scale=0.2)[:, :o.nu].copy()
-    o.step_batch(q, v, w, c, nsub=5, nthreads=cores)  # warm
-    t = time.time(); done = 0
-    while time.time() - t < budget_s:
-        o.step_batch(q, v, w, c, nsub=nsub, nthreads=cores)
-        done += nenv * nsub
-    dt = time.time() - t
-    return {"value": done / dt / frame_skip, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": "%d envs x %d physics substeps of the same workload (random torques; the controller / observation glue is not timed), fp64 C oracle, OpenMP over %d threads, %.1f s; frame_skip %d"
-                      % (nenv, done // nenv, cores, dt, frame_skip)}
-
-
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -60,8 +47,106 @@ def main():
     ap.add_argument("--frame-skip", type=int, default=None)
     ap.add_argument("--level", choices=["env", "ctrl"], default="env")
     ap.add_argument("--model", default="jaco2_curtain_torque")
+    ap.add_argument("--task", default="picking")
+    ap.add_argument("--action-scale", type=float, default=1.0, help="actions are U(-1,1)^7 times this (1.0 = the headline)")
+    ap.add_argument("--preroll", type=int, default=40, help="untimed env steps (with masked resets) before warmup")
+    ap.add_argument("--extra-scales", default="0.3,0.05", help="action scales also timed (briefly) after the headline window; '' = none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--dry-gather", action="store_true",
+                    help="CPU rehearsal of the N > 1 plumbing (spawn, rendezvous, gather, max-over-ranks timing) on gloo: no GPU, no physics")
+    return ap.parse_args(argv)
+
+
+def self_launch(args):
+    """--gpus N > 1 outside a launcher: N child ranks, started before this process has made any GPU call."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
+
+
+def cpu_baseline_and_drift(model, frame_skip, gpu_step, budget_envs_per_core=8):
+    """fp64 oracle (oracle/, test infrastructure) on the host cores: a reported baseline, not the target.  The same oracle
+    run doubles as the reference trajectory of the drift metric: `gpu_step(q0, ctrl, marks)` steps the HIP path on the
+    same inputs and returns qpos at the marks."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    from mujoco_jaco_amd import workload
+    from mujoco_jaco_amd.modelc import blob
+    from oracle_binding import Oracle
+    cores = os.cpu_count() or 1
+    M = blob.load(os.path.join(ROOT, "mujoco_jaco_amd", "assets", model + ".jacomdl"))
+    o = Oracle(model)
+    nenv = max(64, min(2048, budget_envs_per_core * cores))
+    marks = (100, 300, 1000)
+    q0 = workload.reset_states(M["qpos0"], nenv, seed=41, f32_draws=True)
+    c = np.ascontiguousarray(workload.random_ctrl(nenv, seed=42, scale=0.2)[:, :o.nu].astype(np.float32).astype(np.float64))
+    q, v, w = np.ascontiguousarray(q0.copy()), np.zeros((nenv, o.nv)), np.zeros((nenv, o.nv))
+    o.step_batch(q.copy(), v.copy(), w.copy(), c, nsub=2, nthreads=cores)  # warm the thread pool
+    ref, done, t = {}, 0, time.time()
+    for mk in marks:
+        o.step_batch(q, v, w, c, nsub=mk - done, nthreads=cores)
+        done = mk
+        ref[mk] = q.copy()
+    dt = time.time() - t
+    base = {"value": nenv * done / dt / frame_skip, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": "%d envs x %d physics substeps of the same workload (picking reset distribution, constant random torques; the controller / observation glue is not timed), fp64 C oracle, OpenMP over %d threads, %.1f s; frame_skip %d"
+                      % (nenv, done, cores, dt, frame_skip)}
+    got = gpu_step(q0, c, marks)
+    drift = {"metric": "max-abs qpos error of the HIP path vs the fp64 oracle, same (qpos, qvel, ctrl), ctrl level", "envs": nenv, "oracle": "port (parity unpinned: no MuJoCo)"}
+    for mk in marks:
+        e = np.abs(got[mk] - ref[mk]).max(1)
+        drift["after_%d_substeps" % mk] = {"median": float(np.median(e)), "p90": float(np.percentile(e, 90)), "max": float(e.max()),
+                                            "frac_le_1e-4": float(np.mean(e <= 1e-4))}
+    drift["note"] = "contact dynamics amplify last-bit differences: the fp64 oracle carrying fp32-rounded state parts from itself the same way (profiles/r02_drift_control.txt)"
+    return base, drift
+
+
+def dry_rank(args, world, rank):
+    """The N > 1 plumbing without a GPU: gloo, synthetic observation rows, the same barrier / max-over-ranks / JSON path."""
+    import torch
+    import torch.distributed as dist
+    from mujoco_jaco_amd.sharding import ObsGather
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    B = min(args.batch, 4096)
+    gather = ObsGather(B, 26, torch.device("cpu"))
+    local = torch.full((B, 26), float(rank))
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        full = gather(local)
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ok = bool(torch.equal(full.view(world, B, 26)[:, 0, 0], torch.arange(world, dtype=torch.float32)))
+    if rank == 0:
+        print(json.dumps({"metric": "dry-gather rehearsal (no GPU, no physics)", "value": world * B * args.steps / float(t.item()), "unit": "rows/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": 0, "data": "dry-run", "gather_ok": ok}))
+    dist.destroy_process_group()
+    return 0 if ok else 1
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print("bench.py: WORLD_SIZE=%d but --gpus %d" % (world, args.gpus), file=sys.stderr)
+        sys.exit(2)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if args.dry_gather:
+        sys.exit(dry_rank(args, world, rank))
 
     import numpy as np
     import torch
@@ -70,12 +155,6 @@ def main():
     from mujoco_jaco_amd.modelc import blob
     from mujoco_jaco_amd.physics import BatchedMujoco
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        print("bench.py: WORLD_SIZE=%d but --gpus %d (launch N>1 through torch.distributed.run)" % (world, args.gpus), file=sys.stderr)
-        sys.exit(2)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -84,20 +163,29 @@ def main():
     B = args.batch
     fs = args.frame_skip if args.frame_skip is not None else (50 if args.level == "env" else 1)
     M = blob.load(os.path.join(ROOT, "mujoco_jaco_amd", "assets", args.model + ".jacomdl"))
+    done_count = torch.zeros((), dtype=torch.int64, device=dev)
     if args.level == "env":
         from mujoco_jaco_amd.env import JacoBatchedEnv
         from mujoco_jaco_amd.sharding import ObsGather, env_seed
-        genv = JacoBatchedEnv(num_envs=B, device=local_rank, frame_skip=fs, seed=env_seed(1000, rank), task="picking", robot_file=args.model)
+        genv = JacoBatchedEnv(num_envs=B, device=local_rank, frame_skip=fs, seed=env_seed(1000, rank), task=args.task, robot_file=args.model)
         env = genv.sim
-        obs = genv.reset()
+        genv.reset()
         gen = torch.Generator(device=dev); gen.manual_seed(2000 + rank)
-        actions = [torch.rand(B, 7, device=dev, generator=gen) * 2 - 1 for _ in range(4)]
+        # a rollout in progress: episode ages spread over [0, task_max_steps) so time-outs (and their resets) arrive at the
+        # steady-state rate instead of all together 700 steps after the global reset
+        ts = genv.task_state()
+        ts[:, 1] = torch.randint(0, genv.task_max_steps, (B,), device=dev, generator=gen).float()
+        genv.set_task_state(ts)
         gather = ObsGather(B, 26, dev) if world > 1 else None
-        it = [0]
+        scale = [float(args.action_scale)]
+        nact = genv.action_space.shape[0]
 
         def step():
-            o, r, d, _ = genv.step(actions[it[0] % 4]); it[0] += 1
-            if world > 1:  # one collective per rollout step: concatenate the observation rows of all shards
+            a = (torch.rand(B, nact, device=dev, generator=gen) * 2 - 1) * scale[0]
+            o, r, d, _ = genv.step(a)
+            done_count.add_(d.sum())
+            genv.reset(d)          # masked jaco_reset of the finished envs: no host sync; their obs rows become the new episode's first
+            if world > 1:          # one collective per rollout step: concatenate the observation rows of all shards
                 gather(o)
     else:
         env = BatchedMujoco(B, robot_file=args.model, device=local_rank, frame_skip=fs, seed=rank)
@@ -112,40 +200,64 @@ def main():
                 qpos, _, _ = env.state_views()
                 dist.all_gather_into_tensor(gathered, qpos)
 
-    for _ in range(args.warmup):
+    def timed(nsteps):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(nsteps):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    for _ in range((args.preroll if args.level == "env" else 0) + args.warmup):
         step()
+    done_count.zero_()
     env.enable_timing(True)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
+    dt = timed(args.steps)
     kern_ms, launches = env.kernel_time_ms()
     env.enable_timing(False)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    done_fraction = float(done_count.item()) / (B * args.steps)
     flags = int(env.flags().max().item())
     stats = env.stats().float().mean(0).cpu().numpy()
+    heavy = float(((env.flags() & 32) != 0).float().mean().item())
+
+    small = {}
+    if args.level == "env" and world == 1 and args.extra_scales:
+        for sc in [float(x) for x in args.extra_scales.split(",") if x]:
+            scale[0] = sc
+            for _ in range(12):   # let the EE settle onto the smaller targets (the regime a converged policy lives in)
+                step()
+            n = 4
+            small["%g" % sc] = B * n / timed(n)
+        scale[0] = float(args.action_scale)
 
     if rank == 0:
-        # algorithmic HBM bytes of one launch of jaco_physics_kernel per env (DESIGN.md "Measurement"):
-        # reads qpos, qvel, qacc_warmstart, ctrl; writes qpos, qvel, qacc_warmstart, sensordata.
-        bytes_per_env = 4 * (2 * env.nq + 4 * env.nv + env.nu + env.nsensor)
-        if args.level == "env":  # + action in, obs / reward / done out, task and controller-cache rows in and out
-            bytes_per_env = 4 * (2 * env.nq + 4 * env.nv + env.nsensor + 7 + 26 + 1 + 2 * 32 + 2 * 96) + 1
-        achieved = bytes_per_env * B / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
-        traffic = None
-        try:  # HBM bytes per launch from the committed rocprofv3 PMC passes (tools/profile_pmc.sh), same level / batch only
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            key = "%s_B%d_fs%d" % (args.level, B, fs)
-            traffic = pm.get(key, {}).get("hbm_bytes_per_launch")
+        # algorithmic HBM bytes per env per launch.  SURVEY 8(d): A = 4 (2 nq + 2 nv + n_act + n_obs + 1) + 1 = 489 B for the env
+        # step of the full model (state in, state + obs + reward + done out); what this implementation actually has to move
+        # in addition: warm start in/out, sensordata, the task row and the controller-cache row in and out.
+        if args.level == "env":
+            a_survey = 4 * (2 * env.nq + 2 * env.nv + 7 + 26 + 1) + 1
+            a_impl = 4 * (2 * env.nq + 4 * env.nv + env.nsensor + 7 + 26 + 1 + 2 * 32 + 2 * 104) + 1
+        else:
+            a_survey = 4 * (2 * env.nq + 2 * env.nv + env.nu)
+            a_impl = 4 * (2 * env.nq + 4 * env.nv + env.nu + env.nsensor)
+        achieved = a_survey * B / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+        traffic = valu = wait = None
+        try:  # counters of the same command from the committed rocprofv3 PMC passes (tools/profile_pmc.sh)
+            pm = json.load(open(PMC_FILE)).get("%s_B%d_fs%d" % (args.level, B, fs), {})
+            traffic = pm.get("hbm_bytes_per_launch")
+            if pm.get("SQ_INSTS_VALU") and pm.get("kernel_ms"):
+                valu = pm["SQ_INSTS_VALU"] / (pm["kernel_ms"] * 1e-3) / VALU_ISSUE_PEAK
+            if pm.get("SQ_WAIT_ANY") and pm.get("SQ_WAVE_CYCLES"):
+                wait = pm["SQ_WAIT_ANY"] / pm["SQ_WAVE_CYCLES"]
         except Exception:
             pass
         out = {
@@ -153,21 +265,35 @@ def main():
             "value": world * B * args.steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "config3: %d envs/GPU, %s, picking reset distribution, %s"
-                                   % (B, args.model, "random actions, env-level jaco_step (OSC + %d substeps + obs/reward/done)" % fs
+            "config": {"workload": "config3: %d envs/GPU, %s, %s reset distribution, %s"
+                                   % (B, args.model, args.task, "fresh random actions x %g each step, env-level jaco_step (OSC + %d substeps + obs/reward/done) + masked reset of finished envs" % (args.action_scale, fs)
                                       if args.level == "env" else "random motor ctrl, ctrl-level jaco_physics_step"),
-                       "level": args.level,
+                       "level": args.level, "action_scale": args.action_scale, "preroll_steps": args.preroll if args.level == "env" else 0,
                        "envs_per_gpu": B, "frame_skip": fs, "substeps_per_s": world * B * args.steps * fs / dt,
+                       "done_fraction": done_fraction,
+                       "small_action_env_steps_per_s": small,
                        "sharding": "independent env shards per rank" + ("; one all_gather of [B,%d] f32 rows per step" % (26 if args.level == "env" else env.nq) if world > 1 else ""),
                        "mean_contacts": float(stats[0]), "mean_rows": float(stats[1]), "mean_newton_iters": float(stats[2]), "flags_or": flags,
-                       "heavy_tier_fraction": float(((env.flags() & 32) != 0).float().mean().item())},
+                       "heavy_tier_fraction": heavy},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "jaco_physics_kernel", "kernel_ms": kern_ms, "launches": launches,
-                         "algorithmic_bytes_per_env_launch": bytes_per_env,
-                         "note": "latency/occupancy-bound by design (SURVEY 8d): algorithmic traffic is ~1 KB per env per launch; `traffic` = L2 fabric-side bytes per launch from profiles/r01_pmc_traffic.json (FETCH_SIZE + WRITE_SIZE, Infinity-Cache hits included): 95 % of it are register-spill lines (6 MB per XCD against a 4 MB L2) cycling between L2 and the Infinity Cache, the env state is 0.1 GB"},
+                         "traffic": traffic, "kernel": "jaco_physics_kernel (+ its tier drains)", "kernel_ms": kern_ms, "launches": launches,
+                         "algorithmic_bytes_per_env_launch": a_survey, "implementation_bytes_per_env_launch": a_impl,
+                         "valu_issue_frac": valu, "wait_frac": wait,
+                         "note": "latency/occupancy-bound by design (SURVEY 8d): algorithmic traffic is ~0.5 KB per env per launch, so the HBM fraction is ~1e-4 whatever the kernel does; the meaningful ceilings are VALU issue (valu_issue_frac: wave-instructions issued / 1.23e12 per s) and exposed latency (wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES), both from the committed PMC pass of this command (profiles/)"},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.model, fs)
+            def gpu_step(q0, c, marks):
+                e2 = BatchedMujoco(q0.shape[0], robot_file=args.model, device=local_rank)
+                e2.set_state(torch.tensor(q0, dtype=torch.float32, device=dev), None, None)
+                cc = torch.tensor(c, dtype=torch.float32, device=dev)
+                got, done = {}, 0
+                for mk in marks:
+                    e2.send_forces(cc, nsub=mk - done)
+                    done = mk
+                    got[mk] = e2.get_state()[0].cpu().numpy().astype(np.float64)
+                e2.close()
+                return got
+            out["cpu_baseline"], out["drift"] = cpu_baseline_and_drift(args.model, fs, gpu_step)
         print(json.dumps(out))
     env.close()
     if world > 1:

@@ -112,6 +112,14 @@ int jaco_reset(JacoHandle* h, const uint8_t* mask_dev, float* obs_dev, void* str
 int jaco_placing_hold(JacoHandle* h, const uint8_t* mask_dev, int nsub, void* stream);
 int jaco_step(JacoHandle* h, const float* action_dev, float* obs_dev, float* reward_dev, uint8_t* done_dev, void* stream);
 int jaco_forward(JacoHandle* h, float* obs_dev, void* stream);
+/* The two halves of jaco_step the reference also exposes as public methods of JacoMujocoEnv (env_mujoco.py:144-161):
+ * jaco_take_action: take_action(a) alone -- new EE target, gripper command / ramp end points, the two marker poses, 6 noise
+ *   draws; no physics.  A following jaco_step would call _take_action again, as the reference's step() does.
+ * jaco_terminal_inspection: terminal_inspection() alone -- current_steps += 1, then the task's termination rule on the
+ *   poses / touch sensors of the last forward pass; done_dev [num_envs] u8, bonus_dev [num_envs] f32 (the reference's
+ *   additional_reward); get_wb / the success flag are then in the task row (JT_WB, JT_SUCC).  Finished envs freeze as in jaco_step. */
+int jaco_take_action(JacoHandle* h, const float* action_dev, void* stream);
+int jaco_terminal_inspection(JacoHandle* h, uint8_t* done_dev, float* bonus_dev, void* stream);
 int jaco_set_noise(JacoHandle* h, const float* noise_dev);
 int jaco_get_task_state(JacoHandle* h, float* out_dev, void* stream);
 int jaco_set_task_state(JacoHandle* h, const float* in_dev, void* stream);

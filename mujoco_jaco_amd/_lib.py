@@ -38,6 +38,8 @@ SYMBOLS = {
     "jaco_placing_hold": (_ci, [_vp, _vp, _ci, _vp]),
     "jaco_step": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "jaco_forward": (_ci, [_vp, _vp, _vp]),
+    "jaco_take_action": (_ci, [_vp, _vp, _vp]),
+    "jaco_terminal_inspection": (_ci, [_vp, _vp, _vp, _vp]),
     "jaco_set_noise": (_ci, [_vp, _vp]),
     "jaco_get_task_state": (_ci, [_vp, _vp, _vp]),
     "jaco_set_task_state": (_ci, [_vp, _vp, _vp]),

@@ -424,9 +424,19 @@ JDEV bool mpr_penetration(const JacoStepArgs& A, const JacoModelDev* m, const L&
     dr = portal_dir(p1, p2, p3);
     v4 = mpr_support(A, G1, G2, dr, lane);
     if (reach_tol(p1, p2, p3, v4, dr, tol) || it > m->mpr_iterations) {
-      v3 cp;
-      *depth = point_tri_closest(p1.v, p2.v, p3.v, &cp);
-      *dirout = *depth < 1e-10f ? dr : normalized(cp);
+      if (m->mpr_output == 1) {
+        // Portal-plane output: the refined portal lies (within mpr_tolerance) in the face of the Minkowski difference that the
+        // ray from the interior point through the origin leaves by; its normal and the support value h(dr) = v4 . dr do not
+        // depend on which triangle of that face the refinement ended on.  libccd's closest point of the final triangle
+        // (mpr_output 0) is the same whenever the origin projects into the triangle; otherwise it depends on the refinement
+        // path, and for shallow contacts its direction is the normalisation of a ~1e-6 vector: noise in fp32.
+        *dirout = dr;
+        *depth = dot(v4.v, dr);
+      } else {
+        v3 cp;
+        *depth = point_tri_closest(p1.v, p2.v, p3.v, &cp);
+        *dirout = *depth < 1e-10f ? dr : normalized(cp);
+      }
       *pos = mpr_find_pos(p0, p1, p2, p3);
       return true;
     }

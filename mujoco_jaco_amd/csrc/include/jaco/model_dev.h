@@ -32,6 +32,7 @@ struct JacoModelDev {
   int nbody, nv, nq, nu, ngeom, npair, nsensor, nhullvert, nmocap;
   float timestep, gravity[3], tolerance, meaninertia, mpr_tolerance;
   int iterations, ls_iterations, mpr_iterations;
+  int mpr_output;   // 1 (default): portal-plane normal + support depth; 0: libccd's closest point of the final portal triangle
   float ls_tolerance;
 
   // bodies (parents precede children)

@@ -95,12 +95,20 @@ JDEV int jaco_atomic_dec(int* p, bool release) {
 }
 // device-scope publish / observe for the light -> heavy work list (the two tiers run concurrently in different workgroups)
 // Write-through stores (visible device-wide once acknowledged, no L2 write-back needed afterwards): used for the state of
-// an env that is handed to another workgroup.  dev_stores_done(): this lane's earlier stores have been acknowledged.
+// an env that is handed to another workgroup.  INVARIANT: every store whose value a hand-off carries to another workgroup
+// (state rows, task row, flags, marker / pin poses, cost, remaining) must be st_wt / or_wt, followed by dev_stores_done()
+// before the work-list entry is published; the reader does one agent-scope acquire (dev_acquire) after seeing the entry.
 JDEV void st_wt(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 JDEV void st_wt_i(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 JDEV void st_wt_u(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 JDEV void or_wt(unsigned* p, unsigned v) { atomicOr(p, v); }
-JDEV void dev_stores_done() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+// dev_stores_done(): every earlier global store of this lane (the write-through state rows of a hand-off) has been
+// acknowledged by memory before anything after it issues.  The wait is explicit: a workgroup-scope release fence alone emits
+// no s_waitcnt on gfx950 (single-wave workgroup, non-tgsplit), so nothing would order the sc1 stores before the list publish.
+JDEV void dev_stores_done() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+}
 JDEV void dev_fence() { __threadfence(); }
 JDEV void dev_store_release(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
 // polling: coherent relaxed load (no cache invalidation -- an acquire per poll would keep flushing the XCD's L2 under the

@@ -22,6 +22,7 @@ struct JacoHandle {
   JacoModelDev model_host;
   JacoModelDev* model_dev = nullptr;
   float* hull_dev = nullptr;
+  float* qpos0_dev = nullptr;   // [nq] reset pose, uploaded once (resets never touch host memory)
   float *qpos = nullptr, *qvel = nullptr, *qacc_ws = nullptr, *sensordata = nullptr, *dbg = nullptr;
   unsigned* flags = nullptr;
   int* stats = nullptr;
@@ -57,6 +58,9 @@ static std::string g_create_error;
       return JACO_EHIP;                                                                              \
     }                                                                                                \
   } while (0)
+
+// Every entry point that touches HIP runs on the handle's own GPU, whatever the caller's current device.
+#define ENTER(h) HIPCHK(h, hipSetDevice((h)->device))
 
 extern "C" const char* jaco_last_error(const JacoHandle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
@@ -148,6 +152,8 @@ extern "C" int jaco_create(const JacoConfig* cfg, JacoHandle** out) {
       off += nb + ((8 - nb % 8) % 8);
     }
     if ((int)h->qpos0.size() != m.nq) { g_create_error = "jaco_create: qpos0 missing"; jaco_destroy(h); return JACO_EINVAL; }
+    CREATECHK(hipMalloc(&h->qpos0_dev, m.nq * sizeof(float)));
+    CREATECHK(hipMemcpy(h->qpos0_dev, h->qpos0.data(), m.nq * sizeof(float), hipMemcpyHostToDevice));
   }
   *out = h;
   int rc = jaco_reset_state(h, nullptr);
@@ -163,7 +169,7 @@ extern "C" int jaco_destroy(JacoHandle* h) {
   if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
-  void* ptrs[] = {h->model_dev, h->hull_dev, h->qpos, h->qvel, h->qacc_ws, h->sensordata, h->flags, h->stats, h->dbg, h->prof, h->remaining, h->heavy_list, h->heavy_count, h->task_rows, h->cache, h->cost, h->order, h->marker, h->order_ctl, h->heavy2_list};
+  void* ptrs[] = {h->model_dev, h->hull_dev, h->qpos, h->qvel, h->qacc_ws, h->sensordata, h->flags, h->stats, h->dbg, h->prof, h->remaining, h->heavy_list, h->heavy_count, h->task_rows, h->cache, h->cost, h->order, h->marker, h->order_ctl, h->heavy2_list, h->qpos0_dev};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   delete h;
   return JACO_OK;
@@ -183,7 +189,7 @@ extern "C" int jaco_num_envs(const JacoHandle* h) { return h ? h->num_envs : JAC
 
 extern "C" int jaco_set_state(JacoHandle* h, const float* qpos, const float* qvel, const float* qacc_ws, void* stream) {
   if (!h) return JACO_EINVAL;
-  HIPCHK(h, hipSetDevice(h->device));   // the handle's kernels and streams live on its own GPU, whatever the caller's current device
+  ENTER(h);
   hipStream_t st = (hipStream_t)stream;
   size_t B = h->num_envs;
   if (qpos) HIPCHK(h, hipMemcpyAsync(h->qpos, qpos, B * h->model_host.nq * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -193,7 +199,7 @@ extern "C" int jaco_set_state(JacoHandle* h, const float* qpos, const float* qve
 }
 extern "C" int jaco_get_state(JacoHandle* h, float* qpos, float* qvel, float* qacc_ws, void* stream) {
   if (!h) return JACO_EINVAL;
-  HIPCHK(h, hipSetDevice(h->device));   // the handle's kernels and streams live on its own GPU, whatever the caller's current device
+  ENTER(h);
   hipStream_t st = (hipStream_t)stream;
   size_t B = h->num_envs;
   if (qpos) HIPCHK(h, hipMemcpyAsync(qpos, h->qpos, B * h->model_host.nq * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -208,14 +214,12 @@ __global__ void jaco_fill_rows_kernel(float* dst, const float* row, int n, int n
 }
 extern "C" int jaco_reset_state(JacoHandle* h, void* stream) {
   if (!h) return JACO_EINVAL;
-  HIPCHK(h, hipSetDevice(h->device));   // the handle's kernels and streams live on its own GPU, whatever the caller's current device
+  ENTER(h);
   hipStream_t st = (hipStream_t)stream;
   const JacoModelDev& m = h->model_host;
   size_t B = h->num_envs;
-  // stage qpos0 in the debug buffer (device), then replicate it over all rows
-  HIPCHK(h, hipMemcpyAsync(h->dbg, h->qpos0.data(), m.nq * sizeof(float), hipMemcpyHostToDevice, st));
   size_t total = B * m.nq;
-  hipLaunchKernelGGL(jaco_fill_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, h->qpos, h->dbg, m.nq, (int)B);
+  hipLaunchKernelGGL(jaco_fill_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, h->qpos, h->qpos0_dev, m.nq, (int)B);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipMemsetAsync(h->qvel, 0, B * m.nv * sizeof(float), st));
   HIPCHK(h, hipMemsetAsync(h->qacc_ws, 0, B * m.nv * sizeof(float), st));
@@ -314,7 +318,7 @@ __global__ void jaco_prepare_kernel(int* ctl, int* list, int n, int max_workers,
 
 static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t st, float* dbg, int dbg_env, const EnvIO& io = EnvIO()) {
   if ((!ctrl && io.mode == 0) || nsub <= 0) { h->err = "jaco_physics_step: bad arguments"; return JACO_EINVAL; }
-  HIPCHK(h, hipSetDevice(h->device));   // the handle's kernels and streams live on its own GPU, whatever the caller's current device
+  ENTER(h);
   JacoStepArgs A{};
   A.model = h->model_dev; A.hull = h->hull_dev; A.qpos = h->qpos; A.qvel = h->qvel; A.qacc_ws = h->qacc_ws;
   A.ctrl = ctrl ? ctrl : h->qvel;   // env modes compute ctrl in-kernel; the pointer only has to be readable
@@ -326,7 +330,7 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
   A.cost = h->cost;
   const bool reorder = io.mode == 1 && h->schedule && nsub >= 8 && h->num_envs >= 4096;
   std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
-  if (h->timing) {
+  if (h->timing && io.mode <= 1) {   // (the masked forward passes of resets are not the kernel being measured)
     if (h->events_used == h->events.size()) {
       hipEvent_t a, b;
       HIPCHK(h, hipEventCreate(&a));
@@ -424,11 +428,11 @@ extern "C" int jaco_placing_hold(JacoHandle* h, const uint8_t* mask_dev, int nsu
 }
 extern "C" int jaco_reset(JacoHandle* h, const uint8_t* mask_dev, float* obs_dev, void* stream) {
   if (!h || !obs_dev) return JACO_EINVAL;
+  ENTER(h);
   hipStream_t st = (hipStream_t)stream;
   const JacoModelDev& m = h->model_host;
-  HIPCHK(h, hipMemcpyAsync(h->dbg, h->qpos0.data(), m.nq * sizeof(float), hipMemcpyHostToDevice, st));
   const float* rest = (const float*)((const char*)h->model_dev + offsetof(JacoModelDev, marker_rest));
-  JacoResetArgs R{h->dbg, h->qpos, h->qvel, h->qacc_ws, h->task_rows, mask_dev, h->marker, rest, h->num_envs, m.nq, m.nv, h->task, m.nq >= 23, h->seed};
+  JacoResetArgs R{h->qpos0_dev, h->qpos, h->qvel, h->qacc_ws, h->task_rows, mask_dev, h->marker, rest, h->num_envs, m.nq, m.nv, h->task, m.nq >= 23, h->seed};
   hipLaunchKernelGGL(jaco_reset_kernel, dim3((unsigned)((h->num_envs + 255) / 256)), dim3(256), 0, st, R);
   HIPCHK(h, hipGetLastError());
   if (h->task == JACO_TASK_PLACING) {   // object into the hand, 150 held substeps while the fingers close (env_mujoco_util.py:106-117)
@@ -444,6 +448,16 @@ extern "C" int jaco_step(JacoHandle* h, const float* action_dev, float* obs_dev,
   EnvIO io; io.mode = 1; io.action = action_dev; io.obs = obs_dev; io.reward = reward_dev; io.done = done_dev;
   return launch_step(h, nullptr, h->frame_skip, (hipStream_t)stream, nullptr, -1, io);
 }
+extern "C" int jaco_take_action(JacoHandle* h, const float* action_dev, void* stream) {
+  if (!h || !action_dev) return JACO_EINVAL;
+  EnvIO io; io.mode = 4; io.action = action_dev;
+  return launch_step(h, nullptr, 1, (hipStream_t)stream, nullptr, -1, io);
+}
+extern "C" int jaco_terminal_inspection(JacoHandle* h, uint8_t* done_dev, float* bonus_dev, void* stream) {
+  if (!h || !done_dev || !bonus_dev) return JACO_EINVAL;
+  EnvIO io; io.mode = 5; io.reward = bonus_dev; io.done = done_dev;
+  return launch_step(h, nullptr, 1, (hipStream_t)stream, nullptr, -1, io);
+}
 extern "C" int jaco_set_noise(JacoHandle* h, const float* noise_dev) {
   if (!h) return JACO_EINVAL;
   h->noise = noise_dev;
@@ -451,26 +465,26 @@ extern "C" int jaco_set_noise(JacoHandle* h, const float* noise_dev) {
 }
 extern "C" int jaco_get_task_state(JacoHandle* h, float* out_dev, void* stream) {
   if (!h || !out_dev) return JACO_EINVAL;
-  HIPCHK(h, hipSetDevice(h->device));   // the handle's kernels and streams live on its own GPU, whatever the caller's current device
+  ENTER(h);
   HIPCHK(h, hipMemcpyAsync(out_dev, h->task_rows, (size_t)h->num_envs * JTASK_N * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return JACO_OK;
 }
 extern "C" int jaco_set_task_state(JacoHandle* h, const float* in_dev, void* stream) {
   if (!h || !in_dev) return JACO_EINVAL;
-  HIPCHK(h, hipSetDevice(h->device));   // the handle's kernels and streams live on its own GPU, whatever the caller's current device
+  ENTER(h);
   HIPCHK(h, hipMemcpyAsync(h->task_rows, in_dev, (size_t)h->num_envs * JTASK_N * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return JACO_OK;
 }
 extern "C" int jaco_task_row_floats(void) { return JTASK_N; }
 extern "C" int jaco_get_markers(JacoHandle* h, float* out_dev, void* stream) {
   if (!h || !out_dev) return JACO_EINVAL;
-  HIPCHK(h, hipSetDevice(h->device));   // the handle's kernels and streams live on its own GPU, whatever the caller's current device
+  ENTER(h);
   HIPCHK(h, hipMemcpyAsync(out_dev, h->marker, (size_t)h->num_envs * 24 * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return JACO_OK;
 }
 extern "C" int jaco_set_markers(JacoHandle* h, const float* in_dev, void* stream) {
   if (!h || !in_dev) return JACO_EINVAL;
-  HIPCHK(h, hipSetDevice(h->device));   // the handle's kernels and streams live on its own GPU, whatever the caller's current device
+  ENTER(h);
   HIPCHK(h, hipMemcpyAsync(h->marker, in_dev, (size_t)h->num_envs * 24 * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return JACO_OK;
 }
@@ -483,6 +497,7 @@ extern "C" int jaco_set_frame_skip(JacoHandle* h, int frame_skip) {
 extern "C" int jaco_debug_dump_floats(void) { return JDBG_SIZE; }
 extern "C" int jaco_physics_step_debug(JacoHandle* h, const float* ctrl_dev, int nsub, int env, float* dump_host, int dump_floats) {
   if (!h || !dump_host || dump_floats < JDBG_SIZE || env < 0 || env >= h->num_envs) return JACO_EINVAL;
+  ENTER(h);
   HIPCHK(h, hipMemset(h->dbg, 0, JDBG_SIZE * sizeof(float)));
   int rc = launch_step(h, ctrl_dev, nsub, nullptr, h->dbg, env);
   if (rc) return rc;
@@ -493,31 +508,32 @@ extern "C" int jaco_physics_step_debug(JacoHandle* h, const float* ctrl_dev, int
 
 extern "C" int jaco_get_sensordata(JacoHandle* h, float* out, void* stream) {
   if (!h || !out) return JACO_EINVAL;
-  HIPCHK(h, hipSetDevice(h->device));   // the handle's kernels and streams live on its own GPU, whatever the caller's current device
+  ENTER(h);
   HIPCHK(h, hipMemcpyAsync(out, h->sensordata, (size_t)h->num_envs * h->model_host.nsensor * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return JACO_OK;
 }
 extern "C" int jaco_get_flags(JacoHandle* h, uint32_t* out, void* stream) {
   if (!h || !out) return JACO_EINVAL;
-  HIPCHK(h, hipSetDevice(h->device));   // the handle's kernels and streams live on its own GPU, whatever the caller's current device
+  ENTER(h);
   HIPCHK(h, hipMemcpyAsync(out, h->flags, (size_t)h->num_envs * sizeof(unsigned), hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return JACO_OK;
 }
 extern "C" int jaco_clear_flags(JacoHandle* h, void* stream) {
   if (!h) return JACO_EINVAL;
-  HIPCHK(h, hipSetDevice(h->device));   // the handle's kernels and streams live on its own GPU, whatever the caller's current device
+  ENTER(h);
   HIPCHK(h, hipMemsetAsync(h->flags, 0, (size_t)h->num_envs * sizeof(unsigned), (hipStream_t)stream));
   return JACO_OK;
 }
 extern "C" int jaco_get_stats(JacoHandle* h, int32_t* out, void* stream) {
   if (!h || !out) return JACO_EINVAL;
-  HIPCHK(h, hipSetDevice(h->device));   // the handle's kernels and streams live on its own GPU, whatever the caller's current device
+  ENTER(h);
   HIPCHK(h, hipMemcpyAsync(out, h->stats, (size_t)h->num_envs * 4 * sizeof(int), hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return JACO_OK;
 }
 
 extern "C" int jaco_set_option(JacoHandle* h, const char* name, double v) {
   if (!h || !name) return JACO_EINVAL;
+  ENTER(h);
   JacoModelDev& m = h->model_host;
   if (!strcmp(name, "disable_contact")) { h->disable_contact = v != 0; return JACO_OK; }
   if (!strcmp(name, "schedule")) { h->schedule = v != 0; return JACO_OK; }
@@ -529,6 +545,7 @@ extern "C" int jaco_set_option(JacoHandle* h, const char* name, double v) {
   else if (!strcmp(name, "ls_iterations")) m.ls_iterations = (int)v;
   else if (!strcmp(name, "mpr_iterations")) m.mpr_iterations = (int)v;
   else if (!strcmp(name, "mpr_tolerance")) m.mpr_tolerance = (float)v;
+  else if (!strcmp(name, "mpr_output")) m.mpr_output = (int)v;
   else { h->err = std::string("jaco_set_option: unknown option ") + name; return JACO_EINVAL; }
   HIPCHK(h, hipDeviceSynchronize());
   return upload_model(h);
@@ -538,6 +555,7 @@ extern "C" int jaco_set_option(JacoHandle* h, const char* name, double v) {
 extern "C" int jaco_stage_profile(JacoHandle* h, uint64_t* out_host, int reset) {
 #ifdef JACO_PROFILE_STAGES
   if (!h) return JACO_EINVAL;
+  ENTER(h);
   size_t n = (size_t)h->num_envs * JPROF_N;
   if (!h->prof) { HIPCHK(h, hipMalloc(&h->prof, n * 8)); HIPCHK(h, hipMemset(h->prof, 0, n * 8)); }
   HIPCHK(h, hipDeviceSynchronize());
@@ -559,6 +577,7 @@ extern "C" int jaco_enable_timing(JacoHandle* h, int enable) {
 }
 extern "C" int jaco_kernel_time_ms(JacoHandle* h, double* avg_ms, int* launches) {
   if (!h || !avg_ms) return JACO_EINVAL;
+  ENTER(h);
   HIPCHK(h, hipDeviceSynchronize());
   double tot = 0;
   for (size_t i = 0; i < h->events_used; i++) {

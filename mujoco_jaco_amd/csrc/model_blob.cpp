@@ -79,7 +79,7 @@ int jaco_model_from_blob(const void* buf, size_t size, JacoModelDev* m, std::vec
   const int32_t *it = B.i32("opt_iterations", 1), *mpi = B.i32("opt_mpr_iterations", 1);
   if (!ts || !gr || !tol || !mi || !mt || !it || !mpi) FAIL(B.err);
   m->timestep = (float)*ts; cp3(m->gravity, gr); m->tolerance = (float)*tol; m->meaninertia = (float)*mi;
-  m->mpr_tolerance = (float)*mt; m->iterations = *it; m->mpr_iterations = *mpi; m->ls_iterations = 50; m->ls_tolerance = 0.01f;
+  m->mpr_tolerance = (float)*mt; m->iterations = *it; m->mpr_iterations = *mpi; m->ls_iterations = 50; m->ls_tolerance = 0.01f; m->mpr_output = 1;
 
   // ---- bodies
   const int32_t *par = B.i32("f_parent", nb), *jt = B.i32("f_jtype", nb), *qa = B.i32("f_qposadr", nb), *da = B.i32("f_dofadr", nb);

@@ -87,6 +87,7 @@ struct JacoStepArgs {
   // env-level mode (jaco_step / jaco_reset): nsub = frame_skip
   int env_mode;              // 0 ctrl-level, 1 env step, 2 forward only (reset: fill cache + observation),
                              // 3 placing reset: nsub controlled substeps with the object pinned in the hand (env_mujoco_util.py:106-117)
+                             // 4 take_action only (env_mujoco.py:158-159), 5 terminal_inspection only (env_mujoco.py:144-150): no physics
   const unsigned char* mask; // modes 2 and 3: envs to run (nullptr = all)
   float* marker;             // [nenv][2][12] poses (position, rotation) of the "hand" / "subgoal_reach" markers, or nullptr = XML rest pose
   int task_id, nact;
@@ -987,6 +988,7 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
   float sens = 0.f;
   int iters = 0, left = 0, sub0 = 0, nls_last = 0, calm = 0;
   const int emode = A.env_mode;
+  if (emode >= 4) nsub = 0;   // take_action / terminal_inspection on their own: no substep runs
   if (emode) {   // task row + the one-substep-stale quantities the controller reads (env_logic.h)
     if (lane < JTASK_N) s.task[lane] = A.task[(size_t)env * JTASK_N + lane];
     const float* CR = A.cache + (size_t)env * JCACHE_N;
@@ -996,9 +998,9 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
     if (lane < 9) s.xmat[m->ee_body][lane] = CR[JC_EEMAT + lane];
   }
   wave_sync();
-  if (emode == 1) {
+  if (emode == 1 || emode == 4) {
     if (s.task[JT_DONE] != 0.f) {   // finished and not yet reset: frozen (no auto-reset)
-      if (lane == 0) { A.reward[env] = 0.f; A.done[env] = 1; }
+      if (lane == 0 && emode == 1) { A.reward[env] = 0.f; A.done[env] = 1; }
       return 0;
     }
     sub0 = wave_uniform_i((int)s.task[JT_SUB]);
@@ -1143,6 +1145,7 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
       constexpr int LCON = TIER == 2 ? JacoMedium::MAXCON : JacoLight::MAXCON, LEFC = TIER == 2 ? JacoMedium::MAXEFC : JacoLight::MAXEFC;
       calm = (s.ncon <= LCON && s.nefc <= LEFC && s.ncand <= JacoLight::MAXCAND / 2) ? calm + 1 : 0;
     }
+    if (TIER == 2) flags |= cflags;   // the last tier has nobody to hand over to: contacts / rows beyond its capacity were dropped, say so
     if (TIER < 2 && cflags) {   // capacity exceeded: leave this substep (and the rest) to the next tier; nothing was mutated
       left = nsub - sub;
       bailed = true;
@@ -1241,9 +1244,10 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
       if (lane < nv) { A.qvel[(size_t)env * nv + lane] = s.qvel[lane]; A.qacc_ws[(size_t)env * nv + lane] = s.qacc_ws[lane]; }
     }
   }
-  if (left == 0 && lane < ns && A.sensordata) A.sensordata[(size_t)env * ns + lane] = sens;
+  if (left == 0 && lane < ns && A.sensordata && emode < 4) A.sensordata[(size_t)env * ns + lane] = sens;
+  if (emode == 5) sens = (lane < ns && A.sensordata) ? A.sensordata[(size_t)env * ns + lane] : 0.f;   // touch of the last forward pass
   if (emode) {
-    if ((left == 0 && emode != 3) || (!LIGHT && left > 0 && !bailed && emode == 1)) {
+    if ((left == 0 && emode != 3 && emode < 4) || (!LIGHT && left > 0 && !bailed && emode == 1)) {
       // what the controller reads one substep late, for the next launch -- or, on a heavy -> light hand-back in the middle
       // of a step, for the light code's next substep
       float* CW = A.cache + (size_t)env * JCACHE_N;
@@ -1253,7 +1257,7 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
       if (lane < 3) { CW[JC_EEPOS + lane] = s.xpos[m->ee_body][lane]; CW[JC_OBJPOS + lane] = s.xpos[ob][lane]; }
       if (lane < 9) CW[JC_EEMAT + lane] = s.xmat[m->ee_body][lane];
     }
-    if (left == 0 && emode != 3) {
+    if (left == 0 && emode != 3 && emode != 4) {
       // observation, reward, termination from the poses / sensors of the last forward pass (one substep stale, as in
       // the reference) -- make_observation, _get_reward, terminal_inspection (env_mujoco.py:122-126)
       int ob = m->obj_body >= 0 ? m->obj_body : 0;
@@ -1273,10 +1277,14 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
       int succ = 0;
       bool done = false;
       const float PI = 3.14159265358979323846f;
-      if (emode == 1) {
-        rew = A.task_id == 0 ? reward_picking(pe, eul, obj, touch) : 0.f;
+      if (emode == 1 || emode == 5) {
+        rew = (A.task_id == 0 && emode == 1) ? reward_picking(pe, eul, obj, touch) : 0.f;
         float trow[4] = {0.f, s.task[JT_STEPS], s.task[JT_EPISODES], 0.f};
         done = terminal_inspection(A.task_id, trow, s.qpos[2], pe, ld3(m->base_pos), obj, destgoal, touch, &bonus, &succ, &wb);
+        // quarantine (failure row): a state that went non-finite ends the episode with no reward and stays
+        // frozen until it is reset -- what MuJoCo's own bad-state check does with mj_resetData, made visible to the learner
+        const bool bad = wave_ballot((flags & JFLAG_NAN) != 0u || !(rew == rew)) != 0ull;
+        if (bad) { done = true; rew = 0.f; bonus = 0.f; succ = 0; flags |= JFLAG_NAN; }
         wave_sync();
         if (lane == 0) {
           s.task[JT_STEPS] = trow[JT_STEPS]; s.task[JT_EPISODES] = trow[JT_EPISODES]; s.task[JT_DONE] = done ? 1.f : 0.f;
@@ -1285,8 +1293,8 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
           A.done[env] = done ? 1 : 0;
         }
       }
-      if (lane == 0) s.task[JT_RNG] = __uint_as_float(cnt + 6u);
-      if (lane < 26) {
+      if (lane == 0 && emode != 5) s.task[JT_RNG] = __uint_as_float(cnt + 6u);
+      if (lane < 26 && emode != 5) {
         float o;
         if (lane == 0) o = (float)touch;
         else if (lane < 4) o = lane == 1 ? pe.x : (lane == 2 ? pe.y : pe.z);
@@ -1298,6 +1306,7 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
         else if (lane < 20) o = spos[lane - 17];
         else if (lane < 23) o = sori[lane - 20] / PI;
         else o = lane == 24 ? PI / 2.f : 0.f;
+        if (!(fabsf(o) <= 3.0e38f)) o = 0.f;   // (quarantined env: the observation row stays finite)
         A.obs[(size_t)env * 26 + lane] = o;
       }
     }
@@ -1327,7 +1336,8 @@ __global__ __launch_bounds__(64, 2) void jaco_physics_kernel(JacoStepArgs A) {
   const int env = A.order ? A.order[env_id()] : env_id();
   const unsigned long long t_start = wave_clock();
   int left = run_env<JacoLight, 0>(A, s, env, A.nsub, lane);
-  if (lane == 0 && A.cost) { unsigned c = (unsigned)((wave_clock() - t_start) >> 4); if (left > 0) st_wt_u(&A.cost[env], c); else A.cost[env] = c; }
+  // (only real steps record their cost: the masked forward pass of a reset must not wipe the launch-order heuristic's input)
+  if (lane == 0 && A.cost && A.env_mode <= 1) { unsigned c = (unsigned)((wave_clock() - t_start) >> 4); if (left > 0) st_wt_u(&A.cost[env], c); else A.cost[env] = c; }
   // hand-off: the env's state went to memory with write-through stores (run_env); once they are acknowledged the env
   // is appended to the heavy tier's work list.  Heavy-tier workgroups run concurrently (jaco_env.hip) and poll the list.
   if (left > 0) {

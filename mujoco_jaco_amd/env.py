@@ -99,9 +99,7 @@ class JacoBatchedEnv:
     # ---- reference surface
     def reset(self, mask=None):
         self.current_steps = 0
-        m = None
-        if mask is not None:
-            m = mask.to(self.device).to(torch.uint8).contiguous()
+        m = self._mask(mask)
         self.sim._chk(self.L.jaco_reset(self.h, self._p(m) if m is not None else None, self._p(self._obs), self.sim._stream()))
         return self._out(self._obs)[0]
 
@@ -118,12 +116,44 @@ class JacoBatchedEnv:
 
     def _placing_hold(self, mask=None, nsub=150):
         """The held part of the placing reset on its own (env_mujoco_util.py:106-117); reset() runs it for task 'placing'."""
-        m = None if mask is None else mask.to(self.device).to(torch.uint8).contiguous()
+        m = self._mask(mask)
         self.sim._chk(self.L.jaco_placing_hold(self.h, self._p(m) if m is not None else None, int(nsub), self.sim._stream()))
 
+    def _mask(self, mask):
+        if mask is None:
+            return None
+        m = torch.as_tensor(mask, device=self.device)
+        if m.numel() != self.num_envs:
+            raise ValueError("mask must have one entry per env (%d), got shape %s" % (self.num_envs, tuple(m.shape)))
+        return m.reshape(self.num_envs).to(torch.uint8).contiguous()
+
+    def _action(self, action):
+        """Validated, clipped [num_envs, nact] fp32 device tensor (the kernel reads nact floats per env unconditionally)."""
+        a = torch.as_tensor(action, dtype=torch.float32, device=self.device)
+        nact = self.action_space.shape[0]
+        if a.numel() != self.num_envs * nact or (a.dim() > 1 and a.shape[-1] != nact):
+            raise ValueError("action must have shape (%d, %d), got %s" % (self.num_envs, nact, tuple(a.shape)))
+        a = a.reshape(self.num_envs, nact)
+        return torch.max(torch.min(a, self._amax), self._amin).contiguous()          # np.clip (env_mujoco.py:117)
+
+    def take_action(self, a, weight=None, subgoal=None, id=None):
+        """env_mujoco.py:158-159 -> _take_action (env_mujoco_util.py:602-646): EE target, gripper command, marker poses; no physics."""
+        a = self._action(a)
+        self.sim._chk(self.L.jaco_take_action(self.h, self._p(a), self.sim._stream()))
+
+    def terminal_inspection(self):
+        """env_mujoco.py:144-150: current_steps += 1, then (done, additional_reward, wb, succ) of the task's termination rule."""
+        bonus = torch.zeros(self.num_envs, device=self.device)
+        self.sim._chk(self.L.jaco_terminal_inspection(self.h, self._p(self._done), self._p(bonus), self.sim._stream()))
+        self.current_steps += 1
+        ts = self.task_state()
+        done, wb, succ = self._done.bool().clone(), ts[:, 30], ts[:, 29] > 0.5
+        if self.num_envs == 1:
+            return bool(done[0].item()), float(bonus[0].item()), float(wb[0].item()), int(succ[0].item())
+        return done, bonus, wb, succ
+
     def step(self, action, weight=None, subgoal=None, id=None):
-        a = torch.as_tensor(action, dtype=torch.float32, device=self.device).reshape(self.num_envs, -1)
-        a = torch.max(torch.min(a, self._amax), self._amin).contiguous()          # np.clip (env_mujoco.py:117)
+        a = self._action(action)
         self.sim._chk(self.L.jaco_step(self.h, self._p(a), self._p(self._obs), self._p(self._rew), self._p(self._done), self.sim._stream()))
         self.current_steps += 1
         obs, rew, done = self._out(self._obs, self._rew, self._done)

@@ -21,6 +21,7 @@ class JacoVecEnv:
         self._actions = None
         self.episode_returns = torch.zeros(self.num_envs, device=self.env.device)
         self.episode_lengths = torch.zeros(self.num_envs, dtype=torch.int64, device=self.env.device)
+        self.quarantined_total = 0
 
     def _out(self, *ts):
         return tuple(t.cpu().numpy() for t in ts) if self.to_numpy else ts
@@ -37,8 +38,15 @@ class JacoVecEnv:
         obs, rew, done, _ = self.env.step(self._actions)
         obs, rew, done = obs.clone(), rew.clone(), done.clone()
         self.episode_returns += rew; self.episode_lengths += 1
-        infos = {"terminal_observation": None, "episode_return": None, "episode_length": None, "is_success": None}
+        infos = {"terminal_observation": None, "episode_return": None, "episode_length": None, "is_success": None, "quarantined": 0}
         if bool(done.any()):
+            # envs whose state went non-finite end their episode inside jaco_step (reward 0, JACO_FLAG_NAN) and are reset here
+            # with the others; the count is reported and their flag cleared (failure row)
+            bad = (self.env.sim.flags() & 8) != 0
+            if bool(bad.any()):
+                infos["quarantined"] = int((bad & done).sum().item())
+                self.quarantined_total += infos["quarantined"]
+                self.env.sim.clear_flags()
             infos["terminal_observation"] = obs[done].clone()
             infos["episode_return"] = self.episode_returns[done].clone()
             infos["episode_length"] = self.episode_lengths[done].clone()

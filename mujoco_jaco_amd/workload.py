@@ -7,19 +7,24 @@ destination pedestal; `random_ctrl` draws ctrl = U(-1,1) * motor force range, fi
 import numpy as np
 
 
-def reset_states(qpos0, nenv, seed=0, contact=True):
+def reset_states(qpos0, nenv, seed=0, contact=True, f32_draws=False):
+    """f32_draws: the drawn coordinates are rounded to fp32 (so an fp32 and an fp64 engine can be handed the same numbers), the
+    model's own constants (finger angles 1.1, pedestal height 0.09, ...) stay exactly what the XML says -- the pedestal's
+    bottom face is at z = 0.09 + 0.07 - 0.16 = 0 by construction, a knife edge that the fp32-rounded 0.09f would move 3.6 nm
+    above the floor for an fp64 engine (no contact in the first step) while the fp32 engine still computes exactly 0."""
     rng = np.random.default_rng(seed)
     nq = len(qpos0)
     q = np.tile(np.asarray(qpos0, np.float64), (nenv, 1))
+    r = (lambda a: np.asarray(a, np.float64).astype(np.float32).astype(np.float64)) if f32_draws else (lambda a: a)
     lo = np.array([0.7, 3.8, 1.0, 1.8, 1.0, 0.8]); hi = np.array([2.5, 4.0, 1.7, 2.5, 2.5, 2.3])
-    q[:, :6] = rng.uniform(lo, hi, (nenv, 6))
+    q[:, :6] = r(rng.uniform(lo, hi, (nenv, 6)))
     if nq >= 23:
-        q[:, 9] = rng.uniform(-0.1, 0.1, nenv)
-        q[:, 10] = 0.65 + rng.uniform(-0.08, 0.02, nenv)
-        q[:, 11] = 0.1898 if contact else 0.5
+        q[:, 9] = r(rng.uniform(-0.1, 0.1, nenv))
+        q[:, 10] = r(0.65 + rng.uniform(-0.08, 0.02, nenv))
+        q[:, 11] = r(0.1898 if contact else 0.5)
         q[:, 12:16] = [1, 0, 0, 0]
-        q[:, 16] = 0.4 + rng.uniform(-0.05, 0.05, nenv)
-        q[:, 17] = 0.3 + rng.uniform(-0.05, 0.05, nenv)
+        q[:, 16] = r(0.4 + rng.uniform(-0.05, 0.05, nenv))
+        q[:, 17] = r(0.3 + rng.uniform(-0.05, 0.05, nenv))
     return q
 
 

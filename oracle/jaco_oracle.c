@@ -24,6 +24,8 @@ struct OrcModel {
   int nq, nv, nu, nbody, njnt, ngeom, nsite, nmesh, nmocap, nsensor, npair;
   double timestep, gravity[3], tolerance, mpr_tolerance, meaninertia;
   int iterations, mpr_iterations, disable_contact, solver, ls_iterations;
+  int mpr_output;  /* 0: libccd's closest point of the final portal triangle; 1 (default): portal plane (see mpr_penetration) */
+  int round_state; /* control experiment: 1 = qpos/qvel/qacc_warmstart are rounded to fp32 after every step (an fp64 engine carrying fp32 state) */
   double ls_tolerance;
   int *body_parentid, *body_weldid, *body_mocapid, *body_jntadr, *body_jntnum, *body_dofadr, *body_dofnum;
   double *body_pos, *body_quat, *body_ipos, *body_inertia, *body_mass, *body_invweight0;
@@ -184,7 +186,7 @@ OrcModel* orc_load_model(const char* path) {
   m->nmesh = *nmesh; m->nmocap = *nmocap; m->nsensor = *nsensor; m->npair = *npair;
   m->timestep = *ts; memcpy(m->gravity, grav, 24); m->tolerance = *tol; m->iterations = *iters;
   m->mpr_tolerance = *mprt; m->mpr_iterations = *mpri; m->meaninertia = *meani;
-  m->solver = ORC_SOLVER_NEWTON; m->ls_iterations = 50; m->ls_tolerance = 0.01;
+  m->solver = ORC_SOLVER_NEWTON; m->ls_iterations = 50; m->ls_tolerance = 0.01; m->mpr_output = 1;
   return m;
 }
 void orc_free_model(OrcModel* m) { if (m) { free(m->blob); free(m); } }
@@ -205,6 +207,8 @@ int orc_set_option(OrcModel* m, const char* n, double v) {
   else if (!strcmp(n, "ls_tolerance")) m->ls_tolerance = v;
   else if (!strcmp(n, "mpr_iterations")) m->mpr_iterations = (int)v;
   else if (!strcmp(n, "mpr_tolerance")) m->mpr_tolerance = v;
+  else if (!strcmp(n, "round_state")) m->round_state = (int)v;
+  else if (!strcmp(n, "mpr_output")) m->mpr_output = (int)v;
   else return -1;
   return 0;
 }
@@ -864,9 +868,19 @@ static int mpr_penetration(const OrcModel* m, const OrcData* d, int g1, int g2, 
     portal_dir(p, dr);
     mpr_support(m, d, g1, g2, dr, &v4);
     if (reach_tol(p, &v4, dr, tol) || it > m->mpr_iterations) {
-      double cp[3];
-      *depth = point_tri_closest(p[1].v, p[2].v, p[3].v, cp);
-      if (*depth < 1e-14) copy3(dir, dr); else { copy3(dir, cp); normalize3(dir); }
+      if (m->mpr_output == 1) {
+        /* Portal-plane output: the refined portal lies (within mpr_tolerance) in the face of the Minkowski difference that
+         * the ray from the interior point through the origin leaves by; its normal and the support value h(dr) = v4 . dr
+         * do not depend on WHICH triangle of that face the refinement ended on.  libccd's closest point of the final
+         * triangle (mpr_output 0) equals this whenever the origin projects into the triangle, and otherwise depends on the
+         * refinement path even in exact arithmetic (and, for shallow contacts, on the last bits of a ~1e-6 vector). */
+        copy3(dir, dr);
+        *depth = dot3(v4.v, dr);
+      } else {
+        double cp[3];
+        *depth = point_tri_closest(p[1].v, p[2].v, p[3].v, cp);
+        if (*depth < 1e-14) copy3(dir, dr); else { copy3(dir, cp); normalize3(dir); }
+      }
       mpr_find_pos(p, pos);
       return 0;
     }
@@ -1291,6 +1305,10 @@ static void integrate(const OrcModel* m, OrcData* d) {
 void orc_step(const OrcModel* m, OrcData* d) {
   orc_forward(m, d);
   integrate(m, d);
+  if (m->round_state) { /* control experiment (tools/drift_control.py): what an fp32-state engine loses per step, nothing else */
+    for (int i = 0; i < m->nq; i++) d->qpos[i] = (double)(float)d->qpos[i];
+    for (int i = 0; i < m->nv; i++) { d->qvel[i] = (double)(float)d->qvel[i]; d->qacc_warmstart[i] = (double)(float)d->qacc_warmstart[i]; }
+  }
 }
 
 /* ------------------------------------------------------------------ accessors */
@@ -1342,6 +1360,11 @@ int orc_get(const OrcModel* m, const OrcData* d, const char* name, double* out, 
 
 void orc_step_batch(const OrcModel* m, int nenv, int nsub, double* qpos, double* qvel, double* qacc_ws, const double* ctrl,
                     double* sensordata, int nthreads) {
+  orc_step_batch_stats(m, nenv, nsub, qpos, qvel, qacc_ws, ctrl, sensordata, nthreads, NULL);
+}
+/* same, and per env stats[4] = max contacts, max constraint rows, max solver iterations over the nsub steps, contacts of the last step */
+void orc_step_batch_stats(const OrcModel* m, int nenv, int nsub, double* qpos, double* qvel, double* qacc_ws, const double* ctrl,
+                          double* sensordata, int nthreads, int* stats) {
 #ifdef _OPENMP
 #pragma omp parallel num_threads(nthreads > 0 ? nthreads : 1)
 #endif
@@ -1355,7 +1378,14 @@ void orc_step_batch(const OrcModel* m, int nenv, int nsub, double* qpos, double*
       memcpy(d->qvel, qvel + (long)e * m->nv, sizeof(double) * m->nv);
       memcpy(d->qacc_warmstart, qacc_ws + (long)e * m->nv, sizeof(double) * m->nv);
       memcpy(d->ctrl, ctrl + (long)e * m->nu, sizeof(double) * m->nu);
-      for (int s = 0; s < nsub; s++) orc_step(m, d);
+      int mc = 0, me = 0, mi = 0;
+      for (int s = 0; s < nsub; s++) {
+        orc_step(m, d);
+        if (d->ncon > mc) mc = d->ncon;
+        if (d->nefc > me) me = d->nefc;
+        if (d->solver_iter > mi) mi = d->solver_iter;
+      }
+      if (stats) { stats[4 * e] = mc; stats[4 * e + 1] = me; stats[4 * e + 2] = mi; stats[4 * e + 3] = d->ncon; }
       memcpy(qpos + (long)e * m->nq, d->qpos, sizeof(double) * m->nq);
       memcpy(qvel + (long)e * m->nv, d->qvel, sizeof(double) * m->nv);
       memcpy(qacc_ws + (long)e * m->nv, d->qacc_warmstart, sizeof(double) * m->nv);

@@ -57,6 +57,9 @@ void orc_jac_body_com(const OrcModel* m, const OrcData* d, int body, double* jac
  * (qpos[nenv][nq], ...), nsub substeps each with constant ctrl; threads via OpenMP if built with it. */
 void orc_step_batch(const OrcModel* m, int nenv, int nsub, double* qpos, double* qvel, double* qacc_ws,
                     const double* ctrl, double* sensordata, int nthreads);
+/* same + per-env stats[4]: max contacts, max rows, max solver iterations over the nsub steps, contacts of the last step (or NULL) */
+void orc_step_batch_stats(const OrcModel* m, int nenv, int nsub, double* qpos, double* qvel, double* qacc_ws,
+                          const double* ctrl, double* sensordata, int nthreads, int* stats);
 
 #ifdef __cplusplus
 }

@@ -15,6 +15,7 @@ extern "C" int emu_lds_bytes() { return (int)sizeof(JacoLDS<JacoLight>); }
 extern "C" int emu_lds_bytes_heavy() { return (int)sizeof(JacoLDS<JacoHeavy>); }
 extern "C" int emu_lds_bytes_medium() { return (int)sizeof(JacoLDS<JacoMedium>); }
 
+static int g_mpr_output_fwd();
 static JacoModelDev g_model;
 static std::vector<float> g_hull;
 static int g_no_tier_return_fwd();
@@ -42,6 +43,7 @@ extern "C" int emu_env_call(const void* blob, long blob_size, int nenv, int mode
                             const float* action, const float* noise, float* obs, float* reward, unsigned char* done, float* marker, int* heavy_envs) {
   std::string err;
   if (jaco_model_from_blob(blob, (size_t)blob_size, &g_model, &g_hull, &err)) { fprintf(stderr, "emu: %s\n", err.c_str()); return -1; }
+  if (g_mpr_output_fwd() >= 0) g_model.mpr_output = g_mpr_output_fwd();
   JacoStepArgs A{};
   A.model = &g_model; A.hull = g_hull.data(); A.qpos = qpos; A.qvel = qvel; A.qacc_ws = qacc_ws; A.ctrl = qvel; A.sensordata = sensordata;
   A.flags = flags; A.stats = stats; A.nenv = nenv; A.nsub = mode == 2 ? 1 : frame_skip; A.env_mode = mode; A.task_id = task_id; A.nact = nact;
@@ -56,6 +58,8 @@ extern "C" int emu_marker_rest(const void* blob, long blob_size, float* out) {
   return 0;
 }
 static int g_no_tier_return = 0;
+static int g_mpr_output = -1;   // -1: the model loader's default
+extern "C" void emu_set_mpr_output(int v) { g_mpr_output = v; }
 extern "C" void emu_set_tier_return(int on) { g_no_tier_return = !on; }
 extern "C" int emu_task_floats() { return JTASK_N; }
 extern "C" int emu_cache_floats() { return JCACHE_N; }
@@ -66,6 +70,7 @@ extern "C" int emu_physics_step(const void* blob, long blob_size, int nenv, int 
   static std::vector<float> hull;
   std::string err;
   if (jaco_model_from_blob(blob, (size_t)blob_size, &model, &hull, &err)) { fprintf(stderr, "emu: %s\n", err.c_str()); return -1; }
+  if (g_mpr_output >= 0) model.mpr_output = g_mpr_output;
   JacoStepArgs A{};
   A.model = &model; A.hull = hull.data(); A.qpos = qpos; A.qvel = qvel; A.qacc_ws = qacc_ws; A.ctrl = ctrl; A.sensordata = sensordata;
   A.flags = flags; A.stats = stats; A.nenv = nenv; A.nsub = nsub; A.disable_contact = disable_contact; A.dbg = dbg; A.dbg_env = dbg_env;
@@ -85,3 +90,4 @@ extern "C" int emu_physics_step(const void* blob, long blob_size, int nenv, int 
 }
 
 static int g_no_tier_return_fwd() { return g_no_tier_return; }
+static int g_mpr_output_fwd() { return g_mpr_output; }

@@ -44,6 +44,7 @@ def lib():
         L.orc_step.argtypes = [vp, vp]
         L.orc_jac_body_com.argtypes = [vp, vp, ci, dp, dp]
         L.orc_step_batch.argtypes = [vp, ci, ci, dp, dp, dp, dp, dp, ci]
+        L.orc_step_batch_stats.argtypes = [vp, ci, ci, dp, dp, dp, dp, dp, ci, ctypes.POINTER(ctypes.c_int)]
         _lib = L
     return _lib
 
@@ -129,10 +130,14 @@ class Oracle:
         self.L.orc_jac_body_com(self.m, self.d, body, _dp(jp), _dp(jr))
         return jp.reshape(3, -1), jr.reshape(3, -1)
 
-    def step_batch(self, qpos, qvel, qacc_ws, ctrl, nsub=1, nthreads=1, sensordata=None):
-        """In-place batched stepping of env-major fp64 arrays."""
+    def step_batch(self, qpos, qvel, qacc_ws, ctrl, nsub=1, nthreads=1, sensordata=None, stats=None):
+        """In-place batched stepping of env-major fp64 arrays; stats: optional int32 [nenv, 4] (max ncon, max nefc, max iterations, last ncon)."""
         nenv = qpos.shape[0]
         for a in (qpos, qvel, qacc_ws, ctrl):
             assert a.dtype == np.float64 and a.flags.c_contiguous
         sp = _dp(sensordata) if sensordata is not None else None
-        self.L.orc_step_batch(self.m, nenv, nsub, _dp(qpos), _dp(qvel), _dp(qacc_ws), _dp(ctrl), sp, nthreads)
+        st = None
+        if stats is not None:
+            assert stats.dtype == np.int32 and stats.flags.c_contiguous and stats.shape == (nenv, 4)
+            st = stats.ctypes.data_as(ctypes.POINTER(ctypes.c_int))
+        self.L.orc_step_batch_stats(self.m, nenv, nsub, _dp(qpos), _dp(qvel), _dp(qacc_ws), _dp(ctrl), sp, nthreads, st)

@@ -156,7 +156,7 @@ def test_touch_sensor_uses_the_normal_ray(names, model_arrays):
     from mujoco_jaco_amd.modelc import rot
     M = model_arrays
     o = Oracle()
-    q = o.get("qpos"); q[:6] = [1.5, 3.9, 1.3, 2.0, 2.0, 1.5]; q[6:9] = 1.4   # fingers open
+    q = o.get("qpos"); q[:6] = [1.5, 3.9, 1.3, 2.0, 2.0, 1.5]; q[6:9] = 1.0   # fingers half open: pads of all three fingers press on the box
     o.set("qpos", q); o.forward()
     b = names["body"].index("palm_plane")
     xp = o.get("xpos").reshape(-1, 3)[b]; xq = o.get("xquat").reshape(-1, 4)[b]

@@ -49,3 +49,17 @@ def test_obs_gather_world2_gloo():
     out = mgr.dict()
     mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
     assert dict(out) == {0: 2.0, 1: 2.0}
+
+
+def test_bench_self_launch_dry_gather():
+    """`bench.py --gpus 2` outside a launcher spawns its own ranks (before any GPU call) and aggregates: rehearsed on gloo / CPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-gather", "--steps", "3"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["gather_ok"] and line["steps"] == 3

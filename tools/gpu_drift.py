@@ -1,6 +1,7 @@
 """Drift of the HIP path against the fp64 oracle over 1 000 physics steps (the BASELINE metric's second half, with the
 oracle standing in for the MuJoCo that is not available): ctrl level (constant random torques, 1 000 substeps) for 256
-envs of the picking reset distribution, and the arm-only model (config 2, no contacts) for 256 envs."""
+envs of the picking reset distribution, and the arm-only model (config 2, no contacts) for 256 envs.  Per-env results go to
+gpurun_out/gpu_drift.npz for tools/drift_attribution.py."""
 import os, sys
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -10,9 +11,9 @@ from mujoco_jaco_amd.modelc import blob
 from mujoco_jaco_amd.physics import BatchedMujoco
 from oracle_binding import Oracle
 
-def run(model, B, nsub, contact, scale):
+def run(model, B, nsub, contact, scale, save=None):
     M = blob.load(_lib.model_path(model))
-    q = workload.reset_states(M["qpos0"], B, seed=41)
+    q = workload.reset_states(M["qpos0"], B, seed=41, f32_draws=True)
     nu = int(M["nu"][0]); nv = int(M["nv"][0])
     c = workload.random_ctrl(B, seed=42, scale=scale)[:, :nu]
     env = BatchedMujoco(B, robot_file=model)
@@ -22,7 +23,7 @@ def run(model, B, nsub, contact, scale):
     if not contact:
         env.set_option("disable_contact", 1); o.option("disable_contact", 1)
     out = {}
-    qo, vo, wo = np.ascontiguousarray(q.astype(np.float32).astype(np.float64)), np.zeros((B, nv)), np.zeros((B, nv))
+    qo, vo, wo = np.ascontiguousarray(q), np.zeros((B, nv)), np.zeros((B, nv))
     cc = np.ascontiguousarray(c.astype(np.float32).astype(np.float64))
     done = 0
     for mark in (100, 300, 1000):
@@ -33,7 +34,10 @@ def run(model, B, nsub, contact, scale):
         out[mark] = err
         print("%-24s %4d substeps: max-abs qpos error median %.2e  p90 %.2e  p99 %.2e  max %.2e  (<= 1e-4: %.1f %%)" % (
             model, mark, np.median(err), *np.percentile(err, [90, 99]), err.max(), 100 * np.mean(err <= 1e-4)))
+    if save:
+        np.savez(save, flags=env.flags().cpu().numpy(), **{"err_%d" % k: v for k, v in out.items()})
     return out
 
-run("jaco2_reaching_torque", 256, 1000, False, 0.2)
-run("jaco2_curtain_torque", 256, 1000, True, 0.2)
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+run("jaco2_reaching_torque", B, 1000, False, 0.2)
+run("jaco2_curtain_torque", B, 1000, True, 0.2, save=os.path.join(ROOT, "gpurun_out", "gpu_drift.npz"))
