@@ -1,9 +1,12 @@
 """GPU tier: the HIP path (through the C ABI, libjaco_env.so) against the fp64 oracle on identical inputs.
 
-Tolerances (stated per BASELINE.json's "stated fp32 tolerance"):
-  * single step from identical state:  |dqpos| <= 2e-6, |dqvel| <= 2e-3 (finger dofs accelerate at ~1e3 rad/s^2)
-  * free-running over N substeps: bulk of the batch (median) <= 1e-5; contact-rich chaotic tails are reported,
-    not bounded (a reset draw can put the hand 5 cm inside the pedestal, see DESIGN.md "Parity")
+Tolerances (stated per BASELINE.json's "stated fp32 tolerance"; measured in profiles/r02_drift_attribution.txt):
+  * single step from identical state, MAX over every env whose contact set is the oracle's (same contact and row counts,
+    no capacity flag):  |dqpos| <= 2e-6, |dqvel| <= 2e-3 (h = 1e-3; finger dofs accelerate at ~1e3 rad/s^2).
+    The other envs (a contact switching on or off exactly at this step: <= 3 %) are counted, not bounded.
+  * free-running over N substeps: contact dynamics amplify last-bit differences, so the bar is the fp64 oracle carrying
+    fp32-rounded state ("control", no fp32 arithmetic at all): the HIP path must lose no more envs than the control does,
+    and stay <= 1e-4 (MAX) on every env the control keeps <= 1e-5 and that raised no capacity flag.
   * integer-like outputs (contact count, row count, flags) exact on the single-step check.
 Full-size (65 536 env) checks use size-independent properties: bitwise determinism, independence of an env from
 its batch neighbours, nsub composition, unit quaternions, finite state.
@@ -33,29 +36,41 @@ def _oracle_batch(model, q, v, w, c, nsub):
     return q, v, w
 
 
+def _oracle_batch_stats(model, q, v, w, c, nsub, round_state=False):
+    import os
+    from oracle_binding import Oracle
+    o = Oracle(model)
+    if round_state:
+        o.option("round_state", 1)
+    q, v, w = q.copy(), v.copy(), w.copy()
+    st = np.zeros((q.shape[0], 4), np.int32)
+    o.step_batch(q, v, w, np.ascontiguousarray(c), nsub=nsub, nthreads=os.cpu_count(), stats=st)
+    return q, v, w, st
+
+
 def test_single_step_parity_reset_distribution(model_arrays):
     from mujoco_jaco_amd import workload
-    B = 512
+    B = 1024
     q = workload.reset_states(model_arrays["qpos0"], B, seed=21)
-    c = workload.random_ctrl(B, seed=22, scale=0.2)
-    # advance a few steps on the oracle first so velocities / warm starts are non-trivial
+    c = workload.random_ctrl(B, seed=22, scale=0.2).astype(np.float32).astype(np.float64)
+    # advance a few steps on the oracle first so velocities / warm starts are non-trivial; then both sides get the same
+    # fp32-representable state
     q, v, w = _oracle_batch("jaco2_curtain_torque", q, np.zeros((B, 21)), np.zeros((B, 21)), c, 12)
+    q, v, w = [a.astype(np.float32).astype(np.float64) for a in (q, v, w)]
     env = _env(B)
     env.set_state(_t(q, env.device), _t(v, env.device), _t(w, env.device))
     env.send_forces(_t(c, env.device), nsub=1)
     gq, gv, _ = [t.cpu().numpy().astype(np.float64) for t in env.get_state()]
-    # oracle from the fp32-rounded state the GPU actually received
-    q32, v32, w32 = [a.astype(np.float32).astype(np.float64) for a in (q, v, w)]
-    qo, vo, _ = _oracle_batch("jaco2_curtain_torque", q32, v32, w32, c.astype(np.float32).astype(np.float64), 1)
+    qo, vo, _, st = _oracle_batch_stats("jaco2_curtain_torque", q, v, w, c, 1)
     eq, ev = np.abs(gq - qo).max(1), np.abs(gv - vo).max(1)
-    print("single step: qpos err median %.2e p90 %.2e p99 %.2e max %.2e" % (np.median(eq), *np.percentile(eq, [90, 99]), eq.max()))
-    # bulk: fp32 rounding.  The tail (few %) are envs whose hand starts inside the pedestal: >256 rows (buffer overflow,
-    # flagged) or hull contacts whose MPR portal path differs between fp32 and fp64 (DESIGN.md "Parity")
-    assert np.median(eq) <= 3e-7 and np.percentile(eq, 90) <= 2e-6, (np.median(eq), eq.max())
-    assert np.percentile(ev, 90) <= 2e-3
     fl = env.flags().cpu().numpy()
-    clean = (fl & 3) == 0
-    assert np.percentile(eq[clean], 97) <= 1e-4
+    gs = env.stats().cpu().numpy()
+    clean = ((fl & 7) == 0) & (gs[:, 0] == st[:, 0]) & (gs[:, 1] == st[:, 1])
+    print("single step: %d of %d envs have the oracle's contact set; over those qpos err median %.2e max %.2e, qvel err max %.2e; others: max %.2e" % (
+        clean.sum(), B, np.median(eq[clean]), eq[clean].max(), ev[clean].max(), eq[~clean].max() if (~clean).any() else 0.0))
+    assert clean.mean() >= 0.97
+    assert eq[clean].max() <= 2e-6 and ev[clean].max() <= 2e-3, (eq[clean].max(), ev[clean].max())   # measured 2.7e-7 / 2.2e-4
+    assert np.median(eq) <= 3e-7
     assert int(env.flags().max()) & 8 == 0
 
 
@@ -85,23 +100,48 @@ def test_stage_dump_and_counts_match(model_arrays):
         box = oc[:, 9] == 3                                               # analytic (plane / box) contacts; hull contacts: see DESIGN.md
         assert np.abs(C[box, 0] - oc[box, 0]).max() < 1e-6 and np.abs(C[box, 1:4] - oc[box, 1:4]).max() < 1e-6
         assert np.abs(C[box, 4:7] - oc[box, 4:7]).max() < 1e-5
+        hull = ~box                                                       # MPR contacts: portal-plane output (collision.h) agrees across precisions
+        if hull.any():
+            dh = (np.abs(C[hull, 0] - oc[hull, 0]).max(), np.abs(C[hull, 1:4] - oc[hull, 1:4]).max(), np.abs(C[hull, 4:7] - oc[hull, 4:7]).max())
+            print("hull contacts of env %d: dist / pos / normal max diff %.2e %.2e %.2e" % ((k,) + dh))
+            assert dh[0] < 1e-5 and dh[1] < 1e-4 and dh[2] < 1e-3
 
 
-def test_free_running_drift_bulk(model_arrays):
+def _drift_vs_control(model_arrays, B, nsub, seed):
     from mujoco_jaco_amd import workload
-    B, nsub = 256, 200
-    q = workload.reset_states(model_arrays["qpos0"], B, seed=41)
-    c = workload.random_ctrl(B, seed=42, scale=0.2)
+    q = workload.reset_states(model_arrays["qpos0"], B, seed=seed, f32_draws=True)
+    c = workload.random_ctrl(B, seed=seed + 1, scale=0.2).astype(np.float32).astype(np.float64)
     env = _env(B)
     env.set_state(_t(q, env.device), None, None)
     env.send_forces(_t(c, env.device), nsub=nsub)
     gq = env.get_state()[0].cpu().numpy().astype(np.float64)
-    qo, _, _ = _oracle_batch("jaco2_curtain_torque", q.astype(np.float32).astype(np.float64), np.zeros((B, 21)), np.zeros((B, 21)),
-                             c.astype(np.float32).astype(np.float64), nsub)
-    err = np.abs(gq - qo).max(1)
-    print("drift after %d substeps: median %.2e p90 %.2e p99 %.2e max %.2e" % (nsub, np.median(err), *np.percentile(err, [90, 99]), err.max()))
-    assert np.median(err) <= 1e-5
-    assert np.mean(err <= 1e-4) >= 0.85
+    z = np.zeros((B, 21))
+    qo, _, _, _ = _oracle_batch_stats("jaco2_curtain_torque", q, z, z, c, nsub)
+    qc, _, _, _ = _oracle_batch_stats("jaco2_curtain_torque", q, z, z, c, nsub, round_state=True)   # control: fp64 arithmetic, fp32 state
+    err, ctl = np.abs(gq - qo).max(1), np.abs(qc - qo).max(1)
+    fl = env.flags().cpu().numpy()
+    print("drift after %d substeps: HIP median %.2e p90 %.2e max %.2e (<= 1e-4: %.1f %%) | fp64 control with fp32 state: median %.2e p90 %.2e max %.2e (<= 1e-4: %.1f %%)" % (
+        nsub, np.median(err), np.percentile(err, 90), err.max(), 100 * np.mean(err <= 1e-4), np.median(ctl), np.percentile(ctl, 90), ctl.max(), 100 * np.mean(ctl <= 1e-4)))
+    return err, ctl, fl
+
+
+def test_free_running_drift_100_substeps(model_arrays):
+    err, ctl, fl = _drift_vs_control(model_arrays, 256, 100, 41)
+    calm = (ctl <= 1e-5) & ((fl & 7) == 0)       # envs the control itself keeps together, no dropped rows / contacts
+    assert calm.mean() >= 0.95
+    assert err[calm].max() <= 1e-4, err[calm].max()                          # MAX over the attributed-clean set
+    assert np.median(err) <= 2 * np.median(ctl) + 1e-7
+    assert np.mean(err <= 1e-4) >= np.mean(ctl <= 1e-4) - 0.02
+
+
+def test_free_running_drift_1000_substeps_matches_fp64_control(model_arrays):
+    """The headline drift metric: after 1 000 substeps most contact-rich envs have parted from the oracle by more than
+    1e-4 -- and so has the fp64 oracle from itself when its state is rounded to fp32 every step.  The HIP path must not
+    lose more envs than that control (within sampling noise), nor be further out in the bulk."""
+    err, ctl, fl = _drift_vs_control(model_arrays, 256, 1000, 41)
+    assert np.mean(err <= 1e-4) >= np.mean(ctl <= 1e-4) - 0.06
+    assert np.median(err) <= 3 * np.median(ctl)
+    assert np.percentile(err, 25) <= 1e-4
 
 
 def test_arm_only_config2_4096_envs():
@@ -200,4 +240,5 @@ def test_touch_sensors_in_grasp(model_arrays, names):
         so = o.get("sensordata")
         nmatch += int(np.abs(s[0] - so).max() <= 2e-2 * max(1.0, so.max()))
         nclass += int(touch_class(s[0]) == touch_class(so))
-    assert nmatch >= 24 and nclass >= 27   # hull contacts can differ for single steps (MPR path, DESIGN.md "Parity")
+    print('touch: sensordata within 2 %% in %d of 30 frames, class equal in %d' % (nmatch, nclass))
+    assert nmatch >= 29 and nclass >= 29   # (a contact entering a site volume exactly at a frame can differ for that frame)

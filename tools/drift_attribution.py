@@ -66,18 +66,22 @@ def classify(rec):
 
 
 if __name__ == "__main__":
-    B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+    B = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 256
     from mujoco_jaco_amd import workload, _lib
     from mujoco_jaco_amd.modelc import blob
     M = blob.load(_lib.model_path(MODEL))
     q = workload.reset_states(M["qpos0"], B, seed=41, f32_draws=True)
     c = workload.random_ctrl(B, seed=42, scale=0.2).astype(np.float32).astype(np.float64)
-    with mp.Pool(os.cpu_count()) as pool:
-        res = pool.map(one_env, [(k, q[k], c[k]) for k in range(B)], chunksize=1)
-    rec = np.zeros((B, NSTEP, 8))
-    for k, r in res:
-        rec[k] = r
-    np.save(os.path.join(ROOT, "gpurun_out", "drift_attribution.npy"), rec)
+    if "--report" in sys.argv:   # re-print the tables from the saved per-step records
+        rec = np.load(os.path.join(ROOT, "gpurun_out", "drift_attribution.npy"))
+        B = rec.shape[0]
+    else:
+        with mp.Pool(os.cpu_count()) as pool:
+            res = pool.map(one_env, [(k, q[k], c[k]) for k in range(B)], chunksize=1)
+        rec = np.zeros((B, NSTEP, 8))
+        for k, r in res:
+            rec[k] = r
+        np.save(os.path.join(ROOT, "gpurun_out", "drift_attribution.npy"), rec)
     final = rec[:, -1, 0]
     print("free-running fp32 kernel (emulated) vs fp64 oracle, %d envs x %d steps: <= 1e-4: %.1f %%, median %.2e" % (B, NSTEP, 100 * np.mean(final <= 1e-4), np.median(final)))
     for mark in (100, 300, 1000):

@@ -6,7 +6,10 @@ Controls, all run by the SAME fp64 code on the SAME envs / ctrl as tools/gpu_dri
   A  fp64 oracle                                   (the reference trajectory)
   B  fp64 oracle whose state (qpos, qvel, qacc_warmstart) is rounded to fp32 after every step
   C  fp64 oracle started from a state 1 ulp(fp32) away in the six arm joints
-B and C contain no fp32 arithmetic at all: every force, contact and solve is fp64.  Whatever divergence they show is the
+  D  fp64 oracle handed the pedestal height as the fp32 number 0.09f instead of 0.09 (3.6e-9 higher): the pedestal's bottom
+     face sits exactly on the floor plane by construction (0.09 + 0.07 - 0.16), so this decides whether its 4 floor contacts
+     exist in the very first step -- the knife edge every reset of the reference starts on
+B, C and D contain no fp32 arithmetic at all: every force, contact and solve is fp64.  Whatever divergence they show is the
 floor for any engine that carries fp32 state (B) or is handed inputs that differ in the last fp32 bit (C).
 Writes per-env errors at 100 / 300 / 1000 steps + the oracle's max contact / row counts to an .npz for the attribution.
 """
@@ -32,9 +35,9 @@ def run(model, B, contact, scale, variant, seed=41):
     if variant == "B":
         o.option("round_state", 1)
     if variant == "C":
-        q32 = q.astype(np.float32)
-        q32[:, :6] = np.nextafter(q32[:, :6], np.float32(np.inf))
-        q = q32.astype(np.float64)
+        q[:, :6] = np.nextafter(q[:, :6].astype(np.float32), np.float32(np.inf)).astype(np.float64)
+    if variant == "D" and q.shape[1] >= 23:
+        q[:, 18] = np.float64(np.float32(q[:, 18]))   # pedestal height 0.09 -> 0.09f: its bottom face leaves the floor plane by 3.6 nm
     q = np.ascontiguousarray(q)
     v, w = np.zeros((B, nv)), np.zeros((B, nv))
     out, done = {}, 0
@@ -61,7 +64,10 @@ if __name__ == "__main__":
     for model, contact in (("jaco2_reaching_torque", False), ("jaco2_curtain_torque", True)):
         ref, smax = run(model, B, contact, 0.2, "A")
         save[model + "_maxcon"] = smax[:, 0]; save[model + "_maxefc"] = smax[:, 1]
-        for variant, what in (("B", "fp64 oracle, fp32-rounded state"), ("C", "fp64 oracle, +1 ulp(fp32) initial arm angles")):
+        for variant, what in (("B", "fp64 oracle, fp32-rounded state"), ("C", "fp64 oracle, +1 ulp(fp32) initial arm angles"),
+                              ("D", "fp64 oracle, pedestal height 0.09f instead of 0.09")):
+            if variant == "D" and not contact:
+                continue
             got, _ = run(model, B, contact, 0.2, variant)
             err = {k: np.abs(got[k] - ref[k]).max(1) for k in MARKS}
             summarize("%s | %s" % (model, what), err)
