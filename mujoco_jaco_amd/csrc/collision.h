@@ -537,80 +537,86 @@ template <class L>
 JDEV void stage_contact_rows(const JacoModelDev* m, L& s, int lane, unsigned& flags) {
   constexpr int MAXEFC = L::Caps::MAXEFC;
   const int nv = m->nv, ncon = wave_uniform_i(s.ncon), nlim = wave_uniform_i(s.nlimit);
-  // rows per contact and row offsets: lane = contact
-  int dim = 0, nrow = 0;
-  float mu0 = 0.f, mu1 = 0.f, mu2 = 0.f;
-  unsigned cm1 = 0, cm2 = 0;
-  // per-contact row parameters (lane = contact), from the pair's pre-mixed constants: every row of a contact shares the
-  // regulariser (pyramidal: 2 mu^2 R of the first row, impratio = 1) and the position part of aref; only the velocity
-  // part differs per row.  aref_row = a0 - bcoef * vel_row,  D_row = dinv.
-  float a0 = 0.f, bcoef = 0.f, dinv = 0.f;
-  if (lane < ncon) {
-    const JacoPairParam& P = m->pair[s.c_pair[lane]];
-    dim = s.c_dim[lane]; nrow = dim == 1 ? 1 : 2 * (dim - 1);
-    mu0 = P.mu[0]; mu1 = P.mu[2]; mu2 = P.mu[3];   // (mu[1] == mu[0], mu[4] == mu[3]: one tangential, one rolling coefficient)
-    cm1 = s.c_m1[lane]; cm2 = s.c_m2[lane];
-    const float pos = s.c_dist[lane] - P.margin, tran = P.tran;
-    float R, imp;
-    a0 = row_params(P.solref, P.solimp, pos, 0.f, dim == 1 ? tran : tran + mu0 * mu0 * tran, &R, &imp);
-    bcoef = 2.f / fmaxf(JMINVAL, fminf(0.9999f, fmaxf(0.0001f, P.solimp[1])) * P.solref[0]);
-    if (dim > 1) R = fmaxf(JMINVAL, 2.f * mu0 * mu0 * R);
-    dinv = 1.f / R;
-  }
-  int end = nlim + wave_scan_incl(nrow, lane);
-  unsigned long long fm = wave_ballot(lane < ncon && end <= MAXEFC);
-  int kept = popc64(fm);   // row offsets are monotone, so the contacts that fit form a prefix
-  if (kept < ncon) flags |= JFLAG_EFC_OVERFLOW;
-  int total = wave_bcast_i(end, kept > 0 ? kept - 1 : 0);
-  total = kept > 0 ? total : nlim;
-  int r0 = end - nrow;
-  if (lane < kept) {
-    s.c_efc[lane] = r0;
-    unsigned mm = cm1 | cm2;
-    int blk = ((mm & ((1u << JB0) - 1u)) ? 1 : 0) | (((mm >> JB0) & ((1u << (JB1 - JB0)) - 1u)) ? 2 : 0) | ((mm >> JB1) ? 4 : 0);
-    for (int e = 0; e < nrow; e++) {
-      s.e_con[r0 + e] = lane | (e << 8) | (blk << 16);
-      s.e_f[r0 + e] = e < 4 ? mu0 : (e < 6 ? mu1 : mu2);   // friction of the row's pyramid edge (e_f is free until the solver runs)
-    }
-  }
+  // per-contact parameters handed to the row lanes through LDS: a contact's chain masks are dead once its own lane has read
+  // them (each lane only ever overwrites its own contact's slots), c_fn is not yet in use
+  float* pa0 = reinterpret_cast<float*>(s.c_m1);
+  float* pbc = reinterpret_cast<float*>(s.c_m2);
+  int rowbase = nlim, kept_total = 0;
   // Jacobian rows: lane = (contact slot 0..2, dof); the slot's contact data is fetched from its owner lane
   const int cl = lane / JNV, k = lane - cl * JNV;
   const bool dofok = cl < 3 && k < nv;
-  sv S = ldsv(s.cdof[dofok ? k : 0]);
-  for (int c0 = 0; c0 < kept; c0 += 3) {
-    int c = c0 + (cl < 3 ? cl : 0);
-    int src = c < 64 ? c : 0;
-    int cdim = wave_shfl_i(dim, src), cr0 = wave_shfl_i(r0, src);
-    float f0 = wave_shfl(mu0, src), f1 = wave_shfl(mu1, src), f2 = wave_shfl(mu2, src);
-    unsigned a1 = (unsigned)wave_shfl_i((int)cm1, src), a2 = (unsigned)wave_shfl_i((int)cm2, src);
-    if (dofok && c < kept) {
-      float coef = (float)((int)((a2 >> k) & 1u) - (int)((a1 >> k) & 1u));
-      v3 pos = ld3(s.c_pos[c]);
-      v3 jp = (S.b + cross(S.a, pos)) * coef, jr = S.a * coef;
-      const float* fr = s.c_frame[c];
-      float Jc[6];
+  const sv S = ldsv(s.cdof[dofok ? k : 0]);
+  for (int cb = 0; cb < ncon; cb += 64) {   // lane = contact, 64 at a time (one pass unless the tier holds more than 64 contacts)
+    const int ci = cb + lane, nhere = ncon - cb < 64 ? ncon - cb : 64;
+    // rows per contact and row offsets
+    int dim = 0, nrow = 0;
+    float mu0 = 0.f, mu1 = 0.f, mu2 = 0.f;
+    unsigned cm1 = 0, cm2 = 0;
+    // per-contact row parameters, from the pair's pre-mixed constants: every row of a contact shares the regulariser
+    // (pyramidal: 2 mu^2 R of the first row, impratio = 1) and the position part of aref; only the velocity part differs per
+    // row.  aref_row = a0 - bcoef * vel_row,  D_row = dinv.
+    float a0 = 0.f, bcoef = 0.f, dinv = 0.f;
+    if (lane < nhere) {
+      const JacoPairParam& P = m->pair[s.c_pair[ci]];
+      dim = s.c_dim[ci]; nrow = dim == 1 ? 1 : 2 * (dim - 1);
+      mu0 = P.mu[0]; mu1 = P.mu[2]; mu2 = P.mu[3];   // (mu[1] == mu[0], mu[4] == mu[3]: one tangential, one rolling coefficient)
+      cm1 = s.c_m1[ci]; cm2 = s.c_m2[ci];
+      const float pos = s.c_dist[ci] - P.margin, tran = P.tran;
+      float R, imp;
+      a0 = row_params(P.solref, P.solimp, pos, 0.f, dim == 1 ? tran : tran + mu0 * mu0 * tran, &R, &imp);
+      bcoef = 2.f / fmaxf(JMINVAL, fminf(0.9999f, fmaxf(0.0001f, P.solimp[1])) * P.solref[0]);
+      if (dim > 1) R = fmaxf(JMINVAL, 2.f * mu0 * mu0 * R);
+      dinv = 1.f / R;
+    }
+    const int end = rowbase + wave_scan_incl(nrow, lane);
+    const unsigned long long fm = wave_ballot(lane < nhere && end <= MAXEFC);
+    const int kept = popc64(fm);   // row offsets are monotone, so the contacts that fit form a prefix
+    int total = wave_bcast_i(end, kept > 0 ? kept - 1 : 0);
+    total = kept > 0 ? total : rowbase;
+    const int r0 = end - nrow;
+    if (lane < kept) {
+      s.c_efc[ci] = r0;
+      unsigned mm = cm1 | cm2;
+      int blk = ((mm & ((1u << JB0) - 1u)) ? 1 : 0) | (((mm >> JB0) & ((1u << (JB1 - JB0)) - 1u)) ? 2 : 0) | ((mm >> JB1) ? 4 : 0);
+      for (int e = 0; e < nrow; e++) {
+        s.e_con[r0 + e] = ci | (e << 8) | (blk << 16);
+        s.e_f[r0 + e] = e < 4 ? mu0 : (e < 6 ? mu1 : mu2);   // friction of the row's pyramid edge (e_f is free until the solver runs)
+      }
+      pa0[ci] = a0; pbc[ci] = bcoef; s.c_fn[ci] = dinv;
+    }
+    for (int c0 = 0; c0 < kept; c0 += 3) {
+      int c = c0 + (cl < 3 ? cl : 0);
+      int src = c < 64 ? c : 0;
+      int cdim = wave_shfl_i(dim, src), cr0 = wave_shfl_i(r0, src);
+      float f0 = wave_shfl(mu0, src), f1 = wave_shfl(mu1, src), f2 = wave_shfl(mu2, src);
+      unsigned a1 = (unsigned)wave_shfl_i((int)cm1, src), a2 = (unsigned)wave_shfl_i((int)cm2, src);
+      if (dofok && c < kept) {
+        float coef = (float)((int)((a2 >> k) & 1u) - (int)((a1 >> k) & 1u));
+        v3 pos = ld3(s.c_pos[cb + c]);
+        v3 jp = (S.b + cross(S.a, pos)) * coef, jr = S.a * coef;
+        const float* fr = s.c_frame[cb + c];
+        float Jc[6];
 #pragma unroll
-      for (int a = 0; a < 3; a++) { Jc[a] = dot(ld3(fr + 3 * a), jp); Jc[3 + a] = dot(ld3(fr + 3 * a), jr); }
-      float* Jw = s.J + cr0 * JLD + k;
-      if (cdim == 1) Jw[0] = Jc[0];
-      else {
-        Jw[0] = Jc[0] + f0 * Jc[1]; Jw[JLD] = Jc[0] - f0 * Jc[1];
-        Jw[2 * JLD] = Jc[0] + f0 * Jc[2]; Jw[3 * JLD] = Jc[0] - f0 * Jc[2];
-        if (cdim > 3) {
-          Jw[4 * JLD] = Jc[0] + f1 * Jc[3]; Jw[5 * JLD] = Jc[0] - f1 * Jc[3];
-          Jw[6 * JLD] = Jc[0] + f2 * Jc[4]; Jw[7 * JLD] = Jc[0] - f2 * Jc[4];
-          Jw[8 * JLD] = Jc[0] + f2 * Jc[5]; Jw[9 * JLD] = Jc[0] - f2 * Jc[5];
+        for (int a = 0; a < 3; a++) { Jc[a] = dot(ld3(fr + 3 * a), jp); Jc[3 + a] = dot(ld3(fr + 3 * a), jr); }
+        float* Jw = s.J + cr0 * JLD + k;
+        if (cdim == 1) Jw[0] = Jc[0];
+        else {
+          Jw[0] = Jc[0] + f0 * Jc[1]; Jw[JLD] = Jc[0] - f0 * Jc[1];
+          Jw[2 * JLD] = Jc[0] + f0 * Jc[2]; Jw[3 * JLD] = Jc[0] - f0 * Jc[2];
+          if (cdim > 3) {
+            Jw[4 * JLD] = Jc[0] + f1 * Jc[3]; Jw[5 * JLD] = Jc[0] - f1 * Jc[3];
+            Jw[6 * JLD] = Jc[0] + f2 * Jc[4]; Jw[7 * JLD] = Jc[0] - f2 * Jc[4];
+            Jw[8 * JLD] = Jc[0] + f2 * Jc[5]; Jw[9 * JLD] = Jc[0] - f2 * Jc[5];
+          }
         }
       }
     }
+    rowbase = total; kept_total += kept;
+    if (kept < nhere) { flags |= JFLAG_EFC_OVERFLOW; break; }   // the row buffer is full: this contact and all later ones are dropped
   }
-  wave_sync();  // every lane has read the incoming row / contact counts; J rows and e_con are visible
-  if (lane == 0) { s.nefc = total; s.ncon = kept; }
-  // hand the per-contact parameters to the row lanes through LDS: the chain masks are dead now, c_fn is not yet in use
-  float* pa0 = reinterpret_cast<float*>(s.c_m1);
-  float* pbc = reinterpret_cast<float*>(s.c_m2);
-  if (lane < kept) { pa0[lane] = a0; pbc[lane] = bcoef; s.c_fn[lane] = dinv; }
-  wave_sync();
+  const int total = rowbase;
+  wave_sync();  // every lane has read the incoming row / contact counts; J rows, e_con and the per-contact parameters are visible
+  if (lane == 0) { s.nefc = total; s.ncon = kept_total; }
   // per-row parameters, lane = row
   for (int rr = nlim + lane; rr < total; rr += 64) {
     int ce = s.e_con[rr], c = ce & 255, e = (ce >> 8) & 255;
@@ -690,15 +696,15 @@ JDEV void stage_touch(const JacoModelDev* m, L& s, int lane, float* sens) {
   {   // no contact on a body that carries a touch site (the common case: only object/pedestal/floor contacts): all zero
     const unsigned long long sb = ((unsigned long long)m->sens_bodymask[1] << 32) | m->sens_bodymask[0];
     bool mine = false;
-    if (lane < ncon) { int obs = s.c_ob[lane]; mine = (((sb >> (obs & 0xFF)) | (sb >> ((obs >> 16) & 0xFF))) & 1ull) != 0ull; }
+    for (int ci = lane; ci < ncon; ci += 64) { int obs = s.c_ob[ci]; mine = mine || (((sb >> (obs & 0xFF)) | (sb >> ((obs >> 16) & 0xFF))) & 1ull) != 0ull; }
     if (!wave_ballot(mine)) { *sens = 0.f; return; }
   }
-  if (lane < ncon) {
-    int cd = s.c_dim[lane];
-    int nrow = cd == 1 ? 1 : 2 * (cd - 1), r0 = s.c_efc[lane];
+  for (int ci = lane; ci < ncon; ci += 64) {
+    int cd = s.c_dim[ci];
+    int nrow = cd == 1 ? 1 : 2 * (cd - 1), r0 = s.c_efc[ci];
     float fn = 0.f;
     for (int e = 0; e < nrow; e++) fn += s.e_f[r0 + e];
-    s.c_fn[lane] = fn;
+    s.c_fn[ci] = fn;
   }
   wave_sync();
   float sum = 0.f;

@@ -28,6 +28,7 @@ struct JacoHandle {
   int* stats = nullptr;
   int *remaining = nullptr, *heavy_list = nullptr, *heavy_count = nullptr;   // heavy_count[0..4]: appended, claimed, light workgroups left, resident workers, passed on to the heavy tier
   int* heavy2_list = nullptr;   // envs the medium tier passed on to the heavy tier
+  int* heavy3_list = nullptr;   // envs the heavy tier passed on to the huge tier (heavy_count[5] = their number)
   hipStream_t side = nullptr;                 // heavy-tier workers run here, concurrently with the light tier
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int concurrent = 1, workers = 512, tier_return = 1;           // options "concurrent_heavy", "heavy_workers"
@@ -112,6 +113,7 @@ extern "C" int jaco_create(const JacoConfig* cfg, JacoHandle** out) {
   CREATECHK(hipMalloc(&h->heavy_count, 8 * sizeof(int)));
   CREATECHK(hipMemset(h->heavy_count, 0, 8 * sizeof(int)));
   CREATECHK(hipMalloc(&h->heavy2_list, B * sizeof(int)));
+  CREATECHK(hipMalloc(&h->heavy3_list, B * sizeof(int)));
   {
     int lo = 0, hi = 0;
     CREATECHK(hipDeviceGetStreamPriorityRange(&lo, &hi));   // (hi = numerically lowest = highest priority)
@@ -169,7 +171,7 @@ extern "C" int jaco_destroy(JacoHandle* h) {
   if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
-  void* ptrs[] = {h->model_dev, h->hull_dev, h->qpos, h->qvel, h->qacc_ws, h->sensordata, h->flags, h->stats, h->dbg, h->prof, h->remaining, h->heavy_list, h->heavy_count, h->task_rows, h->cache, h->cost, h->order, h->marker, h->order_ctl, h->heavy2_list, h->qpos0_dev};
+  void* ptrs[] = {h->model_dev, h->hull_dev, h->qpos, h->qvel, h->qacc_ws, h->sensordata, h->flags, h->stats, h->dbg, h->prof, h->remaining, h->heavy_list, h->heavy_count, h->task_rows, h->cache, h->cost, h->order, h->marker, h->order_ctl, h->heavy2_list, h->heavy3_list, h->qpos0_dev};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   delete h;
   return JACO_OK;
@@ -312,7 +314,7 @@ __global__ void jaco_prepare_kernel(int* ctl, int* list, int n, int max_workers,
   if (i == 0) {
     int want = 16 + ctl[0] / 10;
     ctl[3] = want < max_workers ? want : max_workers;
-    ctl[0] = 0; ctl[1] = 0; ctl[2] = n; ctl[4] = 0;
+    ctl[0] = 0; ctl[1] = 0; ctl[2] = n; ctl[4] = 0; ctl[5] = 0;
   }
 }
 
@@ -324,7 +326,7 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
   A.ctrl = ctrl ? ctrl : h->qvel;   // env modes compute ctrl in-kernel; the pointer only has to be readable
   A.sensordata = h->sensordata; A.flags = h->flags; A.stats = h->stats; A.nenv = h->num_envs; A.nsub = nsub;
   A.disable_contact = h->disable_contact; A.no_tier_return = !h->tier_return; A.dbg = dbg; A.dbg_env = dbg_env; A.prof = h->prof;
-  A.remaining = h->remaining; A.heavy_list = h->heavy_list; A.heavy_count = h->heavy_count; A.heavy_taken = h->heavy_count + 1; A.light_left = h->heavy_count + 2; A.worker_limit = h->heavy_count + 3; A.heavy2_count = h->heavy_count + 4; A.heavy2_list = h->heavy2_list;
+  A.remaining = h->remaining; A.heavy_list = h->heavy_list; A.heavy_count = h->heavy_count; A.heavy_taken = h->heavy_count + 1; A.light_left = h->heavy_count + 2; A.worker_limit = h->heavy_count + 3; A.heavy2_count = h->heavy_count + 4; A.heavy2_list = h->heavy2_list; A.heavy3_count = h->heavy_count + 5; A.heavy3_list = h->heavy3_list;
   A.env_mode = io.mode; A.task_id = h->task; A.nact = h->task == JACO_TASK_REACHING ? 6 : 7; A.seed = h->seed;
   A.task = h->task_rows; A.cache = h->cache; A.action = io.action; A.noise = h->noise; A.obs = io.obs; A.reward = io.reward; A.done = io.done; A.mask = io.mask; A.marker = h->marker;
   A.cost = h->cost;
@@ -371,6 +373,8 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
   hipLaunchKernelGGL(jaco_physics_kernel_medium_drain, dim3(mg), dim3(64), 0, st, A);
   HIPCHK(h, hipGetLastError());
   hipLaunchKernelGGL(jaco_physics_kernel_heavy_drain, dim3(hg), dim3(64), 0, st, A);
+  HIPCHK(h, hipGetLastError());
+  hipLaunchKernelGGL(jaco_physics_kernel_huge_drain, dim3((unsigned)(h->num_envs < 512 ? h->num_envs : 512)), dim3(64), 0, st, A);
   HIPCHK(h, hipGetLastError());
   if (ev) HIPCHK(h, hipEventRecord(ev->second, st));
   return JACO_OK;

@@ -20,7 +20,8 @@
 // Three capacity tiers of the same kernel (DESIGN.md "Tiers"):
 //   light: <= 64 rows / 32 contacts / 64 candidates -> 1 constraint row per lane, ~17 KB LDS, the common case;
 //   medium: <= 128 rows / 48 contacts -> 2 rows per lane, ~28 KB LDS, for envs that overflow light (marker-stick contacts);
-//   heavy: <= 256 rows / 64 contacts -> 4 rows per lane, ~43 KB LDS, for envs that overflow medium.
+//   heavy: <= 256 rows / 64 contacts -> 4 rows per lane, ~43 KB LDS, for envs that overflow medium;
+//   huge: <= 512 rows / 128 contacts -> 8 rows per lane, ~80 KB LDS, for envs that overflow heavy (beyond that rows are dropped and flagged).
 // A light wave that meets an overflow hands its env (state untouched for that substep) to the heavy launch.
 template <int MAXEFC_, int MAXCON_, int MAXCAND_>
 struct JacoCaps {
@@ -30,6 +31,7 @@ struct JacoCaps {
 typedef JacoCaps<64, 32, 128> JacoLight;   // (candidates = bounding-sphere survivors: closed fingers alone contribute > 64)
 typedef JacoCaps<128, 48, 128> JacoMedium;  // 2 rows per lane: the EE axis sticks resting on the "hand" marker's sticks add ~36 rows to the usual 32
 typedef JacoCaps<256, 64, 256> JacoHeavy;
+typedef JacoCaps<512, 128, 256> JacoHuge;    // 8 rows per lane: a reset that puts the hand inside the pedestal (1 % of picking resets: up to ~90 contacts / ~410 rows)
 #define JDBG_MAXCON 64
 #define JDBG_MAXEFC 256
 #define JLD (JNV)     // row stride of per-row dof vectors in LDS (21: odd, conflict-free for lane-per-row access)
@@ -79,6 +81,8 @@ struct JacoStepArgs {
   int* heavy_count;    // [1] entries appended to heavy_list
   int* heavy2_list;    // [nenv] env ids the medium tier handed on to the heavy tier
   int* heavy2_count;   // [1]
+  int* heavy3_list;    // [nenv] env ids the heavy tier handed on to the huge tier
+  int* heavy3_count;   // [1]
   int* heavy_taken;    // [1] entries claimed by heavy-tier workgroups
   int* light_left;     // [1] light-tier workgroups still running (0: no further entries will appear)
   const int* worker_limit;  // [1] heavy-tier workers beyond this index leave at once (sized from the previous launch's hand-overs), or nullptr
@@ -971,8 +975,8 @@ JDEV void stage_integrate_pos(const JacoModelDev* m, L& s, int lane) {
 
 // ---------------------------------------------------------------- the kernels
 // One substep loop for one env; returns the number of substeps NOT done (light tier bail-out) or 0.
-// TIER: 0 light, 1 medium, 2 heavy.  Tiers below 2 stop at a capacity overflow (*why = 1) and leave the env to the next tier;
-// tiers above 0 can give the env back to the light code once it would fit again (handback; *why = 2).
+// TIER: 0 light, 1 medium, 2 heavy, 3 huge.  Tiers below 3 stop at a capacity overflow (*why = 1) and leave the env to the next
+// tier; tiers above 0 can give the env back to the tier below once it would fit again (handback; *why = 2).
 template <class C, int TIER>
 JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int lane, bool handback = false, int* why = nullptr) {
   constexpr bool LIGHT = TIER == 0;
@@ -1142,11 +1146,12 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
       wave_sync();
     }
     if (!LIGHT) {   // would the tier below have coped with this substep?  (heavy -> medium, medium -> light)
-      constexpr int LCON = TIER == 2 ? JacoMedium::MAXCON : JacoLight::MAXCON, LEFC = TIER == 2 ? JacoMedium::MAXEFC : JacoLight::MAXEFC;
+      constexpr int LCON = TIER == 3 ? JacoHeavy::MAXCON : (TIER == 2 ? JacoMedium::MAXCON : JacoLight::MAXCON);
+      constexpr int LEFC = TIER == 3 ? JacoHeavy::MAXEFC : (TIER == 2 ? JacoMedium::MAXEFC : JacoLight::MAXEFC);
       calm = (s.ncon <= LCON && s.nefc <= LEFC && s.ncand <= JacoLight::MAXCAND / 2) ? calm + 1 : 0;
     }
-    if (TIER == 2) flags |= cflags;   // the last tier has nobody to hand over to: contacts / rows beyond its capacity were dropped, say so
-    if (TIER < 2 && cflags) {   // capacity exceeded: leave this substep (and the rest) to the next tier; nothing was mutated
+    if (TIER == 3) flags |= cflags;   // the last tier has nobody to hand over to: contacts / rows beyond its capacity were dropped, say so
+    if (TIER < 3 && cflags) {   // capacity exceeded: leave this substep (and the rest) to the next tier; nothing was mutated
       left = nsub - sub;
       bailed = true;
       if (emode == 1 || emode == 3) {
@@ -1196,12 +1201,12 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
         D[JDBG_QACC + lane] = nw.qacc; D[JDBG_QFRC_CON + lane] = nw.qfrc_con;
       }
       if (lane == 0) { D[JDBG_NCON] = (float)s.ncon; D[JDBG_NCON + 1] = (float)s.nefc; D[JDBG_NCON + 2] = (float)iters; D[JDBG_NCON + 3] = (float)s.ncand; }
-      for (int c = lane; c < s.ncon && c < C::MAXCON; c += 64) {
+      for (int c = lane; c < s.ncon && c < JDBG_MAXCON; c += 64) {
         float* o = D + JDBG_CONTACT + 8 * c;
         o[0] = s.c_dist[c]; o[1] = s.c_pos[c][0]; o[2] = s.c_pos[c][1]; o[3] = s.c_pos[c][2];
         o[4] = s.c_frame[c][0]; o[5] = s.c_frame[c][1]; o[6] = s.c_frame[c][2]; o[7] = (float)s.c_pair[c];
       }
-      for (int r = lane; r < s.nefc && r < C::MAXEFC; r += 64) {
+      for (int r = lane; r < s.nefc && r < JDBG_MAXEFC; r += 64) {
         float* o = D + JDBG_EFC + 4 * r;
         o[0] = s.e_aref[r]; o[1] = 1.f / s.e_D[r]; o[2] = 0.f; o[3] = s.e_f[r];
       }
@@ -1440,6 +1445,10 @@ __global__ __launch_bounds__(64) void jaco_physics_kernel_heavy_drain(JacoStepAr
     for (;;) {
       left = run_env<JacoHeavy, 2>(A, u.heavy, env, stepmode ? A.nsub : left, lane, !A.no_tier_return, &why);
       if (left <= 0) break;
+      if (why == 1) {   // outgrew the heavy capacities too: the huge tier's launch follows in stream order
+        if (lane == 0) { A.remaining[env] = left; A.heavy3_list[jaco_atomic_inc(A.heavy3_count)] = env; }
+        break;
+      }
       wave_sync();
       if (!stepmode && lane == 0) A.remaining[env] = left;   // (ctrl level: run_env_tiers reads the substeps left from here)
       wave_sync();
@@ -1447,6 +1456,20 @@ __global__ __launch_bounds__(64) void jaco_physics_kernel_heavy_drain(JacoStepAr
       if (left <= 0) break;
       wave_sync();
     }
+    if (lane == 0 && A.cost) A.cost[env] += (unsigned)((wave_clock() - t_start) >> 4);
+    wave_sync();
+  }
+}
+// huge tier: whatever outgrew the heavy tier (a reset with the hand inside the pedestal) finishes its step here
+__global__ __launch_bounds__(64) void jaco_physics_kernel_huge_drain(JacoStepArgs A) {
+  __shared__ JacoLDS<JacoHuge> s;
+  const int lane = lane_id();
+  const int count = *A.heavy3_count;
+  const bool stepmode = A.env_mode == 1 || A.env_mode == 3;
+  for (int i = env_id(); i < count; i += grid_size()) {
+    const int env = A.heavy3_list[i];
+    const unsigned long long t_start = wave_clock();
+    run_env<JacoHuge, 3>(A, s, env, stepmode ? A.nsub : A.remaining[env], lane);
     if (lane == 0 && A.cost) A.cost[env] += (unsigned)((wave_clock() - t_start) >> 4);
     wave_sync();
   }

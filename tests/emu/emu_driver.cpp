@@ -14,6 +14,7 @@ extern "C" int emu_dbg_size() { return JDBG_SIZE; }
 extern "C" int emu_lds_bytes() { return (int)sizeof(JacoLDS<JacoLight>); }
 extern "C" int emu_lds_bytes_heavy() { return (int)sizeof(JacoLDS<JacoHeavy>); }
 extern "C" int emu_lds_bytes_medium() { return (int)sizeof(JacoLDS<JacoMedium>); }
+extern "C" int emu_lds_bytes_huge() { return (int)sizeof(JacoLDS<JacoHuge>); }
 
 static int g_mpr_output_fwd();
 static JacoModelDev g_model;
@@ -23,8 +24,9 @@ static int emu_launch(JacoStepArgs A, int* heavy_envs) {
   A.no_tier_return = g_no_tier_return_fwd();
   std::vector<int> remaining(A.nenv, 0), list(A.nenv, 0);
   std::fill(list.begin(), list.end(), -1);
-  std::vector<int> list2(A.nenv, -1);
-  int count = 0, taken = 0, light_left = A.nenv, count2 = 0;
+  std::vector<int> list2(A.nenv, -1), list3(A.nenv, -1);
+  int count = 0, taken = 0, light_left = A.nenv, count2 = 0, count3 = 0;
+  A.heavy3_list = list3.data(); A.heavy3_count = &count3;
   A.remaining = remaining.data(); A.heavy_list = list.data(); A.heavy_count = &count; A.heavy_taken = &taken; A.light_left = &light_left;
   A.heavy2_list = list2.data(); A.heavy2_count = &count2;
   emu_grid = A.nenv;
@@ -34,6 +36,7 @@ static int emu_launch(JacoStepArgs A, int* heavy_envs) {
   if (count > 0) emu_run_wave(0, [&]() { jaco_physics_kernel_medium(A); });
   if (count > 0) emu_run_wave(0, [&]() { jaco_physics_kernel_medium_drain(A); });
   if (count2 > 0) emu_run_wave(0, [&]() { jaco_physics_kernel_heavy_drain(A); });
+  if (count3 > 0) emu_run_wave(0, [&]() { jaco_physics_kernel_huge_drain(A); });
   if (heavy_envs) *heavy_envs = count;
   return 0;
 }
@@ -75,8 +78,9 @@ extern "C" int emu_physics_step(const void* blob, long blob_size, int nenv, int 
   A.model = &model; A.hull = hull.data(); A.qpos = qpos; A.qvel = qvel; A.qacc_ws = qacc_ws; A.ctrl = ctrl; A.sensordata = sensordata;
   A.flags = flags; A.stats = stats; A.nenv = nenv; A.nsub = nsub; A.disable_contact = disable_contact; A.dbg = dbg; A.dbg_env = dbg_env;
   std::vector<int> remaining(nenv, 0), list(nenv, -1);
-  std::vector<int> list2(nenv, -1);
-  int count = 0, taken = 0, light_left = nenv, count2 = 0;
+  std::vector<int> list2(nenv, -1), list3(nenv, -1);
+  int count = 0, taken = 0, light_left = nenv, count2 = 0, count3 = 0;
+  A.heavy3_list = list3.data(); A.heavy3_count = &count3;
   A.remaining = remaining.data(); A.heavy_list = list.data(); A.heavy_count = &count; A.heavy_taken = &taken; A.light_left = &light_left;
   A.heavy2_list = list2.data(); A.heavy2_count = &count2;
   emu_grid = nenv;
@@ -85,6 +89,7 @@ extern "C" int emu_physics_step(const void* blob, long blob_size, int nenv, int 
   if (count > 0) emu_run_wave(0, [&]() { jaco_physics_kernel_medium(A); });
   if (count > 0) emu_run_wave(0, [&]() { jaco_physics_kernel_medium_drain(A); });
   if (count2 > 0) emu_run_wave(0, [&]() { jaco_physics_kernel_heavy_drain(A); });
+  if (count3 > 0) emu_run_wave(0, [&]() { jaco_physics_kernel_huge_drain(A); });
   if (heavy_envs) *heavy_envs = count;
   return 0;
 }

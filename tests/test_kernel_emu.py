@@ -90,3 +90,20 @@ def test_bitwise_deterministic(model_arrays):
         e.step(workload.random_ctrl(1, seed=6)[0], nsub=5)
         out.append((e.qpos.copy(), e.qvel.copy()))
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
+def test_huge_tier_keeps_every_row_of_a_hand_in_pedestal_reset(model_arrays):
+    """A picking reset that spawns the hand inside the pedestal (1 % of draws): 64 contacts / 292 constraint rows in the first
+    step, beyond the 256-row heavy tier.  The 512-row tier keeps them all (MuJoCo's njmax is 8000): same counts as the oracle,
+    no capacity flag, and the violent ejection stays on the oracle's trajectory."""
+    q = workload.reset_states(model_arrays["qpos0"], 256, seed=41, f32_draws=True)[200]
+    c = workload.random_ctrl(256, seed=42, scale=0.2)[200].astype(np.float32).astype(np.float64)
+    o = Oracle(); e = EmuEnv()
+    o.reset(); o.set("qpos", q); o.set("ctrl", c); e.qpos[0] = q
+    seen = 0
+    for t in range(12):
+        e.step(c); o.step()
+        assert (e.stats[0, 0], e.stats[0, 1]) == (o.ncon, o.nefc), t
+        seen = max(seen, o.nefc)
+        assert np.abs(e.qpos[0] - o.get("qpos")).max() < 1e-5
+    assert seen > 256 and (e.flags[0] & 7) == 0
