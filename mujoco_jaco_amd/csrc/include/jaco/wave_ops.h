@@ -9,8 +9,21 @@
 JDEV int lane_id() { return (int)threadIdx.x; }
 JDEV int env_id() { return (int)blockIdx.x; }
 
-// LDS hand-off between lanes of the (single-wave) workgroup.
+// LDS hand-off between lanes of the (single-wave) workgroup.  One wavefront issues its LDS instructions in program order and
+// the LDS unit serves them in that order, so a read issued after a write of another lane of the SAME wave sees it: nothing
+// has to be waited for in hardware.  What must be stopped is the compiler, which reasons per thread ("lane k's store to
+// x[k] cannot alias its load of x[k + 1]") and could move the load up: a wavefront-scope fence pair + the scheduling barrier
+// pins the order without emitting an instruction.  (__syncthreads() here meant s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier at every
+// one of the ~100 stage boundaries per substep: each drained the write acknowledgements and every model load in flight.)
+#ifdef JACO_SYNCTHREADS
 JDEV void wave_sync() { __syncthreads(); }
+#else
+JDEV void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+#endif
 
 // Broadcast from a wave-uniform source lane (v_readlane_b32).
 JDEV float wave_bcast(float v, int src) {

@@ -18,6 +18,11 @@ static_assert(JFLAG_CON_OVERFLOW == JACO_FLAG_CON_OVERFLOW && JFLAG_EFC_OVERFLOW
                   JFLAG_SOLVER_MAXITER == JACO_FLAG_SOLVER_MAXITER && JFLAG_HEAVY_TIER == JACO_FLAG_HEAVY_TIER,
               "flag bits of the kernel and the public header must agree");
 
+// Queue control words (ints): per tier t (0 medium, 1 heavy, 2 huge) JQ_COUNT + t appended, JQ_TAKEN + t claimed, JQ_LIMIT + t workers
+// that start, JQ_RESERVE + t workers that stay when the queue runs dry; JQ_LIGHT light workgroups still running; JQ_ROUTED envs
+// queued at once by the light grid (hint > 0), JQ_HINTED + t how many of them per tier (counted by the ordering pass).
+enum { JQ_COUNT = 0, JQ_TAKEN = 3, JQ_LIMIT = 6, JQ_LIGHT = 9, JQ_RESERVE = 10, JQ_ROUTED = 13, JQ_HINTED = 14, JQ_PREV_COUNT = 17, JQ_PREV_HINTED = 20, JQ_LASTMODE = 23, JQ_WORDS = 24 };
+
 struct JacoHandle {
   JacoModelDev model_host;
   JacoModelDev* model_dev = nullptr;
@@ -26,12 +31,15 @@ struct JacoHandle {
   float *qpos = nullptr, *qvel = nullptr, *qacc_ws = nullptr, *sensordata = nullptr, *dbg = nullptr;
   unsigned* flags = nullptr;
   int* stats = nullptr;
-  int *remaining = nullptr, *heavy_list = nullptr, *heavy_count = nullptr;   // heavy_count[0..4]: appended, claimed, light workgroups left, resident workers, passed on to the heavy tier
-  int* heavy2_list = nullptr;   // envs the medium tier passed on to the heavy tier
-  int* heavy3_list = nullptr;   // envs the heavy tier passed on to the huge tier (heavy_count[5] = their number)
-  hipStream_t side = nullptr;                 // heavy-tier workers run here, concurrently with the light tier
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  int concurrent = 1, workers = 512, tier_return = 1;           // options "concurrent_heavy", "heavy_workers"
+  int* remaining = nullptr;
+  // tier queues (medium, heavy, huge): lists [3][num_envs] and the control words JQ_* below
+  int *qlist = nullptr, *qctl = nullptr;
+  int* hint = nullptr;                        // [num_envs] tier the env's last step needed
+  int* routed_mark = nullptr;                 // [num_envs] id of the launch that queued the env for a bigger tier before it started
+  int launch_id = 0;
+  hipStream_t side[3] = {nullptr, nullptr, nullptr};   // the tiers' resident workers run here, concurrently with the light grid
+  hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+  int concurrent = 1, workers = 1024, workers_heavy = 256, workers_huge = 32, tier_return = 1, use_hints = 1;   // options "concurrent_heavy", "heavy_workers", "hints"
   float *task_rows = nullptr, *cache = nullptr;
   float* marker = nullptr;    // [num_envs][2][12] poses of the "hand" / "subgoal_reach" markers (mocap bodies the task layer moves)
   unsigned* cost = nullptr;   // per env: shader-clock ticks its last step took (>> 4)
@@ -109,17 +117,21 @@ extern "C" int jaco_create(const JacoConfig* cfg, JacoHandle** out) {
   CREATECHK(hipMalloc(&h->stats, B * 4 * sizeof(int)));
   CREATECHK(hipMalloc(&h->dbg, JDBG_SIZE * sizeof(float)));
   CREATECHK(hipMalloc(&h->remaining, B * sizeof(int)));
-  CREATECHK(hipMalloc(&h->heavy_list, B * sizeof(int)));
-  CREATECHK(hipMalloc(&h->heavy_count, 8 * sizeof(int)));
-  CREATECHK(hipMemset(h->heavy_count, 0, 8 * sizeof(int)));
-  CREATECHK(hipMalloc(&h->heavy2_list, B * sizeof(int)));
-  CREATECHK(hipMalloc(&h->heavy3_list, B * sizeof(int)));
+  CREATECHK(hipMalloc(&h->qlist, 3 * B * sizeof(int)));
+  CREATECHK(hipMalloc(&h->qctl, JQ_WORDS * sizeof(int)));
+  CREATECHK(hipMemset(h->qctl, 0, JQ_WORDS * sizeof(int)));
+  CREATECHK(hipMalloc(&h->hint, B * sizeof(int)));
+  CREATECHK(hipMemset(h->hint, 0, B * sizeof(int)));
+  CREATECHK(hipMalloc(&h->routed_mark, B * sizeof(int)));
+  CREATECHK(hipMemset(h->routed_mark, 0, B * sizeof(int)));
   {
     int lo = 0, hi = 0;
     CREATECHK(hipDeviceGetStreamPriorityRange(&lo, &hi));   // (hi = numerically lowest = highest priority)
-    CREATECHK(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, hi));
     CREATECHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-    CREATECHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    for (int t = 0; t < 3; t++) {
+      CREATECHK(hipStreamCreateWithPriority(&h->side[t], hipStreamNonBlocking, hi));
+      CREATECHK(hipEventCreateWithFlags(&h->ev_join[t], hipEventDisableTiming));
+    }
   }
   CREATECHK(hipMemset(h->remaining, 0, B * sizeof(int)));
   CREATECHK(hipMalloc(&h->marker, B * 24 * sizeof(float)));
@@ -168,10 +180,12 @@ extern "C" int jaco_destroy(JacoHandle* h) {
   if (!h) return JACO_EINVAL;
   (void)hipSetDevice(h->device);
   for (auto& e : h->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-  if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
+  for (int t = 0; t < 3; t++) {
+    if (h->side[t]) { (void)hipStreamSynchronize(h->side[t]); (void)hipStreamDestroy(h->side[t]); }
+    if (h->ev_join[t]) (void)hipEventDestroy(h->ev_join[t]);
+  }
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
-  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
-  void* ptrs[] = {h->model_dev, h->hull_dev, h->qpos, h->qvel, h->qacc_ws, h->sensordata, h->flags, h->stats, h->dbg, h->prof, h->remaining, h->heavy_list, h->heavy_count, h->task_rows, h->cache, h->cost, h->order, h->marker, h->order_ctl, h->heavy2_list, h->heavy3_list, h->qpos0_dev};
+  void* ptrs[] = {h->model_dev, h->hull_dev, h->qpos, h->qvel, h->qacc_ws, h->sensordata, h->flags, h->stats, h->dbg, h->prof, h->remaining, h->qlist, h->qctl, h->hint, h->routed_mark, h->task_rows, h->cache, h->cost, h->order, h->marker, h->order_ctl, h->qpos0_dev};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   delete h;
   return JACO_OK;
@@ -195,6 +209,7 @@ extern "C" int jaco_set_state(JacoHandle* h, const float* qpos, const float* qve
   hipStream_t st = (hipStream_t)stream;
   size_t B = h->num_envs;
   if (qpos) HIPCHK(h, hipMemcpyAsync(h->qpos, qpos, B * h->model_host.nq * sizeof(float), hipMemcpyDeviceToDevice, st));
+  if (qpos) HIPCHK(h, hipMemsetAsync(h->hint, 0, B * sizeof(int), st));   // a state from outside starts in the light tier: results depend on the state alone
   if (qvel) HIPCHK(h, hipMemcpyAsync(h->qvel, qvel, B * h->model_host.nv * sizeof(float), hipMemcpyDeviceToDevice, st));
   if (qacc_ws) HIPCHK(h, hipMemcpyAsync(h->qacc_ws, qacc_ws, B * h->model_host.nv * sizeof(float), hipMemcpyDeviceToDevice, st));
   return JACO_OK;
@@ -225,6 +240,7 @@ extern "C" int jaco_reset_state(JacoHandle* h, void* stream) {
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipMemsetAsync(h->qvel, 0, B * m.nv * sizeof(float), st));
   HIPCHK(h, hipMemsetAsync(h->qacc_ws, 0, B * m.nv * sizeof(float), st));
+  HIPCHK(h, hipMemsetAsync(h->hint, 0, B * sizeof(int), st));
   // markers back to their XML rest pose (sim.reset() restores mocap_pos / mocap_quat)
   const float* rest = (const float*)((const char*)h->model_dev + offsetof(JacoModelDev, marker_rest));
   hipLaunchKernelGGL(jaco_fill_rows_kernel, dim3((unsigned)((B * 24 + 255) / 256)), dim3(256), 0, st, h->marker, rest, 24, (int)B);
@@ -245,9 +261,9 @@ struct EnvIO { int mode = 0; const float* action = nullptr; float* obs = nullptr
 // launch (u64), [66] mean cost used as the bucket reference; [0..65] are zeroed by jaco_prepare_kernel.
 static __device__ __forceinline__ unsigned jaco_cost_bucket(unsigned c, unsigned ref) {
   unsigned long long q = (unsigned long long)c * 8ull / ref;
-  return q > 31ull ? 31u : (unsigned)q;
+  return q > 30ull ? 30u : (unsigned)q;   // (bucket 31 belongs to the envs that start in a bigger tier: they lead the order)
 }
-__global__ __launch_bounds__(1024) void jaco_order_hist_kernel(const unsigned* cost, unsigned* oc, int n) {
+__global__ __launch_bounds__(1024) void jaco_order_hist_kernel(const unsigned* cost, unsigned* oc, int n, const int* mark, int launch_id) {
   __shared__ unsigned lh[32];
   __shared__ unsigned long long lsum;
   const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x), lane = (int)threadIdx.x & 63;
@@ -257,8 +273,9 @@ __global__ __launch_bounds__(1024) void jaco_order_hist_kernel(const unsigned* c
   const bool valid = i < n;
   const unsigned ref = oc[66] + 1u;
   const unsigned c = valid ? cost[i] : 0u;
-  const unsigned b = jaco_cost_bucket(c, ref);
-  unsigned long long sum = c;
+  const bool routed = valid && mark && mark[i] == launch_id;
+  const unsigned b = routed ? 31u : jaco_cost_bucket(c, ref);   // (envs already queued for a bigger tier: their light workgroups only have to leave)
+  unsigned long long sum = routed ? 0u : c;
   for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
   if (lane == 0) atomicAdd(&lsum, sum);
   unsigned long long todo = __ballot(valid);
@@ -273,7 +290,7 @@ __global__ __launch_bounds__(1024) void jaco_order_hist_kernel(const unsigned* c
   if (threadIdx.x < 32 && lh[threadIdx.x]) atomicAdd(&oc[threadIdx.x], lh[threadIdx.x]);   // one global atomic per bucket per block
   if (threadIdx.x == 32) atomicAdd(reinterpret_cast<unsigned long long*>(oc + 64), lsum);
 }
-__global__ __launch_bounds__(1024) void jaco_order_scatter_kernel(const unsigned* cost, unsigned* oc, int* order, int n) {
+__global__ __launch_bounds__(1024) void jaco_order_scatter_kernel(const unsigned* cost, unsigned* oc, int* order, int n, const int* mark, int launch_id) {
   __shared__ unsigned base[32], lh[32], gb[32];
   const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x), lane = (int)threadIdx.x & 63;
   if (threadIdx.x < 32) lh[threadIdx.x] = 0u;
@@ -281,7 +298,7 @@ __global__ __launch_bounds__(1024) void jaco_order_scatter_kernel(const unsigned
   __syncthreads();
   const bool valid = i < n;
   const unsigned ref = oc[66] + 1u;
-  const unsigned b = jaco_cost_bucket(valid ? cost[i] : 0u, ref);
+  const unsigned b = (valid && mark && mark[i] == launch_id) ? 31u : jaco_cost_bucket(valid ? cost[i] : 0u, ref);
   unsigned off = 0;   // position of this env among the block's members of its bucket
   unsigned long long todo = __ballot(valid);
   while (todo) {
@@ -299,22 +316,70 @@ __global__ __launch_bounds__(1024) void jaco_order_scatter_kernel(const unsigned
   __syncthreads();
   if (valid) order[gb[b] + off] = i;
 }
+// ... and sizes this launch's workers from what the ordering pass has just counted: per tier, the envs that start there
+// (a medium worker serves ~8 of them in a third of a step, a heavy one ~4, a huge one ~2) plus a reserve for overflows that
+// only show up during the step (a tenth of the previous launch's total demand)
+// Envs whose previous step ended in a bigger tier go there at once: queued here, before the launch, so that the tier's workers
+// find them when they start; the hint is consumed (it is re-earned during the step by whichever tier is really needed).
+__global__ void jaco_route_kernel(int* hint, int* mark, int launch_id, int* lists, int* ctl, int* remaining, unsigned* cost, int n, int nsub) {
+  const int e = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (e >= n) return;
+  const int t = hint[e];
+  if (t <= 0) return;
+  hint[e] = 0;
+  mark[e] = launch_id;
+  remaining[e] = nsub;
+  cost[e] = 0u;   // (the tiers add what they spend)
+  lists[(size_t)(t - 1) * n + atomicAdd(&ctl[JQ_COUNT + t - 1], 1)] = e;
+}
+// ... and this launch's workers are sized from what has just been queued: per tier, the envs that start there (a medium worker
+// serves ~8 of them in a third of a step, a heavy one ~4, a huge one ~2) plus the reserve for overflows that only show up
+// during the step (jaco_prepare_kernel: a tenth of the last step's late arrivals)
+__global__ void jaco_route_finish_kernel(int n, int* ctl, int wm, int wh, int wg) {
+  const int cap[3] = {wm, wh, wg}, per[3] = {8, 4, 2};
+  int routed = 0;
+  for (int t = 0; t < 3; t++) {
+    const int hinted = ctl[JQ_COUNT + t];
+    ctl[JQ_HINTED + t] = hinted;
+    routed += hinted;
+    const int reserve = ctl[JQ_RESERVE + t] < cap[t] ? ctl[JQ_RESERVE + t] : cap[t];
+    const int want = reserve + (hinted + per[t] - 1) / per[t];
+    ctl[JQ_LIMIT + t] = want < cap[t] ? want : cap[t];
+    ctl[JQ_RESERVE + t] = reserve;
+  }
+  ctl[JQ_ROUTED] = routed;
+  ctl[JQ_LIGHT] = n - routed;   // the light workgroups of queued envs leave without being counted
+}
 __global__ void jaco_order_finish_kernel(unsigned* oc, int n) {
   const unsigned long long total = *reinterpret_cast<unsigned long long*>(oc + 64);
   oc[66] = (unsigned)(total / (unsigned long long)(n > 0 ? n : 1));
 }
 
-// work-list reset before every launch: counters = {0 appended, 0 claimed, nenv light workgroups to go}, entries = -1;
-// ctl[3] = how many of the launched medium-tier workers stay resident: about one per ten envs the previous launch handed
-// over (a worker serves an env in ~1/20 of a step; an idle one still holds LDS the light tier could use), at least 16
-__global__ void jaco_prepare_kernel(int* ctl, int* list, int n, int max_workers, unsigned* oc) {
+// queue reset before every launch: entries = -1, counters zeroed, light workgroups to go = nenv; how many of the launched
+// workers of each tier stay resident follows the previous launch's demand for that tier (an idle worker still holds LDS the
+// light grid could use): a medium worker serves an env in ~1/20 of a step, a heavy / huge one in ~1/8 - 1/4
+__global__ void jaco_prepare_kernel(int* ctl, int* lists, int n, int wm, int wh, int wg, unsigned* oc, int mode) {
   int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-  if (i < n) list[i] = -1;
+  if (i < 3 * n) lists[i] = -1;
   if (i < 66) oc[i] = 0u;
   if (i == 0) {
-    int want = 16 + ctl[0] / 10;
-    ctl[3] = want < max_workers ? want : max_workers;
-    ctl[0] = 0; ctl[1] = 0; ctl[2] = n; ctl[4] = 0; ctl[5] = 0;
+    // without the ordering pass (small batches, reset-time launches) nothing is known about this launch's demand: workers as
+    // the previous launch would have wanted them, all of them staying to the end
+    // (the demand that counts is that of the last real step, not of a reset-time forward pass in between)
+    if (ctl[JQ_LASTMODE] <= 1) for (int t = 0; t < 3; t++) { ctl[JQ_PREV_COUNT + t] = ctl[JQ_COUNT + t]; ctl[JQ_PREV_HINTED + t] = ctl[JQ_HINTED + t]; }
+    ctl[JQ_LASTMODE] = mode;
+    const int* pc = ctl + JQ_PREV_COUNT;
+    int want[3] = {16 + pc[0] / 10, 8 + pc[1] / 4, 2 + pc[2] / 2}, cap[3] = {wm, wh, wg};
+    for (int t = 0; t < 3; t++) {
+      const int w = want[t] < cap[t] ? want[t] : cap[t];
+      // reserve: overflows that only show up during a step = last step's demand minus what it had queued at once
+      int late = pc[t] - ctl[JQ_PREV_HINTED + t];
+      late = late < 0 ? 0 : late;
+      const int base = t == 0 ? 16 : (t == 1 ? 8 : 2);
+      ctl[JQ_LIMIT + t] = w; ctl[JQ_RESERVE + t] = base + late / 10; ctl[JQ_COUNT + t] = 0; ctl[JQ_TAKEN + t] = 0; ctl[JQ_HINTED + t] = 0;
+    }
+    ctl[JQ_ROUTED] = 0;
+    ctl[JQ_LIGHT] = n;
   }
 }
 
@@ -326,7 +391,9 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
   A.ctrl = ctrl ? ctrl : h->qvel;   // env modes compute ctrl in-kernel; the pointer only has to be readable
   A.sensordata = h->sensordata; A.flags = h->flags; A.stats = h->stats; A.nenv = h->num_envs; A.nsub = nsub;
   A.disable_contact = h->disable_contact; A.no_tier_return = !h->tier_return; A.dbg = dbg; A.dbg_env = dbg_env; A.prof = h->prof;
-  A.remaining = h->remaining; A.heavy_list = h->heavy_list; A.heavy_count = h->heavy_count; A.heavy_taken = h->heavy_count + 1; A.light_left = h->heavy_count + 2; A.worker_limit = h->heavy_count + 3; A.heavy2_count = h->heavy_count + 4; A.heavy2_list = h->heavy2_list; A.heavy3_count = h->heavy_count + 5; A.heavy3_list = h->heavy3_list;
+  A.remaining = h->remaining; A.light_left = h->qctl + JQ_LIGHT; A.hint = h->use_hints ? h->hint : nullptr;
+  for (int t = 0; t < 3; t++) { A.q[t].list = h->qlist + (size_t)t * h->num_envs; A.q[t].count = h->qctl + JQ_COUNT + t; A.q[t].taken = h->qctl + JQ_TAKEN + t; A.q[t].limit = h->qctl + JQ_LIMIT + t; A.q[t].reserve = h->qctl + JQ_RESERVE + t; }
+  A.routed_mark = nullptr; A.launch_id = ++h->launch_id;
   A.env_mode = io.mode; A.task_id = h->task; A.nact = h->task == JACO_TASK_REACHING ? 6 : 7; A.seed = h->seed;
   A.task = h->task_rows; A.cache = h->cache; A.action = io.action; A.noise = h->noise; A.obs = io.obs; A.reward = io.reward; A.done = io.done; A.mask = io.mask; A.marker = h->marker;
   A.cost = h->cost;
@@ -342,18 +409,24 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
     ev = &h->events[h->events_used++];
     HIPCHK(h, hipEventRecord(ev->first, st));
   }
-  // Light tier for every env.  An env that overflows the light capacities is handed over (work list) to the medium tier,
-  // whose persistent workgroups run concurrently on a second, higher-priority stream: started just before the light grid
-  // they are resident from the beginning (a bigger workgroup needs more LDS than a finishing light workgroup frees and
-  // would otherwise starve behind the light grid, leaving a serial tail of several ms per env step).  The medium drain
-  // that follows in stream order serves whatever the workers did not (all of it when concurrency is off: a full grid,
-  // which is also what carries the load when most envs overflow); the heavy drain serves what outgrew the medium tier.
-  hipLaunchKernelGGL(jaco_prepare_kernel, dim3((unsigned)((h->num_envs + 255) / 256)), dim3(256), 0, st, h->heavy_count, h->heavy_list, h->num_envs, h->workers, h->order_ctl);
+  // Light grid for every env.  An env that overflows the light capacities is handed over (queue) to the medium tier, and on
+  // to the heavy / huge tiers if need be; an env whose previous step ended in a bigger tier is queued there straight away.
+  // Each tier's persistent worker workgroups run concurrently on their own higher-priority stream: started just before the
+  // light grid they are resident from the beginning (a bigger workgroup needs more LDS than a finishing light workgroup
+  // frees and would otherwise starve behind the light grid, leaving serial tails of several ms per env step).  The drains that
+  // follow in stream order serve whatever the workers did not (all of it when concurrency is off: full grids, which is also
+  // what carries the load when most envs overflow).
+  hipLaunchKernelGGL(jaco_prepare_kernel, dim3((unsigned)((3 * h->num_envs + 255) / 256)), dim3(256), 0, st, h->qctl, h->qlist, h->num_envs, h->workers, h->workers_heavy, h->workers_huge, h->order_ctl, io.mode);
   HIPCHK(h, hipGetLastError());
+  if (A.hint && io.mode <= 1) {   // queue the envs whose last step ended in a bigger tier, size the tiers' workers
+    hipLaunchKernelGGL(jaco_route_kernel, dim3((unsigned)((h->num_envs + 255) / 256)), dim3(256), 0, st, h->hint, h->routed_mark, A.launch_id, h->qlist, h->qctl, h->remaining, h->cost, h->num_envs, nsub);
+    hipLaunchKernelGGL(jaco_route_finish_kernel, dim3(1), dim3(1), 0, st, h->num_envs, h->qctl, h->workers, h->workers_heavy, h->workers_huge);
+    A.routed_mark = h->routed_mark;
+  }
   if (reorder) {
     const unsigned ob = (unsigned)((h->num_envs + 1023) / 1024);
-    hipLaunchKernelGGL(jaco_order_hist_kernel, dim3(ob), dim3(1024), 0, st, h->cost, h->order_ctl, h->num_envs);
-    hipLaunchKernelGGL(jaco_order_scatter_kernel, dim3(ob), dim3(1024), 0, st, h->cost, h->order_ctl, h->order, h->num_envs);
+    hipLaunchKernelGGL(jaco_order_hist_kernel, dim3(ob), dim3(1024), 0, st, h->cost, h->order_ctl, h->num_envs, A.routed_mark, A.launch_id);
+    hipLaunchKernelGGL(jaco_order_scatter_kernel, dim3(ob), dim3(1024), 0, st, h->cost, h->order_ctl, h->order, h->num_envs, A.routed_mark, A.launch_id);
     hipLaunchKernelGGL(jaco_order_finish_kernel, dim3(1), dim3(1), 0, st, h->order_ctl, h->num_envs);
     HIPCHK(h, hipGetLastError());
     A.order = h->order;
@@ -361,20 +434,22 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
   const bool conc = h->concurrent && io.mode == 1 && nsub >= 8 && h->num_envs >= 4096;
   if (conc) {
     HIPCHK(h, hipEventRecord(h->ev_fork, st));
-    HIPCHK(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
-    hipLaunchKernelGGL(jaco_physics_kernel_medium, dim3((unsigned)h->workers), dim3(64), 0, h->side, A);
+    for (int t = 2; t >= 0; t--) HIPCHK(h, hipStreamWaitEvent(h->side[t], h->ev_fork, 0));
+    hipLaunchKernelGGL(jaco_physics_kernel_huge_workers, dim3((unsigned)h->workers_huge), dim3(64), 0, h->side[2], A);
+    hipLaunchKernelGGL(jaco_physics_kernel_heavy_workers, dim3((unsigned)h->workers_heavy), dim3(64), 0, h->side[1], A);
+    hipLaunchKernelGGL(jaco_physics_kernel_medium, dim3((unsigned)h->workers), dim3(64), 0, h->side[0], A);
     HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipEventRecord(h->ev_join, h->side));
+    for (int t = 0; t < 3; t++) HIPCHK(h, hipEventRecord(h->ev_join[t], h->side[t]));
   }
   hipLaunchKernelGGL(jaco_physics_kernel, dim3((unsigned)h->num_envs), dim3(64), 0, st, A);
   HIPCHK(h, hipGetLastError());
-  if (conc) HIPCHK(h, hipStreamWaitEvent(st, h->ev_join, 0));
-  unsigned mg = (unsigned)(h->num_envs < 1280 ? h->num_envs : 1280), hg = (unsigned)(h->num_envs < 1024 ? h->num_envs : 1024);
+  if (conc) for (int t = 0; t < 3; t++) HIPCHK(h, hipStreamWaitEvent(st, h->ev_join[t], 0));
+  const unsigned ne = (unsigned)h->num_envs;
+  unsigned mg = ne < 1280 ? ne : 1280, hg = ne < 1024 ? ne : 1024, gg = ne < 128 ? ne : 128;
+  if (io.mode == 2) { mg = mg < 128 ? mg : 128; hg = hg < 64 ? hg : 64; gg = gg < 16 ? gg : 16; }   // (reset-time forward passes: a handful of envs at most)
   hipLaunchKernelGGL(jaco_physics_kernel_medium_drain, dim3(mg), dim3(64), 0, st, A);
-  HIPCHK(h, hipGetLastError());
   hipLaunchKernelGGL(jaco_physics_kernel_heavy_drain, dim3(hg), dim3(64), 0, st, A);
-  HIPCHK(h, hipGetLastError());
-  hipLaunchKernelGGL(jaco_physics_kernel_huge_drain, dim3((unsigned)(h->num_envs < 512 ? h->num_envs : 512)), dim3(64), 0, st, A);
+  hipLaunchKernelGGL(jaco_physics_kernel_huge_drain, dim3(gg), dim3(64), 0, st, A);
   HIPCHK(h, hipGetLastError());
   if (ev) HIPCHK(h, hipEventRecord(ev->second, st));
   return JACO_OK;
@@ -544,6 +619,7 @@ extern "C" int jaco_set_option(JacoHandle* h, const char* name, double v) {
   if (!strcmp(name, "concurrent_heavy")) { h->concurrent = v != 0; return JACO_OK; }
   if (!strcmp(name, "tier_return")) { h->tier_return = v != 0; return JACO_OK; }
   if (!strcmp(name, "heavy_workers")) { h->workers = v < 1 ? 1 : (int)v; return JACO_OK; }
+  if (!strcmp(name, "hints")) { h->use_hints = v != 0; return JACO_OK; }
   else if (!strcmp(name, "iterations")) m.iterations = (int)v;
   else if (!strcmp(name, "tolerance")) m.tolerance = (float)v;
   else if (!strcmp(name, "ls_iterations")) m.ls_iterations = (int)v;

@@ -77,15 +77,20 @@ struct JacoStepArgs {
   unsigned* flags;     // [nenv] sticky error bits
   int* stats;          // [nenv][4]: ncon, nefc, newton iterations, candidates (last substep) or nullptr
   int* remaining;      // [nenv] substeps left for the heavy tier (written by the light tier)
-  int* heavy_list;     // [nenv] env ids handed to the heavy tier
-  int* heavy_count;    // [1] entries appended to heavy_list
-  int* heavy2_list;    // [nenv] env ids the medium tier handed on to the heavy tier
-  int* heavy2_count;   // [1]
-  int* heavy3_list;    // [nenv] env ids the heavy tier handed on to the huge tier
-  int* heavy3_count;   // [1]
-  int* heavy_taken;    // [1] entries claimed by heavy-tier workgroups
-  int* light_left;     // [1] light-tier workgroups still running (0: no further entries will appear)
-  const int* worker_limit;  // [1] heavy-tier workers beyond this index leave at once (sized from the previous launch's hand-overs), or nullptr
+  // work queues of the three bigger tiers (q[0] medium, q[1] heavy, q[2] huge): env ids appended by whoever meets an overflow
+  // (or, at the start of a step, by the light grid for envs whose last step needed that tier: `hint`), served by resident worker
+  // workgroups while the light grid runs and by the drain launches after it
+  struct Queue {
+    int* list;          // [nenv] env ids; -1 = not yet published, -2 = taken by a worker
+    int* count;         // [1] entries appended
+    int* taken;         // [1] slots claimed by workers
+    const int* limit;   // [1] workers beyond this index leave at once (sized from the previous launch's demand), or nullptr
+    const int* reserve; // [1] workers beyond this index leave as soon as the queue has run dry (the others wait for late arrivals)
+  } q[3];
+  const int* routed_mark;  // [nenv] == launch_id: the env was queued for a bigger tier before the launch (hint > 0): not the light grid's
+  int launch_id;
+  int* light_left;     // [1] light-tier workgroups still running (0: the resident workers leave, the drains take the rest)
+  int* hint;           // [nenv] highest tier (0..3) the env's last step really needed, or nullptr: where its next step starts
   int nenv, nsub, disable_contact;
   int no_tier_return;  // 1: an env handed to the heavy tier stays there for the rest of the launch (option "tier_return" = 0)
   // env-level mode (jaco_step / jaco_reset): nsub = frame_skip
@@ -973,6 +978,23 @@ JDEV void stage_integrate_pos(const JacoModelDev* m, L& s, int lane) {
 #include "collision.h"
 #include "env_logic.h"
 
+// Append `env` to tier queue `t` from inside a running launch.  Everything the consumer will read (state rows, task row,
+// remaining, ...) must already have gone out with write-through stores; the entry is published after they are acknowledged.
+JDEV void queue_push(const JacoStepArgs& A, int t, int env, int left, int lane) {
+  if (lane == 0) st_wt_i(&A.remaining[env], left);
+  dev_stores_done();
+  wave_sync();
+  if (lane == 0) {
+    int slot = jaco_atomic_inc(A.q[t].count);
+    st_wt_i(&A.q[t].list[slot], env);
+    dev_stores_done();   // (the entry is out before the count of running light workgroups drops)
+  }
+}
+// a tier (1..3) that really had to be used in this step is remembered for the env's next step
+JDEV void hint_raise(const JacoStepArgs& A, int env, int tier, int lane) {
+  if (lane == 0 && A.hint) atomicMax(&A.hint[env], tier);
+}
+
 // ---------------------------------------------------------------- the kernels
 // One substep loop for one env; returns the number of substeps NOT done (light tier bail-out) or 0.
 // TIER: 0 light, 1 medium, 2 heavy, 3 huge.  Tiers below 3 stop at a capacity overflow (*why = 1) and leave the env to the next
@@ -991,6 +1013,7 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
   unsigned flags = LIGHT ? 0u : JFLAG_HEAVY_TIER;
   float sens = 0.f;
   int iters = 0, left = 0, sub0 = 0, nls_last = 0, calm = 0;
+  bool tier_used = false;   // this tier's extra capacity was really needed in at least one substep
   const int emode = A.env_mode;
   if (emode >= 4) nsub = 0;   // take_action / terminal_inspection on their own: no substep runs
   if (emode) {   // task row + the one-substep-stale quantities the controller reads (env_logic.h)
@@ -1145,10 +1168,12 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
       if (lane == 0) { s.ncon = 0; s.ncand = 0; }
       wave_sync();
     }
-    if (!LIGHT) {   // would the tier below have coped with this substep?  (heavy -> medium, medium -> light)
+    if (!LIGHT) {   // would the tier below have coped with this substep?  (huge -> heavy, heavy -> medium, medium -> light)
       constexpr int LCON = TIER == 3 ? JacoHeavy::MAXCON : (TIER == 2 ? JacoMedium::MAXCON : JacoLight::MAXCON);
       constexpr int LEFC = TIER == 3 ? JacoHeavy::MAXEFC : (TIER == 2 ? JacoMedium::MAXEFC : JacoLight::MAXEFC);
-      calm = (s.ncon <= LCON && s.nefc <= LEFC && s.ncand <= JacoLight::MAXCAND / 2) ? calm + 1 : 0;
+      const bool fits = s.ncon <= LCON && s.nefc <= LEFC && s.ncand <= JacoLight::MAXCAND / 2;
+      calm = fits ? calm + 1 : 0;
+      if (!fits && !tier_used) { tier_used = true; hint_raise(A, env, TIER, lane); }
     }
     if (TIER == 3) flags |= cflags;   // the last tier has nobody to hand over to: contacts / rows beyond its capacity were dropped, say so
     if (TIER < 3 && cflags) {   // capacity exceeded: leave this substep (and the rest) to the next tier; nothing was mutated
@@ -1339,21 +1364,19 @@ __global__ __launch_bounds__(64, 2) void jaco_physics_kernel(JacoStepArgs A) {
   const int lane = lane_id();
   if (env_id() >= A.nenv) return;
   const int env = A.order ? A.order[env_id()] : env_id();
-  const unsigned long long t_start = wave_clock();
-  int left = run_env<JacoLight, 0>(A, s, env, A.nsub, lane);
-  // (only real steps record their cost: the masked forward pass of a reset must not wipe the launch-order heuristic's input)
-  if (lane == 0 && A.cost && A.env_mode <= 1) { unsigned c = (unsigned)((wave_clock() - t_start) >> 4); if (left > 0) st_wt_u(&A.cost[env], c); else A.cost[env] = c; }
-  // hand-off: the env's state went to memory with write-through stores (run_env); once they are acknowledged the env
-  // is appended to the heavy tier's work list.  Heavy-tier workgroups run concurrently (jaco_env.hip) and poll the list.
-  if (left > 0) {
-    if (lane == 0) st_wt_i(&A.remaining[env], left);
-    dev_stores_done();
-    wave_sync();
-    if (lane == 0) {
-      int slot = jaco_atomic_inc(A.heavy_count);
-      st_wt_i(&A.heavy_list[slot], env);
-      dev_stores_done();   // (the entry is out before the count of running light workgroups drops)
-    }
+  // (envs whose previous step ended in a bigger tier were queued there before the launch: not this grid's, and not counted in light_left)
+  if (A.routed_mark && A.routed_mark[env] == A.launch_id) return;
+  const bool masked_out = (A.env_mode == 2 || A.env_mode == 3) && A.mask && !A.mask[env];
+  int left = 0;
+  if (!masked_out) {
+    if (A.hint && A.env_mode >= 2 && lane == 0) st_wt_i(&A.hint[env], 0);   // a reset env starts from scratch (its forward pass may raise it again)
+    const unsigned long long t_start = wave_clock();
+    left = run_env<JacoLight, 0>(A, s, env, A.nsub, lane);
+    // (only real steps record their cost: the masked forward pass of a reset must not wipe the launch-order heuristic's input)
+    if (lane == 0 && A.cost && A.env_mode <= 1) { unsigned c = (unsigned)((wave_clock() - t_start) >> 4); if (left > 0) st_wt_u(&A.cost[env], c); else A.cost[env] = c; }
+    // hand-off: the env's state went to memory with write-through stores (run_env); once they are acknowledged the env
+    // is appended to the medium tier's queue.  Its workgroups run concurrently (jaco_env.hip) and poll the queue.
+    if (left > 0) queue_push(A, 0, env, left, lane);
   }
   if (lane == 0 && A.light_left) jaco_atomic_dec(A.light_left, false);
 }
@@ -1377,100 +1400,146 @@ JDEV int run_env_tiers(const JacoStepArgs& A, U& u, int env, int lane) {
   return left > 0 ? left : 0;
 }
 union JacoMediumLDS { JacoLDS<JacoMedium> big; JacoLDS<JacoLight> light; };
-// medium tier: an env that outgrew it as well goes on the heavy tier's list (served after the medium tier, in stream order)
+// medium tier: an env that outgrew it as well goes on the heavy tier's queue
 JDEV void medium_env(const JacoStepArgs& A, JacoMediumLDS& u, int env, int lane) {
   int left = run_env_tiers<JacoMedium, 1>(A, u, env, lane);
-  if (left > 0 && lane == 0) {
-    A.remaining[env] = left;
-    A.heavy2_list[jaco_atomic_inc(A.heavy2_count)] = env;
+  if (left > 0) queue_push(A, 1, env, left, lane);
+}
+// heavy tier: heavy code while the env needs more than the medium capacities, then medium <-> light as above.
+// Returns 0 when the env's step is complete, or the substeps left when it outgrew the heavy capacities too (huge tier's turn).
+union JacoAllLDS { JacoLDS<JacoHeavy> heavy; JacoMediumLDS ml; };
+JDEV int heavy_env_run(const JacoStepArgs& A, JacoAllLDS& u, int env, int lane) {
+  const bool stepmode = A.env_mode == 1 || A.env_mode == 3;
+  int left = stepmode ? A.nsub : A.remaining[env], why = 0;
+  for (;;) {
+    left = run_env<JacoHeavy, 2>(A, u.heavy, env, stepmode ? A.nsub : left, lane, !A.no_tier_return, &why);
+    if (left <= 0) return 0;
+    if (why == 1) return left;
+    wave_sync();
+    if (!stepmode && lane == 0) A.remaining[env] = left;   // (ctrl level: run_env_tiers reads the substeps left from here)
+    wave_sync();
+    left = run_env_tiers<JacoMedium, 1>(A, u.ml, env, lane);
+    if (left <= 0) return 0;
+    wave_sync();
+    if (!stepmode && lane == 0) A.remaining[env] = left;
+    wave_sync();
   }
 }
-// medium tier, concurrent with the light tier: persistent workgroups claim entries of the work list.  Entries are -1 until the
-// light tier publishes them; a worker leaves as soon as the light tier has finished (the rest of the list goes to the drain's
-// full grid), or (safety) when the light tier makes no progress for ~JACO_WORKER_PATIENCE polls, e.g. because the two launches were
-// serialised; whatever is left is picked up by the drain launch that follows the light tier in stream order.
-#define JACO_WORKER_PATIENCE 6000
-__global__ __launch_bounds__(64, 2) void jaco_physics_kernel_medium(JacoStepArgs A) {
-  __shared__ JacoMediumLDS u;
-  const int lane = lane_id();
-  if (A.worker_limit && env_id() >= *A.worker_limit) return;
+JDEV void heavy_env(const JacoStepArgs& A, JacoAllLDS& u, int env, int lane) {
+  const unsigned long long t_start = wave_clock();
+  const int left = heavy_env_run(A, u, env, lane);
+  if (lane == 0 && A.cost) A.cost[env] += (unsigned)((wave_clock() - t_start) >> 4);
+  if (left > 0) queue_push(A, 2, env, left, lane);   // outgrew the heavy capacities too
+}
+// huge tier: whatever outgrew the heavy tier (a reset with the hand inside the pedestal) runs here while that lasts, then steps
+// down through heavy / medium / light like everything else
+union JacoHugeLDS { JacoLDS<JacoHuge> huge; JacoAllLDS rest; };
+JDEV void huge_env(const JacoStepArgs& A, JacoHugeLDS& u, int env, int lane) {
+  const bool stepmode = A.env_mode == 1 || A.env_mode == 3;
+  const unsigned long long t_start = wave_clock();
+  int left = stepmode ? A.nsub : A.remaining[env], why = 0;
   for (;;) {
-    int i = 0;
-    if (lane == 0) i = jaco_atomic_inc(A.heavy_taken);
-    i = wave_uniform_i(i);
-    if (i >= A.nenv) return;
-    int env = -1, last_left = -1, idle = 0;
+    left = run_env<JacoHuge, 3>(A, u.huge, env, stepmode ? A.nsub : left, lane, !A.no_tier_return, &why);
+    if (left <= 0) break;
+    wave_sync();
+    if (!stepmode && lane == 0) A.remaining[env] = left;
+    wave_sync();
+    left = heavy_env_run(A, u.rest, env, lane);
+    if (left <= 0) break;
+    wave_sync();
+    if (!stepmode && lane == 0) A.remaining[env] = left;
+    wave_sync();
+  }
+  if (lane == 0 && A.cost) A.cost[env] += (unsigned)((wave_clock() - t_start) >> 4);
+}
+
+// Resident workers of tier queue T (0 medium, 1 heavy, 2 huge), concurrent with the light grid: persistent workgroups claim
+// queue slots.  A worker leaves as soon as the light grid has finished (whatever is still queued goes to the drain launch
+// that follows in stream order, which brings a full grid instead of these few workgroups), or -- all but a small reserve --
+// when the queue has run dry after the start-of-step routing.
+#define JACO_WORKER_PATIENCE 6000
+template <int T, class LDS>   // (a direct call: handing the serve function over as a lambda trips the gfx950 backend, "illegal VGPR to SGPR copy")
+JDEV void tier_serve(const JacoStepArgs& A, LDS& u, int env, int lane) {
+  if constexpr (T == 0) medium_env(A, u, env, lane);
+  else if constexpr (T == 1) heavy_env(A, u, env, lane);
+  else huge_env(A, u, env, lane);
+}
+template <int T, class LDS>
+JDEV void tier_workers(const JacoStepArgs& A, LDS& u, int lane) {
+  const JacoStepArgs::Queue& Q = A.q[T];
+  const int me = env_id();
+  if (Q.limit && me >= *Q.limit) return;
+  const int reserve = Q.reserve ? *Q.reserve : 0x7fffffff;
+  for (;;) {
+    // claim a slot that a producer has already reserved (count > taken): nothing is ever claimed that may stay empty
+    int i = -1, last_left = -1, idle = 0;
     for (;;) {
+      // nobody stays once the light grid is done: whatever is still queued then belongs to the drain launches, which bring
+      // full grids instead of these few workgroups (that is also what carries the load when most envs need a bigger tier)
       const int ll = wave_uniform_i(dev_load_relaxed(A.light_left));
-      // The light tier is done: whatever is still on the list (this slot included: it is not marked as taken) belongs to
-      // the drain launch, which brings a full grid instead of these few workgroups.
       if (ll <= 0) return;
-      env = wave_uniform_i(dev_load_relaxed(&A.heavy_list[i]));
-      if (env >= 0) break;
+      int got = -1;
+      if (lane == 0) {
+        const int t = dev_load_relaxed(Q.taken), c = dev_load_relaxed(Q.count);
+        if (t < c) got = atomicCAS(Q.taken, t, t + 1) == t ? t : -2;   // -2: another worker was faster, look again
+      }
+      got = wave_uniform_i(got);
+      if (got >= 0) { i = got; break; }
+      if (got == -2) continue;
+      // the queue is dry.  What the ordering pass queued before the launch (the envs whose last step ended in a bigger tier) has
+      // been handed out: only the reserve stays resident for the odd overflow later on -- an idle worker holds LDS the light
+      // grid could use
+      if (me >= reserve) return;
       idle = ll == last_left ? idle + 1 : 0;
       last_left = ll;
-      if (idle > JACO_WORKER_PATIENCE) return;   // (a slot claimed here and filled later is served by the drain launch)
+      if (idle > JACO_WORKER_PATIENCE) return;   // (safety: the light grid makes no progress, e.g. the launches were serialised)
       wave_sleep();
     }
-    dev_acquire();   // the env's state, written by the light workgroup before it published the entry
-    if (lane == 0) A.heavy_list[i] = -2;   // taken
-    medium_env(A, u, env, lane);
+    int env;
+    for (;;) {   // the producer publishes the entry right after reserving the slot
+      env = wave_uniform_i(dev_load_relaxed(&Q.list[i]));
+      if (env >= 0) break;
+      __builtin_amdgcn_s_sleep(2);
+    }
+    dev_acquire();   // the env's state, written by the producing workgroup before it published the entry
+    if (lane == 0) st_wt_i(&Q.list[i], -2);   // taken
+    tier_serve<T>(A, u, env, lane);
     wave_sync();
   }
 }
-// drains: after the light tier and the workers have finished (stream order), serve whatever entry is still pending on the
-// medium list, then the envs the medium tier passed on
+// drain of tier queue T: after the light grid and the workers have finished (stream order), serve whatever entry is still pending
+template <int T, class LDS>
+JDEV void tier_drain(const JacoStepArgs& A, LDS& u, int lane) {
+  const JacoStepArgs::Queue& Q = A.q[T];
+  const int count = *Q.count;
+  for (int i = env_id(); i < count; i += grid_size()) {
+    int env = Q.list[i];
+    if (env < 0) continue;
+    tier_serve<T>(A, u, env, lane);
+    wave_sync();
+  }
+}
+__global__ __launch_bounds__(64, 2) void jaco_physics_kernel_medium(JacoStepArgs A) {
+  __shared__ JacoMediumLDS u;
+  tier_workers<0>(A, u, lane_id());
+}
 __global__ __launch_bounds__(64, 2) void jaco_physics_kernel_medium_drain(JacoStepArgs A) {
   __shared__ JacoMediumLDS u;
-  const int lane = lane_id();
-  const int count = *A.heavy_count;
-  for (int i = env_id(); i < count; i += grid_size()) {
-    int env = A.heavy_list[i];
-    if (env < 0) continue;
-    medium_env(A, u, env, lane);
-    wave_sync();
-  }
+  tier_drain<0>(A, u, lane_id());
 }
-// heavy tier: heavy code while the env needs more than the medium capacities, then medium <-> light as above
-union JacoAllLDS { JacoLDS<JacoHeavy> heavy; JacoMediumLDS ml; };
+__global__ __launch_bounds__(64) void jaco_physics_kernel_heavy_workers(JacoStepArgs A) {
+  __shared__ JacoAllLDS u;
+  tier_workers<1>(A, u, lane_id());
+}
 __global__ __launch_bounds__(64) void jaco_physics_kernel_heavy_drain(JacoStepArgs A) {
   __shared__ JacoAllLDS u;
-  const int lane = lane_id();
-  const int count = *A.heavy2_count;
-  const bool stepmode = A.env_mode == 1 || A.env_mode == 3;
-  for (int i = env_id(); i < count; i += grid_size()) {
-    const int env = A.heavy2_list[i];
-    const unsigned long long t_start = wave_clock();
-    int left = stepmode ? A.nsub : A.remaining[env], why = 0;
-    for (;;) {
-      left = run_env<JacoHeavy, 2>(A, u.heavy, env, stepmode ? A.nsub : left, lane, !A.no_tier_return, &why);
-      if (left <= 0) break;
-      if (why == 1) {   // outgrew the heavy capacities too: the huge tier's launch follows in stream order
-        if (lane == 0) { A.remaining[env] = left; A.heavy3_list[jaco_atomic_inc(A.heavy3_count)] = env; }
-        break;
-      }
-      wave_sync();
-      if (!stepmode && lane == 0) A.remaining[env] = left;   // (ctrl level: run_env_tiers reads the substeps left from here)
-      wave_sync();
-      left = run_env_tiers<JacoMedium, 1>(A, u.ml, env, lane);
-      if (left <= 0) break;
-      wave_sync();
-    }
-    if (lane == 0 && A.cost) A.cost[env] += (unsigned)((wave_clock() - t_start) >> 4);
-    wave_sync();
-  }
+  tier_drain<1>(A, u, lane_id());
 }
-// huge tier: whatever outgrew the heavy tier (a reset with the hand inside the pedestal) finishes its step here
+__global__ __launch_bounds__(64) void jaco_physics_kernel_huge_workers(JacoStepArgs A) {
+  __shared__ JacoHugeLDS u;
+  tier_workers<2>(A, u, lane_id());
+}
 __global__ __launch_bounds__(64) void jaco_physics_kernel_huge_drain(JacoStepArgs A) {
-  __shared__ JacoLDS<JacoHuge> s;
-  const int lane = lane_id();
-  const int count = *A.heavy3_count;
-  const bool stepmode = A.env_mode == 1 || A.env_mode == 3;
-  for (int i = env_id(); i < count; i += grid_size()) {
-    const int env = A.heavy3_list[i];
-    const unsigned long long t_start = wave_clock();
-    run_env<JacoHuge, 3>(A, s, env, stepmode ? A.nsub : A.remaining[env], lane);
-    if (lane == 0 && A.cost) A.cost[env] += (unsigned)((wave_clock() - t_start) >> 4);
-    wave_sync();
-  }
+  __shared__ JacoHugeLDS u;
+  tier_drain<2>(A, u, lane_id());
 }

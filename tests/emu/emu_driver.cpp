@@ -20,24 +20,30 @@ static int g_mpr_output_fwd();
 static JacoModelDev g_model;
 static std::vector<float> g_hull;
 static int g_no_tier_return_fwd();
+static std::vector<int> g_hint;
+static int g_use_hints = 0;
+extern "C" void emu_set_hints(int on) { g_use_hints = on; }
 static int emu_launch(JacoStepArgs A, int* heavy_envs) {
   A.no_tier_return = g_no_tier_return_fwd();
-  std::vector<int> remaining(A.nenv, 0), list(A.nenv, 0);
-  std::fill(list.begin(), list.end(), -1);
-  std::vector<int> list2(A.nenv, -1), list3(A.nenv, -1);
-  int count = 0, taken = 0, light_left = A.nenv, count2 = 0, count3 = 0;
-  A.heavy3_list = list3.data(); A.heavy3_count = &count3;
-  A.remaining = remaining.data(); A.heavy_list = list.data(); A.heavy_count = &count; A.heavy_taken = &taken; A.light_left = &light_left;
-  A.heavy2_list = list2.data(); A.heavy2_count = &count2;
+  std::vector<int> remaining(A.nenv, 0), lists(3 * (size_t)A.nenv, -1);
+  int count[3] = {0, 0, 0}, taken[3] = {0, 0, 0}, light_left = A.nenv;
+  A.remaining = remaining.data(); A.light_left = &light_left;
+  for (int t = 0; t < 3; t++) { A.q[t].list = lists.data() + (size_t)t * A.nenv; A.q[t].count = &count[t]; A.q[t].taken = &taken[t]; A.q[t].limit = nullptr; A.q[t].reserve = nullptr; }
+  A.routed_mark = nullptr; A.launch_id = 1;
+  if ((int)g_hint.size() != A.nenv) g_hint.assign(A.nenv, 0);
+  A.hint = g_use_hints ? g_hint.data() : nullptr;
   emu_grid = A.nenv;
   for (int e = 0; e < A.nenv; e++) emu_run_wave(e, [&]() { jaco_physics_kernel(A); });
   emu_grid = 1;
-  // the worker form of the medium tier (here after the light tier: every entry is already published), then the drains
-  if (count > 0) emu_run_wave(0, [&]() { jaco_physics_kernel_medium(A); });
-  if (count > 0) emu_run_wave(0, [&]() { jaco_physics_kernel_medium_drain(A); });
-  if (count2 > 0) emu_run_wave(0, [&]() { jaco_physics_kernel_heavy_drain(A); });
-  if (count3 > 0) emu_run_wave(0, [&]() { jaco_physics_kernel_huge_drain(A); });
-  if (heavy_envs) *heavy_envs = count;
+  // (the resident workers of the GPU build leave as soon as the light grid is done: here that is always the case, so the
+  // drains serve every queue; they are the same serve functions)
+  if (count[0] > 0) emu_run_wave(0, [&]() { jaco_physics_kernel_medium(A); });
+  if (count[0] > 0) emu_run_wave(0, [&]() { jaco_physics_kernel_medium_drain(A); });
+  if (count[1] > 0) emu_run_wave(0, [&]() { jaco_physics_kernel_heavy_workers(A); });
+  if (count[1] > 0) emu_run_wave(0, [&]() { jaco_physics_kernel_heavy_drain(A); });
+  if (count[2] > 0) emu_run_wave(0, [&]() { jaco_physics_kernel_huge_workers(A); });
+  if (count[2] > 0) emu_run_wave(0, [&]() { jaco_physics_kernel_huge_drain(A); });
+  if (heavy_envs) *heavy_envs = count[0];
   return 0;
 }
 // env-level call: mode 1 = step (nsub = frame_skip), mode 2 = forward only
@@ -77,21 +83,8 @@ extern "C" int emu_physics_step(const void* blob, long blob_size, int nenv, int 
   JacoStepArgs A{};
   A.model = &model; A.hull = hull.data(); A.qpos = qpos; A.qvel = qvel; A.qacc_ws = qacc_ws; A.ctrl = ctrl; A.sensordata = sensordata;
   A.flags = flags; A.stats = stats; A.nenv = nenv; A.nsub = nsub; A.disable_contact = disable_contact; A.dbg = dbg; A.dbg_env = dbg_env;
-  std::vector<int> remaining(nenv, 0), list(nenv, -1);
-  std::vector<int> list2(nenv, -1), list3(nenv, -1);
-  int count = 0, taken = 0, light_left = nenv, count2 = 0, count3 = 0;
-  A.heavy3_list = list3.data(); A.heavy3_count = &count3;
-  A.remaining = remaining.data(); A.heavy_list = list.data(); A.heavy_count = &count; A.heavy_taken = &taken; A.light_left = &light_left;
-  A.heavy2_list = list2.data(); A.heavy2_count = &count2;
-  emu_grid = nenv;
-  for (int e = 0; e < nenv; e++) emu_run_wave(e, [&]() { jaco_physics_kernel(A); });
-  emu_grid = 1;
-  if (count > 0) emu_run_wave(0, [&]() { jaco_physics_kernel_medium(A); });
-  if (count > 0) emu_run_wave(0, [&]() { jaco_physics_kernel_medium_drain(A); });
-  if (count2 > 0) emu_run_wave(0, [&]() { jaco_physics_kernel_heavy_drain(A); });
-  if (count3 > 0) emu_run_wave(0, [&]() { jaco_physics_kernel_huge_drain(A); });
-  if (heavy_envs) *heavy_envs = count;
-  return 0;
+  static JacoModelDev* keep = &model; (void)keep;
+  return emu_launch(A, heavy_envs);
 }
 
 static int g_no_tier_return_fwd() { return g_no_tier_return; }

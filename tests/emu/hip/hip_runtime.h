@@ -29,3 +29,6 @@ static inline float __frcp_rn(float x) { return 1.0f / x; }
 
 static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+static inline int atomicMax(int* p, int v) { int o = *p; if (v > o) *p = v; return o; }
+static inline int atomicCAS(int* p, int cmp, int v) { int o = *p; if (o == cmp) *p = v; return o; }
+static inline void __builtin_amdgcn_s_sleep(int) {}

@@ -16,12 +16,18 @@ for opt in ("heavy_workers", "tier_return", "concurrent_heavy"):
 genv.reset()
 gen = torch.Generator(device=dev); gen.manual_seed(2000)
 scale = float(sys.argv[sys.argv.index("--action-scale") + 1]) if "--action-scale" in sys.argv else 1.0
-actions = [(torch.rand(B, 7, device=dev, generator=gen) * 2 - 1) * scale for _ in range(4)]
+resets = "--resets" in sys.argv   # bench.py's loop: fresh actions, masked reset of finished envs, staggered episode ages
+if resets:
+    ts = genv.task_state(); ts[:, 1] = torch.randint(0, 700, (B,), device=dev, generator=gen).float(); genv.set_task_state(ts)
+    for _ in range(int(sys.argv[sys.argv.index("--preroll") + 1]) if "--preroll" in sys.argv else 0):
+        o, r, d, _ = genv.step((torch.rand(B, 7, device=dev, generator=gen) * 2 - 1) * scale); genv.reset(d)
 tot = 0.0
 for i in range(n):
     env.clear_flags()
+    a = (torch.rand(B, 7, device=dev, generator=gen) * 2 - 1) * scale
     torch.cuda.synchronize(); t = time.perf_counter()
-    o, r, d, _ = genv.step(actions[i % 4])
+    o, r, d, _ = genv.step(a)
+    if resets: genv.reset(d)
     torch.cuda.synchronize(); dt = time.perf_counter() - t
     if i >= 4: tot += dt
     st = env.stats().float()

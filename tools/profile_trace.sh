@@ -13,9 +13,9 @@ for f in glob.glob("$OUT/*/*kernel_trace.csv"):
 rows.sort()
 step, t0 = -1, 0
 for s, e, k in rows:
-    short = "prepare" if "prepare" in k else "order" if "order" in k else "mdrain" if "medium_drain" in k else "hdrain" if "heavy_drain" in k else "workers" if "medium" in k else "light" if "jaco_physics_kernel" in k else None
+    short = "prepare" if "prepare" in k else "order" if "order" in k else "mdrain" if "medium_drain" in k else "hdrain" if "heavy_drain" in k else "huge" if "huge" in k else "hworkers" if "heavy_workers" in k else "workers" if "medium" in k else "light" if "jaco_physics_kernel" in k else None
     if short is None: continue
     if short == "prepare": step += 1; t0 = s
     if short in ("prepare", "order"): continue
-    print("launch %3d %-8s start %8.3f ms  end %8.3f ms" % (step, short, (s - t0) * 1e-6, (e - t0) * 1e-6))
+    if e - s > 200000: print("launch %3d %-8s start %8.3f ms  end %8.3f ms" % (step, short, (s - t0) * 1e-6, (e - t0) * 1e-6))
 PY
