@@ -121,6 +121,10 @@ int jaco_forward(JacoHandle* h, float* obs_dev, void* stream);
 int jaco_take_action(JacoHandle* h, const float* action_dev, void* stream);
 int jaco_terminal_inspection(JacoHandle* h, uint8_t* done_dev, float* bonus_dev, void* stream);
 int jaco_set_noise(JacoHandle* h, const float* noise_dev);
+/* Observation branch rulebased_subgoal = False (env_mujoco_util.py:255-270; option "obs_mode" = 1): obs[17:23] is the reaching goal
+ * drawn at reset, and _take_action moves the "subgoal_reach" marker to subgoal + previous target (:609) when the caller passes the
+ * policy's sub-goal offsets [num_envs][6] here (NULL: the marker stays where it is). */
+int jaco_set_subgoal(JacoHandle* h, const float* subgoal_dev);
 int jaco_get_task_state(JacoHandle* h, float* out_dev, void* stream);
 int jaco_set_task_state(JacoHandle* h, const float* in_dev, void* stream);
 int jaco_task_row_floats(void);

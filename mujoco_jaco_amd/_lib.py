@@ -41,6 +41,7 @@ SYMBOLS = {
     "jaco_take_action": (_ci, [_vp, _vp, _vp]),
     "jaco_terminal_inspection": (_ci, [_vp, _vp, _vp, _vp]),
     "jaco_set_noise": (_ci, [_vp, _vp]),
+    "jaco_set_subgoal": (_ci, [_vp, _vp]),
     "jaco_get_task_state": (_ci, [_vp, _vp, _vp]),
     "jaco_set_task_state": (_ci, [_vp, _vp, _vp]),
     "jaco_task_row_floats": (_ci, []),

@@ -23,7 +23,9 @@
 #define JT_CTRL 20       // [9]
 #define JT_SUCC 29       // success flag of the last terminal step
 #define JT_WB 30         // last |EE - base| (get_wb)
-#define JTASK_N 32
+#define JT_REACHGOAL 32  // [6] reaching goal: position + Euler rxyz (drawn at reset, env_mujoco_util.py:199-207)
+#define JTASK_N 40
+static_assert(JTASK_N == JTASK_FLOATS, "task row size");
 // per-env cache row: what the controller reads one substep late
 #define JC_M 0           // [6][6] arm block of the mass matrix
 #define JC_BIAS 36       // [6]
@@ -169,12 +171,33 @@ JDEV float reward_picking(v3 ee, const float* eul, v3 obj, int touch) {
   return r * 0.01f;
 }
 
+// ---------------------------------------------------------------- a10 / a11 for task 'reaching' (env_mujoco_util.py:314-351, 504-520)
+// The reference differences Euler angles after an euler -> unit quaternion -> euler round trip (canonical angles, pitch in
+// [-pi/2, pi/2]): the goal's (alpha, beta, gamma) has beta = acos(.) in [0, pi] and is NOT canonical as drawn.
+JDEV float reach_ang_diff(const float* eul_ee, const float* eul_goal) {
+  float q[4], a[3], b[3];
+  euler_rxyz_to_quat(eul_ee[0], eul_ee[1], eul_ee[2], q); quat_to_euler_rxyz(q, a);
+  euler_rxyz_to_quat(eul_goal[0], eul_goal[1], eul_goal[2], q); quat_to_euler_rxyz(q, b);
+  float d = sqrtf((a[0] - b[0]) * (a[0] - b[0]) + (a[1] - b[1]) * (a[1] - b[1]) + (a[2] - b[2]) * (a[2] - b[2]));
+  const float PI = 3.14159265358979323846f;
+  return d > PI ? 2.f * PI - d : d;
+}
+JDEV float reward_reaching(v3 ee, const float* eul, const float* goal, v3 base) {
+  const float dist = norm(ee - mk3(goal[0], goal[1], goal[2])), ang = reach_ang_diff(eul, goal + 3);
+  float r = 5.f * expf(-dist) * 0.5f + 2.f * expf(-ang / 0.52359877559829887f) / (2.f * (dist * 15.f + 1.f));
+  const float wb = norm(ee - base);
+  if (wb < 0.15f) r -= 0.15f - wb;      // gripper too close to the robot base
+  if (ee.z < 0.1f) r -= 0.1f - ee.z;    // gripper too low
+  return 0.05f * r;
+}
+
 // ---------------------------------------------------------------- a11: termination (env_mujoco.py:144-150, env_mujoco_util.py:492-582)
 // returns done; *bonus, *succ; updates steps / episodes counters in the task row
-JDEV bool terminal_inspection(int task, float* trow, float q2, v3 ee, v3 base, v3 obj, v3 dest_goal, int touch, float* bonus, int* succ, float* wb) {
+JDEV bool terminal_inspection(int task, float* trow, float q2, v3 ee, v3 base, v3 obj, v3 dest_goal, int touch, float* bonus, int* succ, float* wb,
+                              const float* eul = nullptr, const float* reachgoal = nullptr) {
   float steps = trow[JT_STEPS] + 1.f;
   trow[JT_STEPS] = steps;
-  const float task_max = 700.f;   // picking / placing (env_mujoco.py:20-21)
+  const float task_max = task == 2 ? 500.f : 700.f;   // picking / placing 700, everything else 500 (env_mujoco.py:20-21)
   *succ = 0; *wb = 0.f;
   if (!(steps < task_max)) { *bonus = -10.f; return true; }
   float n = trow[JT_EPISODES] + 1.f;
@@ -182,6 +205,12 @@ JDEV bool terminal_inspection(int task, float* trow, float q2, v3 ee, v3 base, v
   *wb = norm(ee - base);
   const float PI = 3.14159265358979323846f;
   if (PI - 0.1f < q2 && q2 < PI + 0.1f) { *bonus = -1.f; return true; }
+  if (task == 2) {   // reaching (:504-520; the reference returns a 3-tuple here, which env_mujoco.py:125 cannot unpack: the success flag is the fix)
+    const float dist = norm(ee - mk3(reachgoal[0], reachgoal[1], reachgoal[2]));
+    if (dist < 0.025f && reach_ang_diff(eul, reachgoal + 3) < PI / 6.f) { *bonus = 200.f - n * 0.1f; *succ = 1; return true; }
+    *bonus = 0.f;
+    return false;
+  }
   if (task == 0) {
     if (obj.z > 0.1898f + 0.07f && (touch == 1 || touch == 3)) { *bonus = 200.f - n * 0.1f; *succ = 1; return true; }
     if (obj.z < 0.1f) { *bonus = -20.f; return true; }

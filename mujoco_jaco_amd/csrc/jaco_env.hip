@@ -2,6 +2,7 @@
 // Host side owns model constants, per-env state rows and launch plumbing; all arithmetic is in
 // physics_kernel.h.  There is no CPU fallback: without a HIP device jaco_create fails.
 #include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
 #include <cstddef>
 
 #include <cstdio>
@@ -35,6 +36,7 @@ struct JacoHandle {
   // tier queues (medium, heavy, huge): lists [3][num_envs] and the control words JQ_* below
   int *qlist = nullptr, *qctl = nullptr;
   int* hint = nullptr;                        // [num_envs] tier the env's last step needed
+  bool reset_listed = false;                  // jaco_reset in progress: h->order holds the list of the masked envs
   int* routed_mark = nullptr;                 // [num_envs] id of the launch that queued the env for a bigger tier before it started
   int launch_id = 0;
   hipStream_t side[3] = {nullptr, nullptr, nullptr};   // the tiers' resident workers run here, concurrently with the light grid
@@ -47,6 +49,8 @@ struct JacoHandle {
   unsigned* order_ctl = nullptr;   // histogram / cursors / cost sum / bucket reference of the ordering passes
   int schedule = 1;           // option "schedule": 0 = launch envs in index order
   const float* noise = nullptr;
+  const float* subgoal = nullptr;   // obs_mode 1: the policy's sub-goal offsets for the "subgoal_reach" marker
+  int obs_mode = 0;
   unsigned long long* prof = nullptr;
   std::vector<float> qpos0;
   int num_envs = 0, device = 0, frame_skip = 50, task = 0, disable_contact = 0;
@@ -249,7 +253,8 @@ extern "C" int jaco_reset_state(JacoHandle* h, void* stream) {
 }
 
 #define JACO_PLACING_HOLD_SUBSTEPS 150   // reset_frame_skip (env_mujoco_util.py:114)
-struct EnvIO { int mode = 0; const float* action = nullptr; float* obs = nullptr; float* reward = nullptr; unsigned char* done = nullptr; const unsigned char* mask = nullptr; };
+struct EnvIO { int mode = 0; const float* action = nullptr; float* obs = nullptr; float* reward = nullptr; unsigned char* done = nullptr; const unsigned char* mask = nullptr;
+               bool listed = false; };   // listed: h->order[0 .. order_ctl[67]) holds the envs of `mask` (written by jaco_reset_kernel): launch a small grid over that list
 
 // Launch order for the next env step: envs sorted by the cost of their previous step, most expensive first (32 buckets of
 // 1/8 of the mean cost).  An env step is ~1.5 ms of one wavefront and the expensive ones (hull-hull narrowphase, the
@@ -358,7 +363,7 @@ __global__ void jaco_order_finish_kernel(unsigned* oc, int n) {
 // queue reset before every launch: entries = -1, counters zeroed, light workgroups to go = nenv; how many of the launched
 // workers of each tier stay resident follows the previous launch's demand for that tier (an idle worker still holds LDS the
 // light grid could use): a medium worker serves an env in ~1/20 of a step, a heavy / huge one in ~1/8 - 1/4
-__global__ void jaco_prepare_kernel(int* ctl, int* lists, int n, int wm, int wh, int wg, unsigned* oc, int mode) {
+__global__ void jaco_prepare_kernel(int* ctl, int* lists, int n, int wm, int wh, int wg, unsigned* oc, int mode, int light_wgs) {
   int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   if (i < 3 * n) lists[i] = -1;
   if (i < 66) oc[i] = 0u;
@@ -379,7 +384,7 @@ __global__ void jaco_prepare_kernel(int* ctl, int* lists, int n, int wm, int wh,
       ctl[JQ_LIMIT + t] = w; ctl[JQ_RESERVE + t] = base + late / 10; ctl[JQ_COUNT + t] = 0; ctl[JQ_TAKEN + t] = 0; ctl[JQ_HINTED + t] = 0;
     }
     ctl[JQ_ROUTED] = 0;
-    ctl[JQ_LIGHT] = n;
+    ctl[JQ_LIGHT] = light_wgs;
   }
 }
 
@@ -395,7 +400,7 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
   for (int t = 0; t < 3; t++) { A.q[t].list = h->qlist + (size_t)t * h->num_envs; A.q[t].count = h->qctl + JQ_COUNT + t; A.q[t].taken = h->qctl + JQ_TAKEN + t; A.q[t].limit = h->qctl + JQ_LIMIT + t; A.q[t].reserve = h->qctl + JQ_RESERVE + t; }
   A.routed_mark = nullptr; A.launch_id = ++h->launch_id;
   A.env_mode = io.mode; A.task_id = h->task; A.nact = h->task == JACO_TASK_REACHING ? 6 : 7; A.seed = h->seed;
-  A.task = h->task_rows; A.cache = h->cache; A.action = io.action; A.noise = h->noise; A.obs = io.obs; A.reward = io.reward; A.done = io.done; A.mask = io.mask; A.marker = h->marker;
+  A.task = h->task_rows; A.cache = h->cache; A.action = io.action; A.noise = h->noise; A.obs_mode = h->obs_mode; A.subgoal = h->subgoal; A.obs = io.obs; A.reward = io.reward; A.done = io.done; A.mask = io.mask; A.marker = h->marker;
   A.cost = h->cost;
   const bool reorder = io.mode == 1 && h->schedule && nsub >= 8 && h->num_envs >= 4096;
   std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
@@ -409,6 +414,10 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
     ev = &h->events[h->events_used++];
     HIPCHK(h, hipEventRecord(ev->first, st));
   }
+  // masked reset: the reset kernel has listed its envs; a small grid walks that list instead of 65 536 workgroups finding out one by
+  // one that they have nothing to do (0.9 ms per launch)
+  unsigned light_grid = (unsigned)h->num_envs;
+  if (io.listed && io.mask) { A.order = h->order; A.nslots = reinterpret_cast<const int*>(h->order_ctl + 67); light_grid = light_grid < 1024u ? light_grid : 1024u; }
   // Light grid for every env.  An env that overflows the light capacities is handed over (queue) to the medium tier, and on
   // to the heavy / huge tiers if need be; an env whose previous step ended in a bigger tier is queued there straight away.
   // Each tier's persistent worker workgroups run concurrently on their own higher-priority stream: started just before the
@@ -416,7 +425,7 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
   // frees and would otherwise starve behind the light grid, leaving serial tails of several ms per env step).  The drains that
   // follow in stream order serve whatever the workers did not (all of it when concurrency is off: full grids, which is also
   // what carries the load when most envs overflow).
-  hipLaunchKernelGGL(jaco_prepare_kernel, dim3((unsigned)((3 * h->num_envs + 255) / 256)), dim3(256), 0, st, h->qctl, h->qlist, h->num_envs, h->workers, h->workers_heavy, h->workers_huge, h->order_ctl, io.mode);
+  hipLaunchKernelGGL(jaco_prepare_kernel, dim3((unsigned)((3 * h->num_envs + 255) / 256)), dim3(256), 0, st, h->qctl, h->qlist, h->num_envs, h->workers, h->workers_heavy, h->workers_huge, h->order_ctl, io.mode, (int)light_grid);
   HIPCHK(h, hipGetLastError());
   if (A.hint && io.mode <= 1) {   // queue the envs whose last step ended in a bigger tier, size the tiers' workers
     hipLaunchKernelGGL(jaco_route_kernel, dim3((unsigned)((h->num_envs + 255) / 256)), dim3(256), 0, st, h->hint, h->routed_mark, A.launch_id, h->qlist, h->qctl, h->remaining, h->cost, h->num_envs, nsub);
@@ -441,7 +450,7 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
     HIPCHK(h, hipGetLastError());
     for (int t = 0; t < 3; t++) HIPCHK(h, hipEventRecord(h->ev_join[t], h->side[t]));
   }
-  hipLaunchKernelGGL(jaco_physics_kernel, dim3((unsigned)h->num_envs), dim3(64), 0, st, A);
+  hipLaunchKernelGGL(jaco_physics_kernel, dim3(light_grid), dim3(64), 0, st, A);
   HIPCHK(h, hipGetLastError());
   if (conc) for (int t = 0; t < 3; t++) HIPCHK(h, hipStreamWaitEvent(st, h->ev_join[t], 0));
   const unsigned ne = (unsigned)h->num_envs;
@@ -463,10 +472,13 @@ extern "C" int jaco_physics_step(JacoHandle* h, const float* ctrl_dev, int nsub,
 struct JacoResetArgs {
   const float* qpos0; float* qpos; float* qvel; float* qacc_ws; float* task; const unsigned char* mask; float* marker; const float* marker_rest;
   int nenv, nq, nv, task_id, has_free; unsigned long long seed;
+  float base[3];   // link1 position: the reaching goal's orientation looks along base -> goal (env_mujoco_util.py:201-205)
+  int* list; unsigned* list_count;   // the reset envs, for the launches that follow (forward pass, placing hold)
 };
 __global__ void jaco_reset_kernel(JacoResetArgs R) {
   int e = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   if (e >= R.nenv || (R.mask && !R.mask[e])) return;
+  if (R.mask) R.list[atomicAdd(R.list_count, 1u)] = e;
   float* t = R.task + (size_t)e * JTASK_N;
   unsigned c = __float_as_uint(t[JT_RNG]);
   auto U = [&](float lo, float hi) { float u = rng_uniform(R.seed, (unsigned)e, c++); return lo + (hi - lo) * u; };
@@ -484,6 +496,19 @@ __global__ void jaco_reset_kernel(JacoResetArgs R) {
   }
   for (int k = 0; k < JTASK_N; k++) if (k != JT_RNG) t[k] = 0.f;
   t[JT_GRIP] = 0.6f; t[JT_GRIP_PREV] = 0.6f;
+  {   // reaching goal (__sample_goal, :199-207; drawn for every task, read by task 'reaching' and by the reaching-goal observation)
+    float g[3];
+    for (int k = 0; k < 2; k++) { float m = U(0.3f, 0.42f); g[k] = U(0.f, 1.f) < 0.5f ? -m : m; }
+    g[2] = U(0.3f, 0.5f);
+    float x = g[0] - R.base[0], y = g[1] - R.base[1], z = g[2] - R.base[2];
+    const float n = sqrtf(x * x + y * y + z * z);
+    x /= n; y /= n; z /= n;
+    const float sx = x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f);
+    const float alpha = -asinf(y / sqrtf(y * y + z * z)) * sx, beta = acosf(x) * sx, gamma = U(-0.1f, 0.1f);   // (|xyz| = 1)
+    t[JT_REACHGOAL] = g[0]; t[JT_REACHGOAL + 1] = g[1]; t[JT_REACHGOAL + 2] = g[2];
+    // np.array([alpha, beta, gamma], dtype=np.float16) (:206): the orientation is stored with 11 bits of mantissa
+    t[JT_REACHGOAL + 3] = __half2float(__float2half_rn(alpha)); t[JT_REACHGOAL + 4] = __half2float(__float2half_rn(beta)); t[JT_REACHGOAL + 5] = __half2float(__float2half_rn(gamma));
+  }
   if (R.has_free) {   // __sample_goal (:215-219), set_dest_xyz (mujoco.py:229-237), set_obj_xyz with the zero quaternion (:119-121)
     float ox = U(-0.1f, 0.1f), oy = 0.65f + U(-0.08f, 0.02f), dx = 0.4f + U(-0.05f, 0.05f), dy = 0.3f + U(-0.05f, 0.05f);
     q[9] = ox; q[10] = oy; q[11] = 0.1898f; q[12] = 1.f; q[13] = 0.f; q[14] = 0.f; q[15] = 0.f;
@@ -502,7 +527,7 @@ extern "C" int jaco_forward(JacoHandle* h, float* obs_dev, void* stream) {
 extern "C" int jaco_placing_hold(JacoHandle* h, const uint8_t* mask_dev, int nsub, void* stream) {
   if (!h || nsub <= 0) return JACO_EINVAL;
   if (h->model_host.eeobj_body < 0 || h->model_host.nq < 23) { h->err = "jaco_placing_hold: the model has no EE_obj frame / object body"; return JACO_EINVAL; }
-  EnvIO hold; hold.mode = 3; hold.mask = mask_dev;
+  EnvIO hold; hold.mode = 3; hold.mask = mask_dev; hold.listed = h->reset_listed;
   return launch_step(h, nullptr, nsub, (hipStream_t)stream, nullptr, -1, hold);
 }
 extern "C" int jaco_reset(JacoHandle* h, const uint8_t* mask_dev, float* obs_dev, void* stream) {
@@ -511,15 +536,18 @@ extern "C" int jaco_reset(JacoHandle* h, const uint8_t* mask_dev, float* obs_dev
   hipStream_t st = (hipStream_t)stream;
   const JacoModelDev& m = h->model_host;
   const float* rest = (const float*)((const char*)h->model_dev + offsetof(JacoModelDev, marker_rest));
-  JacoResetArgs R{h->qpos0_dev, h->qpos, h->qvel, h->qacc_ws, h->task_rows, mask_dev, h->marker, rest, h->num_envs, m.nq, m.nv, h->task, m.nq >= 23, h->seed};
+  JacoResetArgs R{h->qpos0_dev, h->qpos, h->qvel, h->qacc_ws, h->task_rows, mask_dev, h->marker, rest, h->num_envs, m.nq, m.nv, h->task, m.nq >= 23, h->seed, {m.base_pos[0], m.base_pos[1], m.base_pos[2]}, h->order, h->order_ctl + 67};
+  if (mask_dev) HIPCHK(h, hipMemsetAsync(h->order_ctl + 67, 0, sizeof(unsigned), st));
+  h->reset_listed = mask_dev != nullptr;
   hipLaunchKernelGGL(jaco_reset_kernel, dim3((unsigned)((h->num_envs + 255) / 256)), dim3(256), 0, st, R);
   HIPCHK(h, hipGetLastError());
   if (h->task == JACO_TASK_PLACING) {   // object into the hand, 150 held substeps while the fingers close (env_mujoco_util.py:106-117)
     int rc = jaco_placing_hold(h, mask_dev, JACO_PLACING_HOLD_SUBSTEPS, stream);
-    if (rc) return rc;
+    if (rc) { h->reset_listed = false; return rc; }
   }
   // sim.forward() + _get_observation for the reset envs (the others keep their observation row and controller cache)
-  EnvIO io; io.mode = 2; io.obs = obs_dev; io.mask = mask_dev;
+  EnvIO io; io.mode = 2; io.obs = obs_dev; io.mask = mask_dev; io.listed = h->reset_listed;
+  h->reset_listed = false;
   return launch_step(h, nullptr, 1, st, nullptr, -1, io);
 }
 extern "C" int jaco_step(JacoHandle* h, const float* action_dev, float* obs_dev, float* reward_dev, uint8_t* done_dev, void* stream) {
@@ -540,6 +568,11 @@ extern "C" int jaco_terminal_inspection(JacoHandle* h, uint8_t* done_dev, float*
 extern "C" int jaco_set_noise(JacoHandle* h, const float* noise_dev) {
   if (!h) return JACO_EINVAL;
   h->noise = noise_dev;
+  return JACO_OK;
+}
+extern "C" int jaco_set_subgoal(JacoHandle* h, const float* subgoal_dev) {
+  if (!h) return JACO_EINVAL;
+  h->subgoal = subgoal_dev;
   return JACO_OK;
 }
 extern "C" int jaco_get_task_state(JacoHandle* h, float* out_dev, void* stream) {
@@ -620,6 +653,7 @@ extern "C" int jaco_set_option(JacoHandle* h, const char* name, double v) {
   if (!strcmp(name, "tier_return")) { h->tier_return = v != 0; return JACO_OK; }
   if (!strcmp(name, "heavy_workers")) { h->workers = v < 1 ? 1 : (int)v; return JACO_OK; }
   if (!strcmp(name, "hints")) { h->use_hints = v != 0; return JACO_OK; }
+  if (!strcmp(name, "obs_mode")) { if (v != 0 && v != 1) { h->err = "jaco_set_option: obs_mode must be 0 or 1"; return JACO_EINVAL; } h->obs_mode = (int)v; return JACO_OK; }
   else if (!strcmp(name, "iterations")) m.iterations = (int)v;
   else if (!strcmp(name, "tolerance")) m.tolerance = (float)v;
   else if (!strcmp(name, "ls_iterations")) m.ls_iterations = (int)v;

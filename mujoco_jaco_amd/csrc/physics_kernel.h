@@ -47,6 +47,7 @@ typedef JacoCaps<512, 128, 256> JacoHuge;    // 8 rows per lane: a reset that pu
 #define JFLAG_TIER_RETURN 128u  // informational: the heavy tier handed the env back to the light code in mid-step
 
 #define JMINVAL 1e-15f
+#define JTASK_FLOATS 40   // per-env task row (layout: JT_* in env_logic.h)
 
 // Diagnostic build only (-DJACO_PROFILE_STAGES): lane 0 accumulates shader-clock cycles per stage into
 // JacoStepArgs::prof[env][JPROF_N]. The shipped library is built without it (no stamp executes).
@@ -105,11 +106,14 @@ struct JacoStepArgs {
   float* cache;              // [nenv][JCACHE_N]
   const float* action;       // [nenv][nact]
   const float* noise;        // optional [nenv][12] sub-goal noise draws (6 for the marker, 6 for the observation), else RNG
+  int obs_mode;              // 0: rule-based sub-goal in obs[17:23] (what main.py selects), 1: the reaching goal (rulebased_subgoal = False, env_mujoco_util.py:255-270)
+  const float* subgoal;      // obs_mode 1, optional [nenv][6]: the policy's sub-goal offset; "subgoal_reach" marker = it + the previous target (:609)
   float* obs;                // [nenv][26]
   float* reward;             // [nenv]
   unsigned char* done;       // [nenv]
   unsigned* cost;            // [nenv] shader-clock ticks (>> 4) the env's last step took (launch-order heuristic), or nullptr
   const int* order;          // light tier, optional: workgroup -> env permutation (expensive envs first), else identity
+  const int* nslots;         // light tier, optional: [1] number of valid entries of `order` (masked resets launch a small grid over the list of reset envs), else nenv
   unsigned long long* prof;  // diagnostic build only: [nenv][JPROF_N] cycle sums, else nullptr
   float* dbg;          // optional stage dump of env dbg_env (see JDBG_* offsets), else nullptr
   int dbg_env;
@@ -158,7 +162,7 @@ struct JacoLDS {
   int e_con[C::MAXEFC];                         // contact | edge << 8 | block bits << 16
   float e_x[C::MAXEFC > 64 ? C::MAXEFC : 1];    // heavy tier only: residuals staged for the MFMA pass (light reuses `smooth`)
   int ncon, nefc, ncand, nlimit;
-  float task[32];
+  float task[JTASK_FLOATS];                    // (= JTASK_N of env_logic.h)
   float osc_qd[4];                              // target orientation quaternion of the current env step (constant over its substeps)
   // per-launch copy of the small, hot model tables (per-lane gathers from LDS instead of dependent global loads)
   struct {
@@ -1033,6 +1037,9 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
     sub0 = wave_uniform_i((int)s.task[JT_SUB]);
     if (sub0 == 0) {
       // _take_action: the marker placement consumes 6 draws (a8), then the EE target and the gripper ramp
+      // the previous target (subgoal_reach = policy sub-goal + self.target_pos, :609, reads it before the new one is set)
+      float prev_tg[6];
+      for (int k = 0; k < 6; k++) prev_tg[k] = s.task[JT_TARGET + k];
       take_action(m, s, A.action + (size_t)env * A.nact, A.nact, lane);
       const unsigned cnt0 = __float_as_uint(s.task[JT_RNG]);
       wave_sync();
@@ -1043,9 +1050,14 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
         ee_frame(m, s, &pe, &Re);
         const int ob = m->obj_body >= 0 ? m->obj_body : 0;
         rulebased_subgoal(A.task_id, pe, ld3(s.task + JT_OBJGOAL), s.xpos[ob][1], ld3(s.task + JT_DESTGOAL), nz, spos, sori);
+        bool move_sub = true;
+        if (A.obs_mode == 1) {   // no rule-based sub-goal: the marker follows the policy's sub-goal, if the caller passes one
+          move_sub = A.subgoal != nullptr;
+          if (move_sub) for (int k = 0; k < 3; k++) { spos[k] = A.subgoal[(size_t)env * 6 + k] + prev_tg[k]; sori[k] = A.subgoal[(size_t)env * 6 + 3 + k] + prev_tg[3 + k]; }
+        }
         // every lane whose geom rides on a marker stores that marker's pose itself (it is also the lane that reads it back)
         const int km = lane < m->ngeom ? m->g_marker[lane] : -1;
-        if (km >= 0) {
+        if (km >= 0 && (km == 0 || move_sub)) {
           const float* tg = s.task + JT_TARGET;
           v3 mp = km == 0 ? ld3(tg) : mk3(spos[0], spos[1], spos[2]);
           m3 MR = euler_rxyz_to_mat(km == 0 ? tg[3] : sori[0], km == 0 ? tg[4] : sori[1], km == 0 ? tg[5] : sori[2]);
@@ -1057,7 +1069,7 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
           for (int k = 0; k < 9; k++) st_wt(P + 3 + k, MR.m[k]);
         }
       }
-      if (lane == 0) s.task[JT_RNG] = __uint_as_float(cnt0 + 6u);
+      if (lane == 0 && A.obs_mode == 0) s.task[JT_RNG] = __uint_as_float(cnt0 + 6u);
       wave_sync();
     }
     osc_target_quat(s, lane);
@@ -1308,9 +1320,9 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
       bool done = false;
       const float PI = 3.14159265358979323846f;
       if (emode == 1 || emode == 5) {
-        rew = (A.task_id == 0 && emode == 1) ? reward_picking(pe, eul, obj, touch) : 0.f;
+        if (emode == 1) rew = A.task_id == 0 ? reward_picking(pe, eul, obj, touch) : (A.task_id == 2 ? reward_reaching(pe, eul, s.task + JT_REACHGOAL, ld3(m->base_pos)) : 0.f);
         float trow[4] = {0.f, s.task[JT_STEPS], s.task[JT_EPISODES], 0.f};
-        done = terminal_inspection(A.task_id, trow, s.qpos[2], pe, ld3(m->base_pos), obj, destgoal, touch, &bonus, &succ, &wb);
+        done = terminal_inspection(A.task_id, trow, s.qpos[2], pe, ld3(m->base_pos), obj, destgoal, touch, &bonus, &succ, &wb, eul, s.task + JT_REACHGOAL);
         // quarantine (failure row): a state that went non-finite ends the episode with no reward and stays
         // frozen until it is reset -- what MuJoCo's own bad-state check does with mj_resetData, made visible to the learner
         const bool bad = wave_ballot((flags & JFLAG_NAN) != 0u || !(rew == rew)) != 0ull;
@@ -1323,7 +1335,7 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
           A.done[env] = done ? 1 : 0;
         }
       }
-      if (lane == 0 && emode != 5) s.task[JT_RNG] = __uint_as_float(cnt + 6u);
+      if (lane == 0 && emode != 5 && A.obs_mode == 0) s.task[JT_RNG] = __uint_as_float(cnt + 6u);
       if (lane < 26 && emode != 5) {
         float o;
         if (lane == 0) o = (float)touch;
@@ -1333,8 +1345,8 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
         else if (lane < 11) o = lane == 8 ? obj.x : (lane == 9 ? obj.y : obj.z);
         else if (lane < 14) o = 0.f;
         else if (lane < 17) o = s.task[JT_DESTGOAL + lane - 14];
-        else if (lane < 20) o = spos[lane - 17];
-        else if (lane < 23) o = sori[lane - 20] / PI;
+        else if (lane < 20) o = A.obs_mode == 1 ? s.task[JT_REACHGOAL + lane - 17] : spos[lane - 17];
+        else if (lane < 23) o = (A.obs_mode == 1 ? s.task[JT_REACHGOAL + lane - 17] : sori[lane - 20]) / PI;
         else o = lane == 24 ? PI / 2.f : 0.f;
         if (!(fabsf(o) <= 3.0e38f)) o = 0.f;   // (quarantined env: the observation row stays finite)
         A.obs[(size_t)env * 26 + lane] = o;
@@ -1363,7 +1375,9 @@ __global__ __launch_bounds__(64, 2) void jaco_physics_kernel(JacoStepArgs A) {
   __shared__ JacoLDS<JacoLight> s;
   const int lane = lane_id();
   if (env_id() >= A.nenv) return;
-  const int env = A.order ? A.order[env_id()] : env_id();
+  const int nslots = A.nslots ? *A.nslots : A.nenv;
+  for (int slot = env_id(); slot < nslots; slot += grid_size()) {   // (one pass, except for the small grid of a masked reset)
+  const int env = A.order ? A.order[slot] : slot;
   // (envs whose previous step ended in a bigger tier were queued there before the launch: not this grid's, and not counted in light_left)
   if (A.routed_mark && A.routed_mark[env] == A.launch_id) return;
   const bool masked_out = (A.env_mode == 2 || A.env_mode == 3) && A.mask && !A.mask[env];
@@ -1377,6 +1391,8 @@ __global__ __launch_bounds__(64, 2) void jaco_physics_kernel(JacoStepArgs A) {
     // hand-off: the env's state went to memory with write-through stores (run_env); once they are acknowledged the env
     // is appended to the medium tier's queue.  Its workgroups run concurrently (jaco_env.hip) and poll the queue.
     if (left > 0) queue_push(A, 0, env, left, lane);
+  }
+  wave_sync();
   }
   if (lane == 0 && A.light_left) jaco_atomic_dec(A.light_left, false);
 }

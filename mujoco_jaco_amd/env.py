@@ -17,7 +17,9 @@ import torch
 from . import _lib
 from .physics import BatchedMujoco, JacoError
 
-TASK_IDS = {"picking": 0, "placing": 1}   # the tasks that run end to end in the reference
+# picking / placing run end to end in the reference; reaching's termination returns a 3-tuple there that env_mujoco.py:125 cannot
+# unpack (env_mujoco_util.py:504-520): built here with the missing success flag added
+TASK_IDS = {"picking": 0, "placing": 1, "reaching": 2}
 
 
 class Box:
@@ -39,13 +41,15 @@ class JacoBatchedEnv:
     def __init__(self, num_envs=1, device=0, frame_skip=50, seed=0, **kwargs):
         self.task = kwargs.get("task", "picking")
         if self.task not in TASK_IDS:
-            # the reference's other task branches (reaching, grasping, ...) return 3-tuples from _get_terminal_inspection
-            # (env_mujoco_util.py:504-536,585-600) that env_mujoco.py:125 cannot unpack: they cannot run there either
-            raise NotImplementedError("task %r: only the reference's live tasks picking / placing are supported" % self.task)
-        # observation / marker branch: the rule-based sub-goal (env_mujoco_util.py:240-254,607-609) is the one main.py:44-45,
-        # 183-184,223-224 always selects and the only one built here
-        if kwargs.get("subgoal_obs", False) or kwargs.get("rulebased_subgoal", True) is False:
-            raise NotImplementedError("only subgoal_obs=False, rulebased_subgoal=True (what the reference's main.py sets) is supported")
+            # the reference's remaining task branches (grasping, carrying, pickAndplace, ...) return 3-tuples from
+            # _get_terminal_inspection (env_mujoco_util.py:521-536,585-600) that env_mujoco.py:125 cannot unpack
+            raise NotImplementedError("task %r: supported tasks are %s" % (self.task, sorted(TASK_IDS)))
+        # observation / marker branch: the rule-based sub-goal (env_mujoco_util.py:240-254,607-609) is what main.py:44-45,183-184,
+        # 223-224 always selects (the default here); rulebased_subgoal=False puts the reaching goal into obs[17:23] (:255-270).
+        # subgoal_obs=True builds a 23-vector in the reference (:226-239) and fails its own shape assert (env_mujoco.py:154-157).
+        if kwargs.get("subgoal_obs", False):
+            raise NotImplementedError("subgoal_obs=True: the reference's own observation assert (23 != 26 entries) rejects this branch")
+        self.rulebased_subgoal = bool(kwargs.get("rulebased_subgoal", True))
         self.n_robots = kwargs.get("n_robots", 1)
         if self.n_robots != 1:
             raise NotImplementedError("n_robots != 1")
@@ -54,6 +58,9 @@ class JacoBatchedEnv:
         self.sim = BatchedMujoco(self.num_envs, robot_file=robot_file, device=device, frame_skip=frame_skip,
                                  task=TASK_IDS[self.task], seed=int(seed))
         self.L, self.h, self.device = self.sim.L, self.sim.h, self.sim.device
+        if not self.rulebased_subgoal:
+            self.sim.set_option("obs_mode", 1)
+        self._subgoal = None
         # ---- RL setup (env_mujoco.py:15-93)
         self.current_steps = 0
         self.max_steps = 2500
@@ -152,8 +159,23 @@ class JacoBatchedEnv:
             return bool(done[0].item()), float(bonus[0].item()), float(wb[0].item()), int(succ[0].item())
         return done, bonus, wb, succ
 
+    def _set_subgoal(self, subgoal):
+        """rulebased_subgoal=False: `subgoal` is what the reference's step() gets from HPC.predict_subgoal -- a dict with the
+        reaching primitive's 6 offsets under 'level1_reaching/level0' (env_mujoco_util.py:609) -- or a [num_envs, 6] tensor."""
+        if subgoal is None or self.rulebased_subgoal:
+            if self._subgoal is not None:
+                self._subgoal = None
+                self.sim._chk(self.L.jaco_set_subgoal(self.h, None))
+            return
+        if isinstance(subgoal, dict):
+            subgoal = subgoal["level1_reaching/level0"]
+        sg = torch.as_tensor(subgoal, dtype=torch.float32, device=self.device).reshape(self.num_envs, -1)[:, :6].contiguous()
+        self._subgoal = sg
+        self.sim._chk(self.L.jaco_set_subgoal(self.h, self._p(sg)))
+
     def step(self, action, weight=None, subgoal=None, id=None):
         a = self._action(action)
+        self._set_subgoal(subgoal)
         self.sim._chk(self.L.jaco_step(self.h, self._p(a), self._p(self._obs), self._p(self._rew), self._p(self._done), self.sim._stream()))
         self.current_steps += 1
         obs, rew, done = self._out(self._obs, self._rew, self._done)

@@ -77,13 +77,53 @@ def reward_picking(ee_pos, ee_quat, obj_pos, touch):
     return r * 0.01
 
 
-def terminal(task, q2, ee_pos, obj_pos, dest_goal, touch, num_episodes, base_pos):
+def canon_euler(e):
+    """euler -> unit quaternion -> euler, as the reaching reward / termination do before differencing (env_mujoco_util.py:323-330)."""
+    return euler_from_quat(quat_from_euler(*e))
+
+
+def reach_ang_diff(ee_quat, goal_euler):
+    d = np.linalg.norm(canon_euler(euler_from_quat(ee_quat)) - canon_euler(goal_euler))
+    return 2 * np.pi - d if d > np.pi else d
+
+
+def reward_reaching(ee_pos, ee_quat, reach_goal, base_pos):
+    """_get_reward, task 'reaching' (env_mujoco_util.py:314-351)."""
+    dist = np.linalg.norm(np.asarray(ee_pos) - reach_goal[:3])
+    ang = reach_ang_diff(ee_quat, reach_goal[3:6])
+    r = 5 * np.exp(-dist) / 2 + 2 * np.exp(-ang / (np.pi / 6)) / (2 * (dist * 15 + 1))
+    wb = np.linalg.norm(np.asarray(ee_pos) - base_pos)
+    if wb < 0.15:
+        r -= 0.15 - wb
+    if ee_pos[2] < 0.1:
+        r -= 0.1 - ee_pos[2]
+    return 0.05 * r
+
+
+def sample_reach_goal(u01, base_pos):
+    """__sample_goal, reaching part (env_mujoco_util.py:199-207). u01: the draws in the reference's order --
+    uniform(0.3, 0.42), choice([-1, 1]) for x, the same for y, uniform(0.3, 0.5) for z, uniform(-0.1, 0.1) for gamma -- given
+    as the values the reference's calls returned."""
+    mx, sx, my, sy, z, gamma = u01
+    pos = np.array([mx * sx, my * sy, z])
+    xyz = pos - base_pos
+    x, y, z_ = xyz / np.linalg.norm(xyz)
+    alpha = -np.arcsin(y / np.sqrt(y ** 2 + z_ ** 2)) * np.sign(x)
+    beta = np.arccos(x / np.linalg.norm([x, y, z_])) * np.sign(x)
+    return np.hstack([pos, np.array([alpha, beta, gamma], dtype=np.float16)])
+
+
+def terminal(task, q2, ee_pos, obj_pos, dest_goal, touch, num_episodes, base_pos, ee_quat=None, reach_goal=None):
     """_get_terminal_inspection for the two live tasks (env_mujoco_util.py:492-502,537-548,567-582).
     `num_episodes` is the counter value *before* the call (the function increments it first)."""
     n = num_episodes + 1
     wb = np.linalg.norm(np.asarray(ee_pos) - base_pos)
     if np.pi - 0.1 < q2 < np.pi + 0.1:
         return True, -1.0, wb, 0
+    if task == "reaching":   # :504-520 (a 3-tuple in the reference: success flag added)
+        if np.linalg.norm(np.asarray(ee_pos) - reach_goal[:3]) < 0.025 and reach_ang_diff(ee_quat, reach_goal[3:6]) < np.pi / 6:
+            return True, 200 - n * 0.1, wb, 1
+        return False, 0.0, wb, 0
     if task == "picking":
         if obj_pos[2] > OBJECT_Z + 0.07 and touch in (1, 3):
             return True, 200 - n * 0.1, wb, 1
@@ -100,11 +140,11 @@ def terminal(task, q2, ee_pos, obj_pos, dest_goal, touch, num_episodes, base_pos
     return False, 0.0, wb, 0
 
 
-def env_terminal(task, current_steps, *args):
+def env_terminal(task, current_steps, *args, **kw):
     """JacoMujocoEnv.terminal_inspection (env_mujoco.py:144-150): current_steps is the value *before* the call."""
     task_max = 700 if task in ("picking", "placing") else 500
     if current_steps + 1 < task_max:
-        return terminal(task, *args)
+        return terminal(task, *args, **kw)
     return True, -10.0, 0.0, 0
 
 
@@ -128,9 +168,13 @@ def rulebased_subgoal(task, ee_pos, obj_goal, obj_y, dest_goal, noise6):
     return pos, ori
 
 
-def observation(task, touch, ee_pos, ee_quat, grip, obj_pos, dest_goal, obj_goal, noise6):
-    """_get_observation, rule-based-subgoal branch (env_mujoco_util.py:240-254,271) -> float32[26]."""
-    pos, ori = rulebased_subgoal(task, ee_pos, obj_goal, obj_pos[1], dest_goal, noise6)
+def observation(task, touch, ee_pos, ee_quat, grip, obj_pos, dest_goal, obj_goal, noise6, reach_goal=None):
+    """_get_observation -> float32[26]: rule-based-subgoal branch (env_mujoco_util.py:240-254,271), or -- reach_goal given --
+    the rulebased_subgoal = False branch with the reaching goal in [17:23] (:255-270)."""
+    if reach_goal is not None:
+        pos, ori = np.asarray(reach_goal[:3], np.float64), np.asarray(reach_goal[3:6], np.float64)
+    else:
+        pos, ori = rulebased_subgoal(task, ee_pos, obj_goal, obj_pos[1], dest_goal, noise6)
     o = np.hstack([[touch], ee_pos, euler_from_quat(ee_quat) / np.pi, [(grip - 0.8) / 0.2], obj_pos, [0, 0, 0], dest_goal, pos, ori / np.pi,
                    [0, np.pi / 2, 0]])
     return o.astype(np.float32)

@@ -22,14 +22,17 @@ static std::vector<float> g_hull;
 static int g_no_tier_return_fwd();
 static std::vector<int> g_hint;
 static int g_use_hints = 0;
+static int g_obs_mode = 0;
+extern "C" void emu_set_obs_mode(int v) { g_obs_mode = v; }
 extern "C" void emu_set_hints(int on) { g_use_hints = on; }
 static int emu_launch(JacoStepArgs A, int* heavy_envs) {
   A.no_tier_return = g_no_tier_return_fwd();
+  A.obs_mode = g_obs_mode;
   std::vector<int> remaining(A.nenv, 0), lists(3 * (size_t)A.nenv, -1);
   int count[3] = {0, 0, 0}, taken[3] = {0, 0, 0}, light_left = A.nenv;
   A.remaining = remaining.data(); A.light_left = &light_left;
   for (int t = 0; t < 3; t++) { A.q[t].list = lists.data() + (size_t)t * A.nenv; A.q[t].count = &count[t]; A.q[t].taken = &taken[t]; A.q[t].limit = nullptr; A.q[t].reserve = nullptr; }
-  A.routed_mark = nullptr; A.launch_id = 1;
+  A.routed_mark = nullptr; A.launch_id = 1; A.nslots = nullptr;
   if ((int)g_hint.size() != A.nenv) g_hint.assign(A.nenv, 0);
   A.hint = g_use_hints ? g_hint.data() : nullptr;
   emu_grid = A.nenv;

@@ -31,6 +31,8 @@ class OracleEnv:
         self.mk_hand, self.mk_sub = _mocap_id(names, "hand"), _mocap_id(names, "subgoal_reach")
         self.grip, self.steps, self.episodes = 0.6, 0, 0
         self.obj_goal, self.dest_goal = np.zeros(3), np.zeros(3)
+        self.reach_goal = np.zeros(6)          # task 'reaching' / the rulebased_subgoal = False observation branch
+        self.rulebased = True
 
     def set_state(self, qpos, qvel=None, qacc_ws=None):
         o = self.o
@@ -47,7 +49,8 @@ class OracleEnv:
         pe, qe = self._ee()
         obj = o.get("xpos").reshape(-1, 3)[self.obj]
         touch = glue.touch_class(o.get("sensordata"))
-        return glue.observation(self.task, touch, pe, qe, self.grip, obj, self.dest_goal, self.obj_goal, noise6), touch, pe, qe, obj
+        return glue.observation(self.task, touch, pe, qe, self.grip, obj, self.dest_goal, self.obj_goal, noise6,
+                                reach_goal=None if self.rulebased else self.reach_goal), touch, pe, qe, obj
 
     def step(self, action, noise12):
         o = self.o
@@ -58,7 +61,8 @@ class OracleEnv:
         target, grip, ramp = glue.take_action(pe, qe, action, self.grip, self.frame_skip)
         self.grip = grip
         mp, mq = o.get("mocap_pos").reshape(-1, 3).copy(), o.get("mocap_quat").reshape(-1, 4).copy()
-        mp[self.mk_sub], mq[self.mk_sub] = spos, glue.quat_from_euler(*sori)
+        if self.rulebased:
+            mp[self.mk_sub], mq[self.mk_sub] = spos, glue.quat_from_euler(*sori)
         mp[self.mk_hand], mq[self.mk_hand] = target[:3], glue.quat_from_euler(*target[3:6])
         o.set("mocap_pos", mp.reshape(-1)); o.set("mocap_quat", mq.reshape(-1))
         for k in range(self.frame_skip):
@@ -71,10 +75,12 @@ class OracleEnv:
             u = glue.osc_generate(q_dq, target, J, M, bias, pe, qe)
             o.step(np.concatenate([u, [ramp[k]] * 3]))
         obs, touch, pe, qe, obj = self.observe(noise12[6:12])
-        rew = glue.reward_picking(pe, qe, obj, touch) if self.task == "picking" else 0.0
-        done, bonus, wb, succ = glue.env_terminal(self.task, self.steps, o.get("qpos")[2], pe, obj, self.dest_goal, touch, self.episodes, self.base)
+        rew = glue.reward_picking(pe, qe, obj, touch) if self.task == "picking" else (
+            glue.reward_reaching(pe, qe, self.reach_goal, self.base) if self.task == "reaching" else 0.0)
+        done, bonus, wb, succ = glue.env_terminal(self.task, self.steps, o.get("qpos")[2], pe, obj, self.dest_goal, touch, self.episodes, self.base,
+                                                  ee_quat=qe, reach_goal=self.reach_goal)
         self.steps += 1
-        if self.steps < 700:
+        if self.steps < (700 if self.task in ("picking", "placing") else 500):
             self.episodes += 1
         return obs, rew + bonus, done, succ
 

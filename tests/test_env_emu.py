@@ -137,3 +137,42 @@ def test_tier_alternation(names, model_arrays):
     assert np.abs(out[1][0] - out[0][0]).max() < 1e-5
     oo, orew, odone, _ = oe.step(a.astype(np.float64), nz[0].astype(np.float64))
     assert out[1][2] == odone and out[1][0][0] == oo[0] and np.abs(out[1][0] - oo).max() < 3e-3
+
+
+def test_reaching_task_matches_oracle_env(names, model_arrays):
+    """Task 'reaching' (env_mujoco_util.py:192-207, 314-351, 504-520): 6-wide action (gripper held at 0.6), reaching reward,
+    reaching termination with the success flag, time-out at 500 steps, and the rulebased_subgoal = False observation
+    (reaching goal in obs[17:23]); glue pinned by tests/golden/glue_vectors_reaching.npz."""
+    import glue
+    fs = 8
+    e = EmuJacoEnv(frame_skip=fs, task_id=2); e.obs_mode = 1
+    oe = OracleEnv(names, task="reaching", frame_skip=fs); oe.rulebased = False
+    q = workload.reset_states(model_arrays["qpos0"], 1, seed=9)[0]
+    oe.obj_goal = q[9:12].copy(); oe.dest_goal = np.array([q[16], q[17], 0.3468])
+    oe.set_state(q.astype(np.float32).astype(np.float64))
+    pe, qe = oe._ee()
+    # a goal 1.5 cm from the EE with a slightly rotated orientation: reached within a few steps
+    goal = np.concatenate([pe + [0.012, -0.006, 0.005], glue.euler_from_quat(qe) + [0.05, -0.04, 0.03]]).astype(np.float32).astype(np.float64)
+    oe.reach_goal = goal
+    e.qpos[0] = q; e.task[0, 4:7] = oe.obj_goal; e.task[0, 7:10] = oe.dest_goal; e.task[0, 32:38] = goal
+    obs0 = e.forward()
+    assert np.abs(obs0[0] - oe.observe(None)[0]).max() < 2e-6 and np.allclose(obs0[0, 17:20], goal[:3], atol=1e-7)
+    rng = np.random.default_rng(9)
+    reached = False
+    for step in range(5):
+        a = np.concatenate([(goal[:3] - oe._ee()[0]) * 25 * 0.8, rng.uniform(-0.05, 0.05, 3)]).clip(-1, 1).astype(np.float32)
+        obs, rew, done = e.env_step(a)
+        oo, orew, odone, osucc = oe.step(a.astype(np.float64), np.full(12, 0.5))
+        assert bool(done[0]) == odone and np.abs(obs[0] - oo).max() < 5e-5 and abs(rew[0] - orew) < 2e-3
+        assert abs(e.task[0, 0] - 0.6) < 1e-7                                # 6-wide action: gripper command stays 0.6
+        if odone:
+            reached = True
+            assert orew > 100 and e.task[0, 29] == 1.0 == float(osucc)      # success flag (the reference's 3-tuple lacks it)
+            break
+    assert reached
+    # time-out of a non-picking task: 500 steps (env_mujoco.py:20-21)
+    e2 = EmuJacoEnv(frame_skip=1, task_id=2); e2.obs_mode = 1
+    e2.qpos[0] = q; e2.task[0, 32:38] = goal + 1.0; e2.forward(); e2.task[0, 1] = 498
+    z = np.zeros(6, np.float32)
+    _, _, d = e2.env_step(z); assert d[0] == 0
+    _, r, d = e2.env_step(z); assert d[0] == 1 and abs(r[0] - (-10.0)) < 0.2

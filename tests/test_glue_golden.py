@@ -76,3 +76,36 @@ def test_take_action():
         # the marker placement consumes the 6 draws of the first _get_rulebased_subgoal call of the step
         pos, ori = glue.rulebased_subgoal("picking", G["s_ee"][k], G["s_obj_goal"][k], G["s_obj"][k][1], G["s_dest_goal"][k], G["s_noise_act"][k])
         assert np.allclose(pos, G["s_mocap_sub_pos"][k], atol=1e-12)
+
+
+# ---- task 'reaching' (tests/golden/make_glue_vectors_reaching.py ran the reference's own branches)
+R = np.load(os.path.join(ROOT, "tests", "golden", "glue_vectors_reaching.npz"))
+
+
+def test_reaching_reward_and_terminal():
+    seen = set()
+    for k in range(len(R["r_ee"])):
+        r = glue.reward_reaching(R["r_ee"][k], R["r_eeq"][k], R["r_goal"][k], BASE)
+        assert abs(r - R["r_reward"][k]) < 1e-12
+        done, bonus, wb, succ = glue.terminal("reaching", R["r_q2"][k], R["r_ee"][k], R["r_obj"][k], R["r_dest_goal"][k], 0, int(R["r_nsteps"][k]), BASE,
+                                              ee_quat=R["r_eeq"][k], reach_goal=R["r_goal"][k])
+        e = R["r_term"][k]
+        assert bool(e[0]) == done and abs(e[1] - bonus) < 1e-12 and abs(e[2] - wb) < 1e-12
+        assert succ == int(done and bonus > 100)      # the success flag the reference's 3-tuple lacks
+        seen.add((done, bonus > 0))
+    assert seen == {(False, False), (True, True), (True, False)}
+
+
+def test_reaching_goal_sampling_with_float16_cast():
+    for d, g in zip(R["g_draws"], R["g_goal"]):
+        got = glue.sample_reach_goal(d, BASE)
+        assert np.array_equal(got[3:], g[3:]) and np.allclose(got[:3], g[:3], atol=1e-15)      # orientation: float16 values, exact
+        assert np.all(got[3:] == got[3:].astype(np.float16).astype(np.float64))
+
+
+def test_reaching_goal_observation_branch():
+    for k in range(len(R["r_ee"])):
+        touch = glue.touch_class(R["r_sens"][k])
+        obs = glue.observation("reaching", touch, R["r_ee"][k], R["r_eeq"][k], R["r_grip"][k], R["r_obj"][k], R["r_dest_goal"][k], None, None,
+                               reach_goal=R["r_goal"][k])
+        assert np.allclose(obs, R["r_obs"][k], atol=2e-7)

@@ -297,3 +297,108 @@ def test_markers_follow_take_action(model_arrays):
     assert torch.equal(env.markers().cpu(), m2)
     env.reset()
     assert np.array_equal(env.markers().cpu().numpy(), rest)
+
+
+def test_reaching_task_on_gpu(model_arrays, names):
+    """Task 'reaching' end to end (env_mujoco_util.py:192-207,314-351,504-520; env_mujoco.py:79-89 action shape (6,), :20-21 500
+    steps): reset draws (goal ranges, float16 orientation), reaching-goal observation branch, env-level parity with the
+    fp64 oracle env, success flag."""
+    from mujoco_jaco_amd.env import JacoBatchedEnv
+    from oracle_env import OracleEnv
+    import glue
+    B = 2048
+    env = JacoBatchedEnv(num_envs=B, task="reaching", rulebased_subgoal=False, seed=31)
+    assert env.action_space.shape == (6,) and env.task_max_steps == 500 and env.get_num_action() == 6
+    obs = env.reset().cpu().numpy()
+    ts = env.task_state().cpu().numpy()
+    g = ts[:, 32:38].astype(np.float64)
+    assert ((np.abs(g[:, 0]) >= 0.3) & (np.abs(g[:, 0]) <= 0.42) & (np.abs(g[:, 1]) >= 0.3) & (np.abs(g[:, 1]) <= 0.42)).all()
+    assert (g[:, 2] >= 0.3).all() and (g[:, 2] <= 0.5).all() and abs((g[:, 0] > 0).mean() - 0.5) < 0.05 and abs((g[:, 1] > 0).mean() - 0.5) < 0.05
+    assert np.array_equal(g[:, 3:], g[:, 3:].astype(np.float16).astype(np.float64))        # np.float16 cast (:206)
+    assert (np.abs(g[:, 5]) <= 0.1 + 1e-3).all()
+    base = np.array([0.0, 0.0, 0.157])
+    for k in range(0, B, 97):   # orientation looks along base -> goal (:201-205), checked through the pinned glue formula
+        ref = glue.sample_reach_goal([abs(g[k, 0]), np.sign(g[k, 0]), abs(g[k, 1]), np.sign(g[k, 1]), g[k, 2], g[k, 5]], base)
+        assert np.abs(ref[3:5] - g[k, 3:5]).max() <= 2e-3                                    # (fp32 vs fp64 before the float16 rounding)
+    assert np.allclose(obs[:, 17:20], g[:, :3], atol=1e-6) and np.allclose(obs[:, 20:23], g[:, 3:] / np.pi, atol=1e-6)
+    with pytest.raises(ValueError):
+        env.step(torch.zeros(B, 7))                                                       # reaching takes 6-wide actions
+    # env-level parity on a few envs, goal placed next to the EE so that the success branch is reached
+    n = 6
+    q = env.sim.get_state()[0].cpu().numpy().astype(np.float64)
+    oes = []
+    for k in range(n):
+        oe = OracleEnv(names, task="reaching"); oe.rulebased = False
+        oe.obj_goal = ts[k, 4:7].astype(np.float64); oe.dest_goal = ts[k, 7:10].astype(np.float64)
+        oe.set_state(q[k])
+        pe, qe = oe._ee()
+        goal = np.concatenate([pe + [0.012, -0.006, 0.005], glue.euler_from_quat(qe) + [0.05, -0.04, 0.03]]).astype(np.float32).astype(np.float64)
+        oe.reach_goal = goal; ts[k, 32:38] = goal
+        oes.append(oe)
+    env.set_task_state(torch.tensor(ts))
+    succ_seen = 0
+    for step in range(5):
+        a = np.zeros((B, 6), np.float32)
+        for k in range(n):
+            a[k, :3] = ((oes[k].reach_goal[:3] - oes[k]._ee()[0]) * 25 * 0.8).clip(-1, 1)
+        obs, rew, done, _ = env.step(torch.tensor(a))
+        obs, rew, done = obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()
+        for k in range(n):
+            if oes[k].steps < 0:
+                continue
+            oo, orew, odone, osucc = oes[k].step(a[k].astype(np.float64), np.full(12, 0.5))
+            assert bool(done[k]) == odone and np.abs(obs[k] - oo).max() < 1e-4 and abs(rew[k] - orew) < 2e-3
+            if odone:
+                succ_seen += int(osucc)
+                assert bool(env.successes()[k]) == bool(osucc)
+                oes[k].steps = -1      # finished: the GPU env freezes
+    assert succ_seen >= 3
+
+
+def test_full_size_env_level_config3_and_config4():
+    """BASELINE configs 3 and 4 at their full size through jaco_step: 65 536 envs, full model; frame_skip 50 (config 3) and 4 with
+    early-termination masking (config 4).  Size-independent properties: bitwise determinism, an env's result does not depend on
+    its batch neighbours, finished envs freeze (done stays 1, reward 0, state untouched), finite outputs, unit quaternions."""
+    from mujoco_jaco_amd.env import JacoBatchedEnv
+    B = 65536
+    for fs, nstep in ((50, 2), (4, 6)):
+        outs = []
+        for rep in range(2):
+            env = JacoBatchedEnv(num_envs=B, task="picking", seed=77, frame_skip=fs)
+            env.reset()
+            ts = env.task_state(); ts[::3, 1] = 699 - nstep + 2; env.set_task_state(ts)     # a third of the envs time out during the run
+            gen = torch.Generator(device=env.device); gen.manual_seed(9)
+            frozen_state = None
+            for s in range(nstep):
+                a = torch.rand(B, 7, device=env.device, generator=gen) * 2 - 1
+                obs, rew, done, _ = env.step(a)
+                if s == nstep - 2:
+                    d_prev = done.clone(); q_prev = env.sim.get_state()[0].clone()
+            q, v, _ = env.sim.get_state()
+            assert d_prev[::3].all() and not d_prev[1::3].any()
+            assert torch.equal(q[d_prev], q_prev[d_prev]) and (rew[d_prev] == 0).all() and done[d_prev].all()   # frozen until reset
+            assert torch.isfinite(obs).all() and torch.isfinite(rew).all() and torch.isfinite(q).all()
+            for adr in (12, 19):
+                assert (q[:, adr:adr + 4].norm(dim=1) - 1).abs().max() < 1e-5
+            assert int(env.sim.flags().max().item()) & 8 == 0
+            outs.append((q.clone(), v.clone(), obs.clone(), rew.clone(), done.clone()))
+            if rep == 1:   # neighbour independence: a 4 096-env slice stepped alone gives the same bits
+                sl = slice(20480, 24576)
+                small = JacoBatchedEnv(num_envs=4096, task="picking", seed=77, frame_skip=fs)
+                small.reset()
+                env2 = JacoBatchedEnv(num_envs=B, task="picking", seed=77, frame_skip=fs)
+                env2.reset()
+                q0, v0, w0 = env2.sim.get_state()
+                small.sim.set_state(q0[sl].contiguous(), v0[sl].contiguous(), w0[sl].contiguous())
+                small.set_task_state(env2.task_state()[sl].contiguous()); small.set_markers(env2.markers()[sl].contiguous())
+                small.make_observation(); env2.make_observation()
+                gen = torch.Generator(device=env.device); gen.manual_seed(9)
+                a = torch.rand(B, 7, device=env.device, generator=gen) * 2 - 1
+                nz = torch.rand(B, 12, device=env.device, generator=gen)
+                env2.set_noise(nz); small.set_noise(nz[sl].contiguous())
+                o2, r2, d2, _ = env2.step(a); os_, rs, ds, _ = small.step(a[sl].contiguous())
+                assert torch.equal(o2[sl], os_) and torch.equal(r2[sl], rs) and torch.equal(d2[sl], ds)
+                del small, env2
+            del env
+        for x, y in zip(*outs):
+            assert torch.equal(x, y)                                                         # bitwise deterministic
