@@ -133,6 +133,9 @@ JDEV void wave_sleep() { __builtin_amdgcn_s_sleep(127); }   // ~8k cycles
 // Pin three already-loaded values in VGPRs here: keeps the optimiser from sinking their loads into a (divergent) branch.
 JDEV void keep_loaded(float& a, float& b, float& c) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c)); }
 
+// Hide the origin of a per-lane value (the lane id) from the optimiser: whatever is derived from it afterwards cannot be hoisted above this point.
+JDEV int wave_opaque_i(int v) { asm volatile("" : "+v"(v)); return v; }
+
 // Hide a (wave-uniform) pointer's provenance from the optimiser: stops it from hoisting per-lane model
 // loads out of the substep loop and keeping them live (in VGPRs) across the whole loop body.
 template <class T>

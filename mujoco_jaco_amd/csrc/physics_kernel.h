@@ -1121,6 +1121,11 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
 #endif
   for (int sub = sub0; sub < nsub; sub++) {
     m = opaque_ptr(A.model);
+    // Same for the lane id: everything a lane addresses (LDS offsets, "lane < n" masks, model table slots) derives from it, and the
+    // optimiser would otherwise compute ~140 such values once, before the loop, and keep them alive across all of it -- in scratch
+    // memory (556 B of spills per lane, every use a scratch load).  Recomputing them where they are used is one or two VALU
+    // instructions each; the kernel's remaining spills (156 B) all sit inside the MPR routine.
+    lane = wave_opaque_i(lane);
     bool held_pending = false;
     if (emode == 3 && s.task[JT_PENDING] != 0.f) {   // resume of an interrupted held substep: its ctrl was saved
       if (lane < nu) s.ctrl[lane] = s.task[JT_CTRL + lane];
@@ -1373,6 +1378,11 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
 // light tier: one workgroup (= one wavefront) per env
 __global__ __launch_bounds__(64, 2) void jaco_physics_kernel(JacoStepArgs A) {
   __shared__ JacoLDS<JacoLight> s;
+#ifdef JACO_LDS_PAD   // occupancy experiment: extra LDS per workgroup (floats), touched so that it is allocated
+  __shared__ float lds_pad[JACO_LDS_PAD];
+  if (A.nenv < 0) lds_pad[threadIdx.x] = 1.f;
+  asm volatile("" :: "v"(&lds_pad[0]));
+#endif
   const int lane = lane_id();
   if (env_id() >= A.nenv) return;
   const int nslots = A.nslots ? *A.nslots : A.nenv;
