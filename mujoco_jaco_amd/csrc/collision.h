@@ -73,10 +73,10 @@ JDEV v3 support_geom(const JacoStepArgs& A, const JacoModelDev* m, const L& s, i
   GeomPose P = geom_pose(s, g);
   v3 l = mulT(P.R, dir), sp;
   if (type == JG_BOX) {
-    sp = mk3(l.x > 0.f ? s.mc.g_size[g][0] : -s.mc.g_size[g][0], l.y > 0.f ? s.mc.g_size[g][1] : -s.mc.g_size[g][1], l.z > 0.f ? s.mc.g_size[g][2] : -s.mc.g_size[g][2]);
+    sp = mk3(l.x > 0.f ? m->g_size[g][0] : -m->g_size[g][0], l.y > 0.f ? m->g_size[g][1] : -m->g_size[g][1], l.z > 0.f ? m->g_size[g][2] : -m->g_size[g][2]);
   } else if (type == JG_SPHERE) {
     float n = norm(l);
-    sp = l * (n > JMINVAL ? s.mc.g_size[g][0] / n : 0.f);
+    sp = l * (n > JMINVAL ? m->g_size[g][0] / n : 0.f);
   } else {  // hull mesh: 64-lane scan + argmax (lowest vertex index wins ties, like a serial first-max scan)
     int adr = m->g_vertadr[g], nvert = m->g_vertnum[g];
     float best = -3.0e38f;
@@ -100,7 +100,7 @@ JDEV void collide_plane_box(const JacoModelDev* m, L& s, int g1, int g2, int pai
   GeomPose P = geom_pose(s, g1), B = geom_pose(s, g2);
   v3 n = col(P.R, 2);
   int i = lane & 7;
-  v3 l = mk3((i & 1) ? s.mc.g_size[g2][0] : -s.mc.g_size[g2][0], (i & 2) ? s.mc.g_size[g2][1] : -s.mc.g_size[g2][1], (i & 4) ? s.mc.g_size[g2][2] : -s.mc.g_size[g2][2]);
+  v3 l = mk3((i & 1) ? m->g_size[g2][0] : -m->g_size[g2][0], (i & 2) ? m->g_size[g2][1] : -m->g_size[g2][1], (i & 4) ? m->g_size[g2][2] : -m->g_size[g2][2]);
   v3 c = B.p + mul(B.R, l);
   float dist = dot(c - P.p, n);
   push_contacts(s, lane < 8 && !(dist > 0.f), dist, c - n * (0.5f * dist), n, pair, ncon, flags, 4);
@@ -109,7 +109,7 @@ template <class L>
 JDEV void collide_plane_sphere(const JacoModelDev* m, L& s, int g1, int g2, int pair, int lane, int& ncon, unsigned& flags) {
   GeomPose P = geom_pose(s, g1);
   v3 n = col(P.R, 2), c = ld3(s.gpos[g2]);
-  float r = s.mc.g_size[g2][0], dist = dot(c - P.p, n) - r;
+  float r = m->g_size[g2][0], dist = dot(c - P.p, n) - r;
   push_contacts(s, lane == 0 && !(dist > 0.f), dist, c - n * (r + 0.5f * dist), n, pair, ncon, flags, 1);
 }
 template <class L>
@@ -125,7 +125,7 @@ JDEV void collide_plane_convex(const JacoStepArgs& A, const JacoModelDev* m, L& 
 template <class L>
 JDEV void collide_box_box(const JacoModelDev* m, L& s, int g1, int g2, int pair, int lane, int& ncon, unsigned& flags) {
   GeomPose P1 = geom_pose(s, g1), P2 = geom_pose(s, g2);
-  float s1[3] = {s.mc.g_size[g1][0], s.mc.g_size[g1][1], s.mc.g_size[g1][2]}, s2[3] = {s.mc.g_size[g2][0], s.mc.g_size[g2][1], s.mc.g_size[g2][2]};
+  float s1[3] = {m->g_size[g1][0], m->g_size[g1][1], m->g_size[g1][2]}, s2[3] = {m->g_size[g2][0], m->g_size[g2][1], m->g_size[g2][2]};
   v3 Aa[3] = {col(P1.R, 0), col(P1.R, 1), col(P1.R, 2)}, Ba[3] = {col(P2.R, 0), col(P2.R, 1), col(P2.R, 2)};
   v3 pp = P2.p - P1.p;
   // lane a < 6: face axis; 6 <= a < 15: edge axis A[i] x B[j]
@@ -250,7 +250,7 @@ template <class L>
 JDEV MprGeom mpr_geom(const JacoModelDev* m, const L& s, int g, int type) {
   MprGeom G;
   G.P = geom_pose(s, g);
-  G.size = ld3(s.mc.g_size[g]);
+  G.size = ld3(m->g_size[g]);
   G.type = type;
   G.adr = type == JG_MESH ? m->g_vertadr[g] : 0;
   G.nvert = type == JG_MESH ? m->g_vertnum[g] : 0;
@@ -488,8 +488,8 @@ JDEV void stage_collision(const JacoStepArgs& A, const JacoModelDev* m, L& s, in
       int code = m->pair_code[k];
       int g1 = code & 255, g2 = (code >> 8) & 255, t1 = (code >> 16) & 15, t2 = (code >> 20) & 15;
       if (t1 != JG_PLANE) {
-        v3 sa = t1 == JG_SPHERE ? mk3(s.mc.g_size[g1][0], s.mc.g_size[g1][0], s.mc.g_size[g1][0]) : ld3(s.mc.g_size[g1]);
-        v3 sb = t2 == JG_SPHERE ? mk3(s.mc.g_size[g2][0], s.mc.g_size[g2][0], s.mc.g_size[g2][0]) : ld3(s.mc.g_size[g2]);
+        v3 sa = t1 == JG_SPHERE ? mk3(m->g_size[g1][0], m->g_size[g1][0], m->g_size[g1][0]) : ld3(m->g_size[g1]);
+        v3 sb = t2 == JG_SPHERE ? mk3(m->g_size[g2][0], m->g_size[g2][0], m->g_size[g2][0]) : ld3(m->g_size[g2]);
         keep = !obb_separated(geom_pose(s, g1), sa, geom_pose(s, g2), sb);
       }
     }

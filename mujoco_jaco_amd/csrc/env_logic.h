@@ -348,7 +348,7 @@ JDEV void stage_osc(const JacoModelDev* m, L& s, int lane, unsigned& flags) {
     B[0] = jp.x; B[1] = jp.y; B[2] = jp.z; B[3] = S.a.x; B[4] = S.a.y; B[5] = S.a.z;
   }
 #pragma unroll
-  for (int j = 0; j < 6; j++) A[j] = s.M[i * JNV + j];
+  for (int j = 0; j < 6; j++) A[j] = s.M[m_index(i, j)];
   gj_inverse6(A, B, lane);
   if (lane < 6) for (int j = 0; j < 6; j++) T[lane * 6 + j] = B[j];
   wave_sync();
@@ -392,7 +392,7 @@ JDEV void stage_osc(const JacoModelDev* m, L& s, int lane, unsigned& flags) {
   wave_sync();
   if (lane < 6) {
     float u = s.bias[lane];
-    for (int k = 0; k < 6; k++) u -= JOSC_KV * s.M[lane * JNV + k] * s.qvel[k] + Jm[k * 6 + lane] * w[k];
+    for (int k = 0; k < 6; k++) u -= JOSC_KV * s.M[m_index(lane, k)] * s.qvel[k] + Jm[k * 6 + lane] * w[k];
     s.ctrl[lane] = u;
   }
   wave_sync();

@@ -136,30 +136,57 @@ struct JacoStepArgs {
 #define JDBG_SENS (JDBG_CFN + JDBG_MAXCON)         // [JNSENS] sensordata
 #define JDBG_SIZE (JDBG_SENS + JNSENS)
 
+// The mass matrix is block diagonal over the dof blocks [0,JB0) arm + fingers, [JB0,JB1) object, [JB1,JNV) pedestal (one block per
+// kinematic tree): only the blocks are stored, row-major one after the other (153 instead of 441 floats).
+#define JMBLK (JB0 * JB0 + (JB1 - JB0) * (JB1 - JB0) + (JNV - JB1) * (JNV - JB1))
+JDEV int m_index(int d, int j) {   // (d, j in the same block)
+  return d < JB0 ? d * JB0 + j : (d < JB1 ? JB0 * JB0 + (d - JB0) * (JB1 - JB0) + (j - JB0) : JB0 * JB0 + (JB1 - JB0) * (JB1 - JB0) + (d - JB1) * (JNV - JB1) + (j - JB1));
+}
+#define JSCRATCH 520   // floats of the constraint-row area that the early stages of a substep use as scratch (stage_walk, stage_mass_bias, stage_osc)
+
+// Per-env working state.  LDS is what caps the number of resident envs per CU (160 KB / sizeof), so arrays whose lifetimes inside
+// a substep do not overlap share storage:
+//   * body inertias / forces (tree walk .. mass matrix)            with   the contact list (collision .. Euler);
+//   * geom poses + broadphase survivors (tree walk .. collision)   with   the constraint rows (row builders .. Euler), behind the
+//     first JSCRATCH floats of that area, which the early stages use as scratch.
+// Light tier: 13.3 KB -> 12 envs per CU (3 waves per SIMD); it was 20.5 KB -> 8.
 template <class C>
 struct JacoLDS {
   typedef C Caps;
   float qpos[24], qvel[24], qacc_ws[24], ctrl[12];
-  float xpos[JNB][3], xmat[JNB][9], xipos[JNB][3];
+  float xpos[JNB][3], xmat[JNB][9];
   float cdof[JNV][6];
-  alignas(16) float cinert[JNB][10];            // (16-byte aligned: cinert+crb double as the frame scratch of stage K)
-  float crb[JNB][10];
-  float cvel[JNB][6], cacc[JNB][6], cfrc[JNB][6];
-  float M[JNV * JNV];
+  float cvel[JNB][6];
+  float M[JMBLK];
   float bias[24], smooth[72];                   // smooth[0..nv); the light tier also stages its <= 64 row residuals here (MFMA pass)
-  alignas(16) float gpos[JMAXGEOM][4];          // world position + bounding radius: one 16-byte LDS read per geom in the broadphase
-  float gmat[JMAXGEOM][9];
-  // contacts
-  float c_dist[C::MAXCON], c_pos[C::MAXCON][3], c_frame[C::MAXCON][9], c_fn[C::MAXCON];
-  int c_pair[C::MAXCON], c_efc[C::MAXCON];
-  unsigned c_m1[C::MAXCON], c_m2[C::MAXCON];   // dof chain masks of the two bodies
-  int c_ob[C::MAXCON];                          // per geom: original (unfused) body id | (fused body + 1) << 8; geom 2 in the upper half
-  int c_dim[C::MAXCON];
-  int cand[C::MAXCAND];
-  // constraint rows
-  alignas(16) float J[C::MAXEFC * JLD];
-  float e_aref[C::MAXEFC], e_D[C::MAXEFC], e_f[C::MAXEFC];
-  int e_con[C::MAXEFC];                         // contact | edge << 8 | block bits << 16
+  float mk[24];                                 // poses of the two task-layer markers ("hand", "subgoal_reach") during this launch
+  union {
+    struct {                                    // tree walk .. mass matrix
+      alignas(16) float cinert[JNB][10];        // (16-byte aligned: cinert+crb double as the frame scratch of stage K)
+      float crb[JNB][10];
+      float cacc[JNB][6], cfrc[JNB][6];
+    };
+    struct {                                    // collision .. Euler: contacts
+      float c_dist[C::MAXCON], c_pos[C::MAXCON][3], c_frame[C::MAXCON][9], c_fn[C::MAXCON];
+      int c_pair[C::MAXCON], c_efc[C::MAXCON];
+      unsigned c_m1[C::MAXCON], c_m2[C::MAXCON];   // dof chain masks of the two bodies
+      int c_ob[C::MAXCON];                          // per geom: original (unfused) body id | (fused body + 1) << 8; geom 2 in the upper half
+      int c_dim[C::MAXCON];
+    };
+  };
+  union {
+    struct {                                    // row builders .. Euler: constraint rows
+      alignas(16) float J[C::MAXEFC * JLD];
+      float e_aref[C::MAXEFC], e_D[C::MAXEFC], e_f[C::MAXEFC];
+      int e_con[C::MAXEFC];                     // contact | edge << 8 | block bits << 16
+    };
+    struct {                                    // tree walk .. collision: geom poses, broadphase survivors
+      float early_scratch[JSCRATCH];
+      alignas(16) float gpos[JMAXGEOM][4];      // world position + bounding radius: one 16-byte LDS read per geom in the broadphase
+      float gmat[JMAXGEOM][9];
+      int cand[C::MAXCAND];
+    };
+  };
   float e_x[C::MAXEFC > 64 ? C::MAXEFC : 1];    // heavy tier only: residuals staged for the MFMA pass (light reuses `smooth`)
   int ncon, nefc, ncand, nlimit;
   float task[JTASK_FLOATS];                    // (= JTASK_N of env_logic.h)
@@ -172,9 +199,9 @@ struct JacoLDS {
     unsigned b_descmask[JNB];
     int b_anc[JNB][3];                          // ancestors 1, 2 and 4 levels up (-1: none), for the pointer-jumping tree stages
     int d_body[JNV], d_parent[JNV];
-    float g_size[JMAXGEOM][3];
   } mc;
 };
+static_assert(JB1 - JB0 == 6 && JNV - JB1 == 6, "dof blocks");
 
 template <class L>
 JDEV void stage_model(const JacoModelDev* m, L& s, int lane) {
@@ -190,11 +217,6 @@ JDEV void stage_model(const JacoModelDev* m, L& s, int lane) {
     s.mc.b_anc[b][0] = p1; s.mc.b_anc[b][1] = p2; s.mc.b_anc[b][2] = p4;
   }
   if (lane < JNV) { s.mc.d_body[lane] = m->d_body[lane]; s.mc.d_parent[lane] = m->d_parent[lane]; }
-  {
-    int g = lane;
-    for (int k = 0; k < 3; k++) s.mc.g_size[g][k] = m->g_size[g][k];
-    s.gpos[g][3] = m->g_rbound[g];   // constant slot of the (position, radius) quadruple
-  }
 }
 
 // ---------------------------------------------------------------- small vector helpers
@@ -432,7 +454,7 @@ JDEV void st_frame(float* T, const m3& R, v3 p) {
   *reinterpret_cast<v4*>(T) = a; *reinterpret_cast<v4*>(T + 4) = b; *reinterpret_cast<v4*>(T + 8) = c;
 }
 template <class L>
-JDEV void stage_walk(const JacoModelDev* m, L& s, int lane, JProfCtx* wpc = nullptr) {
+JDEV void stage_walk(const JacoModelDev* m, L& s, int lane, bool markers, JProfCtx* wpc = nullptr) {
 #ifdef JACO_WALK_PROFILE   // diagnostic: split this stage over profile slots 9..14 (their usual owners are wrong in such a build)
 #define JWSTAMP(i) if (wpc) jprof_stamp(*wpc, (i), lane)
 #else
@@ -441,7 +463,7 @@ JDEV void stage_walk(const JacoModelDev* m, L& s, int lane, JProfCtx* wpc = null
   (void)wpc;
   const int nb = m->nbody, nv = m->nv;
   float* TA = &s.cinert[0][0];   // [JNB][12] frames, ping  (cinert+crb are contiguous: 2 * JNB * 10 floats)
-  float* TB = s.J + 256;         // [JNB][12] frames, pong  (the constraint-row area is free at this point)
+  float* TB = s.J + 256;         // [JNB][12] frames, pong  (the first JSCRATCH floats of the constraint-row area are free at this point)
   float* Sq = s.J;               // [JNV][6] S_d * qvel_d
   float* Sq2 = s.J + JNV * 6;    // [JNV][6] S_d-dot * qvel_d
   const bool isb = lane < nb;
@@ -483,7 +505,6 @@ JDEV void stage_walk(const JacoModelDev* m, L& s, int lane, JProfCtx* wpc = null
     st3(s.xpos[b], pos);
     stm(s.xmat[b], R);
     const v3 c = pos + mul(R, ld3(s.mc.b_com[b]));
-    st3(s.xipos[b], c);
     // spatial inertia about the world origin [m, m c, I_O], from the frame still in registers
     const float* I = m->b_inertia[b];
     m3 Il;
@@ -506,13 +527,25 @@ JDEV void stage_walk(const JacoModelDev* m, L& s, int lane, JProfCtx* wpc = null
 #pragma unroll
     for (int k = 0; k < 10; k++) { s.cinert[b][k] = io[k]; s.crb[b][k] = io[k]; }
   }
-  if (lane < m->ngeom) {
-    const int gb = m->g_body[lane];
-    if (gb >= 0) {
+  if (lane < m->ngeom) {   // geom poses (they share LDS with the constraint rows: every substep writes all of them)
+    const int gb = m->g_body[lane], km = markers ? m->g_marker[lane] : -1;
+    v3 gp; m3 gR;
+    if (gb >= 0) {            // rides on a moving body
       m3 Rg = ldm(s.xmat[gb]);
-      st3(s.gpos[lane], ld3(s.xpos[gb]) + mul(Rg, ld3(m->g_pos[lane])));
-      stm(s.gmat[lane], mul(Rg, ldm(m->g_mat[lane])));
+      gp = ld3(s.xpos[gb]) + mul(Rg, ld3(m->g_pos[lane]));
+      gR = mul(Rg, ldm(m->g_mat[lane]));
+    } else if (km >= 0) {     // rides on one of the two task-layer markers (set_mocap_xyz / set_mocap_orientation between env steps)
+      const float* P = s.mk + 12 * km;
+      m3 R = ldm(P + 3);
+      gp = ld3(P) + mul(R, ld3(m->g_lpos[lane]));
+      gR = mul(R, ldm(m->g_lmat[lane]));
+    } else {                  // static: world pose from the model
+      gp = ld3(m->g_pos[lane]);
+      gR = ldm(m->g_mat[lane]);
     }
+    st3(s.gpos[lane], gp);
+    s.gpos[lane][3] = m->g_rbound[lane];
+    stm(s.gmat[lane], gR);
   }
   if (lane < nv) {   // S_d: hinge -> world axis through the body origin; free joint -> 3 world translations, 3 body-frame rotations
     const int d = lane, bd = s.mc.d_body[d], k = d - s.mc.b_dadr[bd];
@@ -561,24 +594,7 @@ JDEV void stage_walk(const JacoModelDev* m, L& s, int lane, JProfCtx* wpc = null
   }
 }
 
-// ---------------------------------------------------------------- stage G: static geom poses (moving geoms, body inertias and RNE body forces live in stage K)
-template <class L>
-JDEV void stage_static_geoms(const JacoModelDev* m, L& s, int lane, const float* mk) {
-  // world poses of the geoms that do not move during a launch: static geoms and the geoms on the two task-layer markers
-  // (set_mocap_xyz / set_mocap_orientation happen between env steps).  Written once, before the substep loop.
-  if (lane < m->ngeom && m->g_body[lane] < 0) {
-    const int km = mk ? m->g_marker[lane] : -1;
-    if (km >= 0) {
-      const float* P = mk + 12 * km;
-      m3 R = ldm(P + 3);
-      st3(s.gpos[lane], ld3(P) + mul(R, ld3(m->g_lpos[lane])));
-      stm(s.gmat[lane], mul(R, ldm(m->g_lmat[lane])));
-    } else {
-      st3(s.gpos[lane], ld3(m->g_pos[lane]));
-      stm(s.gmat[lane], ldm(m->g_mat[lane]));
-    }
-  }
-}
+// ---------------------------------------------------------------- stage M helpers
 // Subtree sums for the bodies that have children (leaves keep their own values from stage G): composite inertias
 // crb[a] = sum of cinert over a's subtree (lane = (a, component), 10 components) and RNE forces cacc[a] = sum of cfrc over
 // the subtree (6 components; cacc is dead as an acceleration by now and doubles as the summed force).  Sources and
@@ -623,8 +639,8 @@ JDEV void stage_mass_bias(const JacoModelDev* m, L& s, int lane) {
     if (h * 64 + lane < nmp) {
       int d = code & 255, j = code >> 8;
       float v = dot(ldsv(s.cdof[j]), ldsv(Fd + 6 * d));
-      s.M[d * JNV + j] = v;
-      s.M[j * JNV + d] = v;
+      s.M[m_index(d, j)] = v;
+      s.M[m_index(j, d)] = v;
     }
   }
 }
@@ -1020,10 +1036,12 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
   bool tier_used = false;   // this tier's extra capacity was really needed in at least one substep
   const int emode = A.env_mode;
   if (emode >= 4) nsub = 0;   // take_action / terminal_inspection on their own: no substep runs
+  // poses of the two task-layer markers: LDS copy for this launch (their geoms are re-posed every substep)
+  if (lane < 24) s.mk[lane] = A.marker ? A.marker[(size_t)env * 24 + lane] : m->marker_rest[lane / 12][lane % 12];
   if (emode) {   // task row + the one-substep-stale quantities the controller reads (env_logic.h)
     if (lane < JTASK_N) s.task[lane] = A.task[(size_t)env * JTASK_N + lane];
     const float* CR = A.cache + (size_t)env * JCACHE_N;
-    if (lane < 36) { s.M[(lane / 6) * JNV + lane % 6] = CR[JC_M + lane]; s.cdof[lane / 6][lane % 6] = CR[JC_CDOF + lane]; }
+    if (lane < 36) { s.M[m_index(lane / 6, lane % 6)] = CR[JC_M + lane]; s.cdof[lane / 6][lane % 6] = CR[JC_CDOF + lane]; }
     if (lane < 6) s.bias[lane] = CR[JC_BIAS + lane];
     if (lane < 3) { s.xpos[m->ee_body][lane] = CR[JC_EEPOS + lane]; s.xpos[m->obj_body >= 0 ? m->obj_body : 0][lane] = CR[JC_OBJPOS + lane]; }
     if (lane < 9) s.xmat[m->ee_body][lane] = CR[JC_EEMAT + lane];
@@ -1064,9 +1082,11 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
           // write-through: if this env is handed to a heavy-tier workgroup later in the step, that workgroup (possibly on
           // another XCD) reads the pose from memory
           float* P = A.marker + (size_t)env * 24 + 12 * km;
+          float* Q = s.mk + 12 * km;   // (every geom lane of the marker writes the same values)
           st_wt(P + 0, mp.x); st_wt(P + 1, mp.y); st_wt(P + 2, mp.z);
+          Q[0] = mp.x; Q[1] = mp.y; Q[2] = mp.z;
 #pragma unroll
-          for (int k = 0; k < 9; k++) st_wt(P + 3 + k, MR.m[k]);
+          for (int k = 0; k < 9; k++) { st_wt(P + 3 + k, MR.m[k]); Q[3 + k] = MR.m[k]; }
         }
       }
       if (lane == 0 && A.obs_mode == 0) s.task[JT_RNG] = __uint_as_float(cnt0 + 6u);
@@ -1083,7 +1103,7 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
     sub0 = wave_uniform_i((int)s.task[JT_SUB]);
     float* PIN = A.cache + (size_t)env * JCACHE_N + JC_PIN;
     if (sub0 == 0) {
-      stage_walk(m, s, lane);
+      stage_walk(m, s, lane, false);
       wave_sync();
       v3 po, pe; m3 Ro, Re;
       eeobj_frame(m, s, &po, &Ro);
@@ -1110,8 +1130,7 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
     osc_target_quat(s, lane);
     wave_sync();
   }
-  stage_static_geoms(m, s, lane, A.marker ? A.marker + (size_t)env * 24 : nullptr);
-  wave_sync();
+  const bool markers = A.marker != nullptr;
   JProfCtx pc;
   pc.row = nullptr;
   pc.tprev = 0;
@@ -1149,12 +1168,13 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
       }
     }
 #ifdef JACO_WALK_PROFILE
-    stage_walk(m, s, lane, &pc);
+    stage_walk(m, s, lane, markers, &pc);
 #else
-    stage_walk(m, s, lane);
+    stage_walk(m, s, lane, markers);
 #endif
-    for (int i = lane; i < JNV * JNV; i += 64) s.M[i] = 0.f;
+    for (int i = lane; i < JMBLK; i += 64) s.M[i] = 0.f;
     wave_sync();
+    if (A.dbg && env == A.dbg_env && sub == nsub - 1 && lane < m->ngeom) for (int k = 0; k < 3; k++) A.dbg[JDBG_GPOS + 3 * lane + k] = s.gpos[lane][k];
     JSTAMP(0);
     JSTAMP(1);
     stage_accumulate(m, s, lane);
@@ -1168,20 +1188,21 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
     }
     stage_actuation(m, s, lane);
     JSTAMP(2);
-    // constraint rows first: nothing below is live across the (register-hungry) collision code.  (Actuation and the limit
-    // rows touch disjoint LDS arrays: one synchronisation for both.)
-    stage_limit_rows(m, s, lane);
-    wave_sync();
-    JSTAMP(3);
+    // collision first, then the row builders: the constraint rows share LDS with the geom poses and the broadphase survivors,
+    // which are dead once the contact list exists.  (Actuation touches neither: no synchronisation of its own.)
     unsigned cflags = 0;
     if (!A.disable_contact) {
       stage_collision(A, m, s, lane, cflags, pc);
       wave_sync();
       JSTAMP(4);
+      stage_limit_rows(m, s, lane);
+      wave_sync();
+      JSTAMP(3);
       stage_contact_rows(m, s, lane, cflags);
       wave_sync();
       JSTAMP(5);
     } else {
+      stage_limit_rows(m, s, lane);
       if (lane == 0) { s.ncon = 0; s.ncand = 0; }
       wave_sync();
     }
@@ -1204,8 +1225,12 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
       break;
     }
     float mrow[JNV], h[JNV];   // M[lane][:] stays in registers for the rest of the substep
+    {   // row `lane` of the block-diagonal mass matrix: only the lane's own dof block is stored
+      const int blo = lane < JB0 ? 0 : (lane < JB1 ? JB0 : JB1), bn = lane < JB0 ? JB0 : (lane < JB1 ? JB1 - JB0 : JNV - JB1);
+      const int rbase = lane < nv ? m_index(lane, blo) : 0;
 #pragma unroll
-    for (int j = 0; j < JNV; j++) mrow[j] = lane < nv ? s.M[lane * JNV + j] : 0.f;
+      for (int j = 0; j < JNV; j++) { const bool in = lane < nv && j >= blo && j < blo + bn; mrow[j] = in ? s.M[in ? rbase + j - blo : 0] : 0.f; }
+    }
     float smooth = lane < nv ? s.smooth[lane] : 0.f;
     float qas = 0.f;   // (qacc_smooth is no longer formed; kept in the dump layout)
     wave_sync();
@@ -1237,7 +1262,11 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
         for (int k = 0; k < 3; k++) D[JDBG_XPOS + 3 * lane + k] = s.xpos[lane][k];
         for (int k = 0; k < 9; k++) D[JDBG_XMAT + 9 * lane + k] = s.xmat[lane][k];
       }
-      for (int i = lane; i < JNV * JNV; i += 64) D[JDBG_M + i] = s.M[i];
+      for (int i = lane; i < JNV * JNV; i += 64) {
+        const int d = i / JNV, j = i % JNV;
+        const bool same = (d < JB0) == (j < JB0) && (d < JB1) == (j < JB1);
+        D[JDBG_M + i] = same ? s.M[m_index(d, j)] : 0.f;
+      }
       if (lane < nv) {
         D[JDBG_BIAS + lane] = s.bias[lane]; D[JDBG_SMOOTH + lane] = smooth; D[JDBG_QACC_SMOOTH + lane] = qas;
         D[JDBG_QACC + lane] = nw.qacc; D[JDBG_QFRC_CON + lane] = nw.qfrc_con;
@@ -1252,7 +1281,6 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
         float* o = D + JDBG_EFC + 4 * r;
         o[0] = s.e_aref[r]; o[1] = 1.f / s.e_D[r]; o[2] = 0.f; o[3] = s.e_f[r];
       }
-      if (lane < m->ngeom) for (int k = 0; k < 3; k++) D[JDBG_GPOS + 3 * lane + k] = s.gpos[lane][k];
       if (lane < s.ncon) D[JDBG_CFN + lane] = s.c_fn[lane];
       if (lane < m->nsensor) D[JDBG_SENS + lane] = sens;
     }
@@ -1298,7 +1326,7 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
       // what the controller reads one substep late, for the next launch -- or, on a heavy -> light hand-back in the middle
       // of a step, for the light code's next substep
       float* CW = A.cache + (size_t)env * JCACHE_N;
-      if (lane < 36) { CW[JC_M + lane] = s.M[(lane / 6) * JNV + lane % 6]; CW[JC_CDOF + lane] = s.cdof[lane / 6][lane % 6]; }
+      if (lane < 36) { CW[JC_M + lane] = s.M[m_index(lane / 6, lane % 6)]; CW[JC_CDOF + lane] = s.cdof[lane / 6][lane % 6]; }
       if (lane < 6) CW[JC_BIAS + lane] = s.bias[lane];
       int ob = m->obj_body >= 0 ? m->obj_body : 0;
       if (lane < 3) { CW[JC_EEPOS + lane] = s.xpos[m->ee_body][lane]; CW[JC_OBJPOS + lane] = s.xpos[ob][lane]; }
@@ -1376,7 +1404,10 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
 }
 
 // light tier: one workgroup (= one wavefront) per env
-__global__ __launch_bounds__(64, 2) void jaco_physics_kernel(JacoStepArgs A) {
+#ifndef JACO_LIGHT_WAVES
+#define JACO_LIGHT_WAVES 3   // waves per SIMD the light kernel is compiled for: 13.3 KB of LDS per env allow 12 envs per CU, 168 VGPRs each
+#endif
+__global__ __launch_bounds__(64, JACO_LIGHT_WAVES) void jaco_physics_kernel(JacoStepArgs A) {
   __shared__ JacoLDS<JacoLight> s;
 #ifdef JACO_LDS_PAD   // occupancy experiment: extra LDS per workgroup (floats), touched so that it is allocated
   __shared__ float lds_pad[JACO_LDS_PAD];
