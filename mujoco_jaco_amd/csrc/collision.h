@@ -522,11 +522,10 @@ JDEV void stage_collision(const JacoStepArgs& A, const JacoModelDev* m, L& s, in
 #endif
       push_contacts(s, hit && lane == 0, -depth, pos, dir, pk, ncon, flags, 1);
     }
-    if (ncon > before) {   // dof chain masks of the two bodies, cached for the row builder
-      int b1 = m->g_body[g1], b2 = m->g_body[g2];
-      unsigned m1 = b1 >= 0 ? m->b_chainmask[b1] : 0u, m2 = b2 >= 0 ? m->b_chainmask[b2] : 0u;
+    if (ncon > before) {   // dof chain masks / body ids of the two geoms, for the row builder and the touch stage
+      const JacoPairParam& P = m->pair[pk];
       int c = before + lane;
-      if (c < ncon) { s.c_m1[c] = m1; s.c_m2[c] = m2; s.c_ob[c] = m->g_origbody[g1] | ((b1 + 1) << 8) | (m->g_origbody[g2] << 16) | ((b2 + 1) << 24); s.c_dim[c] = m->pair[pk].condim; }
+      if (c < ncon) { s.c_m1[c] = P.m1; s.c_m2[c] = P.m2; s.c_ob[c] = P.ob; s.c_dim[c] = P.condim; }
     }
   }
   if (lane == 0) { s.ncon = ncon; s.ncand = ncand; }

@@ -26,6 +26,10 @@ struct JacoPairParam {
   int condim;        // max of the two geoms
   int g1, g2;        // fused geom ids, type(g1) <= type(g2)
   float tran, rot;   // translational / rotational body_invweight0 of the two geoms' bodies, summed (diagApprox of contact rows)
+  // what a contact of this pair carries into the row builder, precomputed by the loader (one struct read instead of
+  // g_body -> b_chainmask / g_origbody chains per contact):
+  unsigned m1, m2;   // dof chain masks of the two geoms' bodies (0: static)
+  int ob;            // original (unfused) body id | (fused body + 1) << 8 for g1; the same for g2 in the upper half
 };
 
 struct JacoModelDev {

@@ -206,6 +206,9 @@ int jaco_model_from_blob(const void* buf, size_t size, JacoModelDev* m, std::vec
     for (int i = 0; i < 5; i++) { P.mu[i] = (float)pmu[5 * k + i]; P.solimp[i] = (float)pimp[5 * k + i]; }
     P.solref[0] = (float)pref[2 * k]; P.solref[1] = (float)pref[2 * k + 1];
     m->pair_code[k] = g1 | (g2 << 8) | (gty[g1] << 16) | (gty[g2] << 20);
+    const int b1 = m->g_body[g1], b2 = m->g_body[g2];
+    P.m1 = b1 >= 0 ? m->b_chainmask[b1] : 0u; P.m2 = b2 >= 0 ? m->b_chainmask[b2] : 0u;
+    P.ob = m->g_origbody[g1] | ((b1 + 1) << 8) | (m->g_origbody[g2] << 16) | ((b2 + 1) << 24);
   }
   // ---- touch sites
   const int32_t *sb = B.i32("f_site_body", ns), *sty = B.i32("f_site_type", ns), *sob = B.i32("f_site_origbody", ns);
