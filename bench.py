@@ -50,8 +50,9 @@ def parse_args(argv=None):
     ap.add_argument("--task", default="picking")
     ap.add_argument("--action-scale", type=float, default=1.0, help="actions are U(-1,1)^7 times this (1.0 = the headline)")
     ap.add_argument("--preroll", type=int, default=40, help="untimed env steps (with masked resets) before warmup")
-    ap.add_argument("--extra-scales", default="0.3,0.05", help="action scales also timed (briefly) after the headline window; '' = none")
+    ap.add_argument("--extra-scales", default="0.3,0.05", help="action scales also timed (briefly, each in a child process before the headline run); '' = none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--drift-gpu-leg", default=None, help=argparse.SUPPRESS)   # internal: child process that steps the HIP path on the drift workload
     ap.add_argument("--dry-gather", action="store_true",
                     help="CPU rehearsal of the N > 1 plumbing (spawn, rendezvous, gather, max-over-ranks timing) on gloo: no GPU, no physics")
     return ap.parse_args(argv)
@@ -72,22 +73,72 @@ def self_launch(args):
     return max(abs(rc) for rc in rcs)
 
 
-def cpu_baseline_and_drift(model, frame_skip, gpu_step, budget_envs_per_core=8):
-    """fp64 oracle (oracle/, test infrastructure) on the host cores: a reported baseline, not the target.  The same oracle
-    run doubles as the reference trajectory of the drift metric: `gpu_step(q0, ctrl, marks)` steps the HIP path on the
-    same inputs and returns qpos at the marks."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
+def small_action_runs(args):
+    """Throughput at the smaller action scales (the regime a converged policy lives in: the EE sits on its "hand" marker), each in
+    its own child process started BEFORE this process touches the GPU: the parent's launch statistics (rocprofv3 --stats, HIP-event
+    kernel time) then hold the headline workload only."""
+    out = {}
+    for sc in [x for x in args.extra_scales.split(",") if x]:
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--action-scale", sc, "--steps", "6", "--warmup", "2", "--preroll", "16",
+               "--batch", str(args.batch), "--model", args.model, "--task", args.task, "--no-cpu-baseline", "--extra-scales", ""]
+        if args.frame_skip is not None:
+            cmd += ["--frame-skip", str(args.frame_skip)]
+        try:
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            out[sc] = json.loads(p.stdout.strip().splitlines()[-1])["value"]
+        except Exception as e:  # a failed side measurement must not take the headline down
+            out[sc] = None
+            print("bench.py: action scale %s run failed: %r" % (sc, e), file=sys.stderr)
+    return out
+
+
+DRIFT_MARKS = (100, 300, 1000)
+
+
+def drift_workload(model, cores, budget_envs_per_core=8):
     import numpy as np
     from mujoco_jaco_amd import workload
     from mujoco_jaco_amd.modelc import blob
+    M = blob.load(os.path.join(ROOT, "mujoco_jaco_amd", "assets", model + ".jacomdl"))
+    nu = int(M["nu"][0])
+    nenv = max(64, min(2048, budget_envs_per_core * cores))
+    q0 = workload.reset_states(M["qpos0"], nenv, seed=41, f32_draws=True)
+    c = np.ascontiguousarray(workload.random_ctrl(nenv, seed=42, scale=0.2)[:, :nu].astype(np.float32).astype(np.float64))
+    return nenv, q0, c
+
+
+def drift_gpu_leg(args):
+    """Child process (started before the parent touches the GPU): the HIP path on the drift workload, qpos at the marks -> .npz.
+    Kept out of the parent so that its handful of 100..700-substep ctrl-level launches do not sit in the headline run's
+    launch statistics."""
+    import numpy as np
+    import torch
+    from mujoco_jaco_amd.physics import BatchedMujoco
+    nenv, q0, c = drift_workload(args.model, os.cpu_count() or 1)
+    e2 = BatchedMujoco(nenv, robot_file=args.model, device=0)
+    e2.set_state(torch.tensor(q0, dtype=torch.float32, device=e2.device), None, None)
+    cc = torch.tensor(c, dtype=torch.float32, device=e2.device)
+    got, done = {}, 0
+    for mk in DRIFT_MARKS:
+        e2.send_forces(cc, nsub=mk - done)
+        done = mk
+        got["q%d" % mk] = e2.get_state()[0].cpu().numpy().astype(np.float64)
+    np.savez(args.drift_gpu_leg, flags=e2.flags().cpu().numpy(), **got)
+    e2.close()
+    return 0
+
+
+def cpu_baseline_and_drift(model, frame_skip, gpu_npz):
+    """fp64 oracle (oracle/, test infrastructure) on the host cores: a reported baseline, not the target.  The same oracle
+    run doubles as the reference trajectory of the drift metric: `gpu_npz` holds the HIP path's qpos on the same inputs at
+    the marks (drift_gpu_leg)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
     from oracle_binding import Oracle
     cores = os.cpu_count() or 1
-    M = blob.load(os.path.join(ROOT, "mujoco_jaco_amd", "assets", model + ".jacomdl"))
     o = Oracle(model)
-    nenv = max(64, min(2048, budget_envs_per_core * cores))
-    marks = (100, 300, 1000)
-    q0 = workload.reset_states(M["qpos0"], nenv, seed=41, f32_draws=True)
-    c = np.ascontiguousarray(workload.random_ctrl(nenv, seed=42, scale=0.2)[:, :o.nu].astype(np.float32).astype(np.float64))
+    nenv, q0, c = drift_workload(model, cores)
+    marks = DRIFT_MARKS
     q, v, w = np.ascontiguousarray(q0.copy()), np.zeros((nenv, o.nv)), np.zeros((nenv, o.nv))
     o.step_batch(q.copy(), v.copy(), w.copy(), c, nsub=2, nthreads=cores)  # warm the thread pool
     ref, done, t = {}, 0, time.time()
@@ -99,13 +150,26 @@ def cpu_baseline_and_drift(model, frame_skip, gpu_step, budget_envs_per_core=8):
     base = {"value": nenv * done / dt / frame_skip, "unit": "env-steps/s", "cores": cores, "kind": "port",
             "sample": "%d envs x %d physics substeps of the same workload (picking reset distribution, constant random torques; the controller / observation glue is not timed), fp64 C oracle, OpenMP over %d threads, %.1f s; frame_skip %d"
                       % (nenv, done, cores, dt, frame_skip)}
-    got = gpu_step(q0, c, marks)
+    if gpu_npz is None or not os.path.exists(gpu_npz):
+        return base, None
+    got = {mk: np.load(gpu_npz)["q%d" % mk] for mk in marks}
     drift = {"metric": "max-abs qpos error of the HIP path vs the fp64 oracle, same (qpos, qvel, ctrl), ctrl level", "envs": nenv, "oracle": "port (parity unpinned: no MuJoCo)"}
     for mk in marks:
         e = np.abs(got[mk] - ref[mk]).max(1)
         drift["after_%d_substeps" % mk] = {"median": float(np.median(e)), "p90": float(np.percentile(e, 90)), "max": float(e.max()),
                                             "frac_le_1e-4": float(np.mean(e <= 1e-4))}
-    drift["note"] = "contact dynamics amplify last-bit differences: the fp64 oracle carrying fp32-rounded state parts from itself the same way (profiles/r02_drift_control.txt)"
+    # control: the same fp64 code carrying fp32-rounded state (no fp32 arithmetic anywhere) against itself -- the floor for any
+    # engine that keeps its state in fp32
+    oc = Oracle(model); oc.option("round_state", 1)
+    q, v, w = np.ascontiguousarray(q0.copy()), np.zeros((nenv, o.nv)), np.zeros((nenv, o.nv))
+    done, ctl = 0, {}
+    for mk in marks:
+        oc.step_batch(q, v, w, c, nsub=mk - done, nthreads=cores)
+        done = mk
+        e = np.abs(q - ref[mk]).max(1)
+        ctl["after_%d_substeps" % mk] = {"median": float(np.median(e)), "frac_le_1e-4": float(np.mean(e <= 1e-4))}
+    drift["control_fp64_oracle_with_fp32_rounded_state"] = ctl
+    drift["note"] = "contact dynamics amplify last-bit differences: the fp64 oracle carrying fp32-rounded state parts from itself the same way (control above; per-env attribution in profiles/r02_drift_attribution.txt)"
     return base, drift
 
 
@@ -147,6 +211,19 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if args.dry_gather:
         sys.exit(dry_rank(args, world, rank))
+    if args.drift_gpu_leg:
+        sys.exit(drift_gpu_leg(args))
+    small = small_action_runs(args) if (args.level == "env" and world == 1 and args.extra_scales) else {}
+    drift_npz = None
+    if world == 1 and not args.no_cpu_baseline:   # the HIP leg of the drift metric, in a child process before this one touches the GPU
+        drift_npz = os.path.join(ROOT, "gpurun_out", "bench_drift_gpu_%d.npz" % os.getpid())
+        os.makedirs(os.path.dirname(drift_npz), exist_ok=True)
+        try:
+            subprocess.run([sys.executable, os.path.abspath(__file__), "--drift-gpu-leg", drift_npz, "--model", args.model], timeout=600, check=True,
+                           stdout=subprocess.DEVNULL)
+        except Exception as e:
+            print("bench.py: drift GPU leg failed: %r" % (e,), file=sys.stderr)
+            drift_npz = None
 
     import numpy as np
     import torch
@@ -222,22 +299,13 @@ def main():
     done_count.zero_()
     env.enable_timing(True)
     dt = timed(args.steps)
+    step_ms = env.step_time_ms()
     kern_ms, launches = env.kernel_time_ms()
     env.enable_timing(False)
     done_fraction = float(done_count.item()) / (B * args.steps)
     flags = int(env.flags().max().item())
     stats = env.stats().float().mean(0).cpu().numpy()
     heavy = float(((env.flags() & 32) != 0).float().mean().item())
-
-    small = {}
-    if args.level == "env" and world == 1 and args.extra_scales:
-        for sc in [float(x) for x in args.extra_scales.split(",") if x]:
-            scale[0] = sc
-            for _ in range(12):   # let the EE settle onto the smaller targets (the regime a converged policy lives in)
-                step()
-            n = 4
-            small["%g" % sc] = B * n / timed(n)
-        scale[0] = float(args.action_scale)
 
     if rank == 0:
         # algorithmic HBM bytes per env per launch.  SURVEY 8(d): A = 4 (2 nq + 2 nv + n_act + n_obs + 1) + 1 = 489 B for the env
@@ -276,24 +344,15 @@ def main():
                        "mean_contacts": float(stats[0]), "mean_rows": float(stats[1]), "mean_newton_iters": float(stats[2]), "flags_or": flags,
                        "heavy_tier_fraction": heavy},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "jaco_physics_kernel (+ its tier drains)", "kernel_ms": kern_ms, "launches": launches,
+                         "traffic": traffic, "kernel": "jaco_physics_kernel", "kernel_ms": kern_ms, "launches": launches, "step_launch_set_ms": step_ms,
                          "algorithmic_bytes_per_env_launch": a_survey, "implementation_bytes_per_env_launch": a_impl,
                          "valu_issue_frac": valu, "wait_frac": wait,
                          "note": "latency/occupancy-bound by design (SURVEY 8d): algorithmic traffic is ~0.5 KB per env per launch, so the HBM fraction is ~1e-4 whatever the kernel does; the meaningful ceilings are VALU issue (valu_issue_frac: wave-instructions issued / 1.23e12 per s) and exposed latency (wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES), both from the committed PMC pass of this command (profiles/)"},
         }
         if world == 1 and not args.no_cpu_baseline:
-            def gpu_step(q0, c, marks):
-                e2 = BatchedMujoco(q0.shape[0], robot_file=args.model, device=local_rank)
-                e2.set_state(torch.tensor(q0, dtype=torch.float32, device=dev), None, None)
-                cc = torch.tensor(c, dtype=torch.float32, device=dev)
-                got, done = {}, 0
-                for mk in marks:
-                    e2.send_forces(cc, nsub=mk - done)
-                    done = mk
-                    got[mk] = e2.get_state()[0].cpu().numpy().astype(np.float64)
-                e2.close()
-                return got
-            out["cpu_baseline"], out["drift"] = cpu_baseline_and_drift(args.model, fs, gpu_step)
+            out["cpu_baseline"], out["drift"] = cpu_baseline_and_drift(args.model, fs, drift_npz)
+            if drift_npz and os.path.exists(drift_npz):
+                os.remove(drift_npz)
         print(json.dumps(out))
     env.close()
     if world > 1:

@@ -148,9 +148,13 @@ int jaco_set_option(JacoHandle* h, const char* name, double value);
 int jaco_physics_step_debug(JacoHandle* h, const float* ctrl_dev, int nsub, int env, float* dump_host, int dump_floats);
 int jaco_debug_dump_floats(void);
 
-/* Average device time of the physics kernel over the launches since the last call, measured with HIP
- * events on the stream the kernel was launched on (bench.py roofline leg); synchronises. */
+/* Average device time of the light-tier kernel (jaco_physics_kernel: the dominant kernel, what rocprofv3 --stats lists under that
+ * name) over the step launches since jaco_enable_timing, measured with HIP events on the stream the kernel was launched on (bench.py
+ * roofline leg); synchronises. */
 int jaco_kernel_time_ms(JacoHandle* h, double* avg_ms, int* launches);
+/* Same window, the whole launch set of a step (routing and ordering passes, light grid, the tiers' workers and drains): call it
+ * BEFORE jaco_kernel_time_ms, which closes the window. */
+int jaco_step_time_ms(JacoHandle* h, double* avg_ms);
 int jaco_enable_timing(JacoHandle* h, int enable);
 
 /* Diagnostic builds only (-DJACO_PROFILE_STAGES): per-env, per-stage shader-clock sums [num_envs][12] copied to host;

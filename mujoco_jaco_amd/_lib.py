@@ -52,6 +52,7 @@ SYMBOLS = {
     "jaco_debug_dump_floats": (_ci, []),
     "jaco_kernel_time_ms": (_ci, [_vp, ctypes.POINTER(_cd), _ip]),
     "jaco_enable_timing": (_ci, [_vp, _ci]),
+    "jaco_step_time_ms": (_ci, [_vp, ctypes.POINTER(_cd)]),
     "jaco_stage_profile": (_ci, [_vp, ctypes.POINTER(ctypes.c_uint64), _ci]),
 }
 

@@ -57,7 +57,8 @@ struct JacoHandle {
   uint64_t seed = 0;
   std::string err;
   bool timing = false;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;        // around a whole step launch set (routing .. drains)
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> kevents;       // around the light-tier kernel alone (what rocprofv3 reports for it)
   size_t events_used = 0;
 };
 
@@ -184,6 +185,7 @@ extern "C" int jaco_destroy(JacoHandle* h) {
   if (!h) return JACO_EINVAL;
   (void)hipSetDevice(h->device);
   for (auto& e : h->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  for (auto& e : h->kevents) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   for (int t = 0; t < 3; t++) {
     if (h->side[t]) { (void)hipStreamSynchronize(h->side[t]); (void)hipStreamDestroy(h->side[t]); }
     if (h->ev_join[t]) (void)hipEventDestroy(h->ev_join[t]);
@@ -380,7 +382,7 @@ __global__ void jaco_prepare_kernel(int* ctl, int* lists, int n, int wm, int wh,
       // reserve: overflows that only show up during a step = last step's demand minus what it had queued at once
       int late = pc[t] - ctl[JQ_PREV_HINTED + t];
       late = late < 0 ? 0 : late;
-      const int base = t == 0 ? 16 : (t == 1 ? 8 : 2);
+      const int base = t == 0 ? 8 : (t == 1 ? 4 : 1);   // (a resident heavy / huge worker holds the LDS of 3 / 5 light envs)
       ctl[JQ_LIMIT + t] = w; ctl[JQ_RESERVE + t] = base + late / 10; ctl[JQ_COUNT + t] = 0; ctl[JQ_TAKEN + t] = 0; ctl[JQ_HINTED + t] = 0;
     }
     ctl[JQ_ROUTED] = 0;
@@ -403,14 +405,18 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
   A.task = h->task_rows; A.cache = h->cache; A.action = io.action; A.noise = h->noise; A.obs_mode = h->obs_mode; A.subgoal = h->subgoal; A.obs = io.obs; A.reward = io.reward; A.done = io.done; A.mask = io.mask; A.marker = h->marker;
   A.cost = h->cost;
   const bool reorder = io.mode == 1 && h->schedule && nsub >= 8 && h->num_envs >= 4096;
-  std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
+  std::pair<hipEvent_t, hipEvent_t>*ev = nullptr, *kev = nullptr;
   if (h->timing && io.mode <= 1) {   // (the masked forward passes of resets are not the kernel being measured)
     if (h->events_used == h->events.size()) {
       hipEvent_t a, b;
       HIPCHK(h, hipEventCreate(&a));
       HIPCHK(h, hipEventCreate(&b));
       h->events.emplace_back(a, b);
+      HIPCHK(h, hipEventCreate(&a));
+      HIPCHK(h, hipEventCreate(&b));
+      h->kevents.emplace_back(a, b);
     }
+    kev = &h->kevents[h->events_used];
     ev = &h->events[h->events_used++];
     HIPCHK(h, hipEventRecord(ev->first, st));
   }
@@ -450,7 +456,10 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
     HIPCHK(h, hipGetLastError());
     for (int t = 0; t < 3; t++) HIPCHK(h, hipEventRecord(h->ev_join[t], h->side[t]));
   }
-  hipLaunchKernelGGL(jaco_physics_kernel, dim3(light_grid), dim3(64), 0, st, A);
+  if (kev) HIPCHK(h, hipEventRecord(kev->first, st));
+  if (A.nslots || io.mode >= 2) hipLaunchKernelGGL(jaco_physics_kernel_listed, dim3(light_grid), dim3(64), 0, st, A);   // (resets: forward passes, placing hold)
+  else hipLaunchKernelGGL(jaco_physics_kernel, dim3(light_grid), dim3(64), 0, st, A);
+  if (kev) HIPCHK(h, hipEventRecord(kev->second, st));
   HIPCHK(h, hipGetLastError());
   if (conc) for (int t = 0; t < 3; t++) HIPCHK(h, hipStreamWaitEvent(st, h->ev_join[t], 0));
   const unsigned ne = (unsigned)h->num_envs;
@@ -689,18 +698,29 @@ extern "C" int jaco_enable_timing(JacoHandle* h, int enable) {
   h->events_used = 0;
   return JACO_OK;
 }
+static int event_mean(JacoHandle* h, const std::vector<std::pair<hipEvent_t, hipEvent_t>>& evs, double* avg_ms) {
+  double tot = 0;
+  for (size_t i = 0; i < h->events_used; i++) {
+    float ms = 0;
+    HIPCHK(h, hipEventElapsedTime(&ms, evs[i].first, evs[i].second));
+    tot += ms;
+  }
+  *avg_ms = h->events_used ? tot / h->events_used : 0.0;
+  return JACO_OK;
+}
 extern "C" int jaco_kernel_time_ms(JacoHandle* h, double* avg_ms, int* launches) {
   if (!h || !avg_ms) return JACO_EINVAL;
   ENTER(h);
   HIPCHK(h, hipDeviceSynchronize());
-  double tot = 0;
-  for (size_t i = 0; i < h->events_used; i++) {
-    float ms = 0;
-    HIPCHK(h, hipEventElapsedTime(&ms, h->events[i].first, h->events[i].second));
-    tot += ms;
-  }
-  *avg_ms = h->events_used ? tot / h->events_used : 0.0;
+  int rc = event_mean(h, h->kevents, avg_ms);
+  if (rc) return rc;
   if (launches) *launches = (int)h->events_used;
   h->events_used = 0;
   return JACO_OK;
+}
+extern "C" int jaco_step_time_ms(JacoHandle* h, double* avg_ms) {
+  if (!h || !avg_ms) return JACO_EINVAL;
+  ENTER(h);
+  HIPCHK(h, hipDeviceSynchronize());
+  return event_mean(h, h->events, avg_ms);
 }

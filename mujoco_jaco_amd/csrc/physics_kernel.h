@@ -1209,7 +1209,7 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
     if (!LIGHT) {   // would the tier below have coped with this substep?  (huge -> heavy, heavy -> medium, medium -> light)
       constexpr int LCON = TIER == 3 ? JacoHeavy::MAXCON : (TIER == 2 ? JacoMedium::MAXCON : JacoLight::MAXCON);
       constexpr int LEFC = TIER == 3 ? JacoHeavy::MAXEFC : (TIER == 2 ? JacoMedium::MAXEFC : JacoLight::MAXEFC);
-      const bool fits = s.ncon <= LCON && s.nefc <= LEFC && s.ncand <= JacoLight::MAXCAND / 2;
+      const bool fits = s.ncon <= LCON && s.nefc <= LEFC && s.ncand <= JacoLight::MAXCAND / 2;   // (head room below the capacity was tried: no gain)
       calm = fits ? calm + 1 : 0;
       if (!fits && !tier_used) { tier_used = true; hint_raise(A, env, TIER, lane); }
     }
@@ -1407,13 +1407,7 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
 #ifndef JACO_LIGHT_WAVES
 #define JACO_LIGHT_WAVES 3   // waves per SIMD the light kernel is compiled for: 13.3 KB of LDS per env allow 12 envs per CU, 168 VGPRs each
 #endif
-__global__ __launch_bounds__(64, JACO_LIGHT_WAVES) void jaco_physics_kernel(JacoStepArgs A) {
-  __shared__ JacoLDS<JacoLight> s;
-#ifdef JACO_LDS_PAD   // occupancy experiment: extra LDS per workgroup (floats), touched so that it is allocated
-  __shared__ float lds_pad[JACO_LDS_PAD];
-  if (A.nenv < 0) lds_pad[threadIdx.x] = 1.f;
-  asm volatile("" :: "v"(&lds_pad[0]));
-#endif
+JDEV void light_grid(const JacoStepArgs& A, JacoLDS<JacoLight>& s) {
   const int lane = lane_id();
   if (env_id() >= A.nenv) return;
   const int nslots = A.nslots ? *A.nslots : A.nenv;
@@ -1436,6 +1430,16 @@ __global__ __launch_bounds__(64, JACO_LIGHT_WAVES) void jaco_physics_kernel(Jaco
   wave_sync();
   }
   if (lane == 0 && A.light_left) jaco_atomic_dec(A.light_left, false);
+}
+__global__ __launch_bounds__(64, JACO_LIGHT_WAVES) void jaco_physics_kernel(JacoStepArgs A) {
+  __shared__ JacoLDS<JacoLight> s;
+  light_grid(A, s);
+}
+// the same code under its own name for reset-time launches (forward pass, placing hold; for a masked reset a small grid that walks
+// the list of reset envs): the step kernel's launch statistics (rocprofv3 --stats, bench.py's kernel_ms) then hold step launches only
+__global__ __launch_bounds__(64, JACO_LIGHT_WAVES) void jaco_physics_kernel_listed(JacoStepArgs A) {
+  __shared__ JacoLDS<JacoLight> s;
+  light_grid(A, s);
 }
 // One handed-over env on a bigger-tier workgroup: the big code (medium: TB = 1, heavy: TB = 2) runs while the overflow
 // lasts, the light code in between, until the env's step is complete.  Returns 0, or -- medium only -- the substeps left

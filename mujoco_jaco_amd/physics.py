@@ -115,6 +115,12 @@ class BatchedMujoco:
     def enable_timing(self, on=True):
         self._chk(self.L.jaco_enable_timing(self.h, int(on)))
 
+    def step_time_ms(self):
+        """Mean device time of a whole step launch set in the timing window (call before kernel_time_ms, which closes it)."""
+        ms = ctypes.c_double()
+        self._chk(self.L.jaco_step_time_ms(self.h, ctypes.byref(ms)))
+        return ms.value
+
     def kernel_time_ms(self):
         ms, n = ctypes.c_double(), ctypes.c_int()
         self._chk(self.L.jaco_kernel_time_ms(self.h, ctypes.byref(ms), ctypes.byref(n)))

@@ -51,6 +51,12 @@ if "--slow" in sys.argv:   # what the slowest 2 % of envs spend their time on
     for i, n in enumerate(names): print("   %-42s mean %9.0f" % (n, per[slow, i].mean()))
     fl = env.flags().cpu().numpy()
     print("   flags: singular %.3f heavy %.3f maxiter %.3f; ncon mean %.1f cand mean %.1f iters mean %.2f" % (((fl[slow] & 64) != 0).mean(), ((fl[slow] & 32) != 0).mean(), ((fl[slow] & 16) != 0).mean(), st[slow, 0].mean(), (st[slow, 3] & 0xffff).mean(), st[slow, 2].mean()))
+if "--by-rows" in sys.argv:   # stage split by the env's row count at the end of the step (which tier it lives in)
+    for lo, hi in ((0, 64), (64, 128), (128, 256), (256, 100000)):
+        sel = (st[:, 1] > lo) & (st[:, 1] <= hi)
+        if sel.sum() == 0: continue
+        print("rows in (%d, %d]: %d envs, total mean %.0f cycles/substep, newton iters mean %.2f, contacts mean %.1f" % (lo, hi, sel.sum(), tot[sel].mean(), st[sel, 2].mean(), st[sel, 0].mean()))
+        for i, n in enumerate(names): print("   %-42s mean %9.0f" % (n, per[sel, i].mean()))
 if "--heavy" in sys.argv:   # envs the heavy tier touched in the profiled step (flags are cleared before it)
     fl = env.flags().cpu().numpy()
     hv = (fl & 32) != 0
