@@ -127,6 +127,7 @@ int jaco_model_from_blob(const void* buf, size_t size, JacoModelDev* m, std::vec
     int n = jt[b] == JJ_FREE ? 6 : 1;
     for (int k = 0; k < n; k++) mask |= 1u << (da[b] + k);
     m->b_chainmask[b] = mask;
+    if (__builtin_popcount(mask) > 7) FAIL("a body is moved by more than 7 dofs (JMAXCHAIN of physics_kernel.h)");
   }
   // ---- subtree tables for the composite-inertia / mass-matrix stages
   int ninner = 0;
@@ -135,6 +136,7 @@ int jaco_model_from_blob(const void* buf, size_t size, JacoModelDev* m, std::vec
     for (int x = 0; x < nb; x++)
       for (int y = x; y >= 0; y = par[y]) if (y == b) { desc |= 1u << x; break; }
     m->b_descmask[b] = desc;
+    if (__builtin_popcount(desc) > 9) FAIL("a subtree holds more than 9 bodies (JMAXDESC of physics_kernel.h)");
     if (desc != (1u << b)) {
       if (ninner >= JMAXINNER) FAIL("too many bodies with children for the kernels' subtree stage");
       m->inner_body[ninner++] = b;

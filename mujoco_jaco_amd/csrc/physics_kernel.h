@@ -453,6 +453,24 @@ JDEV void st_frame(float* T, const m3& R, v3 p) {
   c.y = p.x; c.z = p.y; c.w = p.z;
   *reinterpret_cast<v4*>(T) = a; *reinterpret_cast<v4*>(T + 4) = b; *reinterpret_cast<v4*>(T + 8) = c;
 }
+// sum of the 6-vectors T[d] over the dofs d of a chain mask.  A body is moved by at most JMAXCHAIN dofs (6 arm joints + its own
+// finger joint; a free body's 6): the loads of all terms are issued together (one LDS round trip) instead of one dependent
+// iteration per set bit.
+#define JMAXCHAIN 7
+JDEV sv chain_sum(const float* T, unsigned mask) {
+  sv t[JMAXCHAIN];
+  bool on[JMAXCHAIN];
+#pragma unroll
+  for (int k = 0; k < JMAXCHAIN; k++) {
+    on[k] = mask != 0u;
+    t[k] = ldsv(T + 6 * (on[k] ? __builtin_ctz(mask) : 0));
+    mask &= mask - 1u;
+  }
+  sv v; v.a = v.b = mk3(0.f, 0.f, 0.f);
+#pragma unroll
+  for (int k = 0; k < JMAXCHAIN; k++) if (on[k]) v = v + t[k];
+  return v;
+}
 template <class L>
 JDEV void stage_walk(const JacoModelDev* m, L& s, int lane, bool markers, JProfCtx* wpc = nullptr) {
 #ifdef JACO_WALK_PROFILE   // diagnostic: split this stage over profile slots 9..14 (their usual owners are wrong in such a build)
@@ -471,6 +489,18 @@ JDEV void stage_walk(const JacoModelDev* m, L& s, int lane, bool markers, JProfC
   const int jt = s.mc.b_jtype[b], qa = s.mc.b_qadr[b], da = s.mc.b_dadr[b];
   const int a1 = s.mc.b_anc[b][0], a2 = s.mc.b_anc[b][1], a4 = s.mc.b_anc[b][2];
   const unsigned chain = isb ? m->b_chainmask[b] : 0u;   // dofs that move this body (used two stages further down)
+  // Model constants of the later phases, issued now: their L2 latency overlaps the frame composition below instead of being paid
+  // right before their use (nothing may cross the wave_sync fences on its own).
+  float Imod[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) Imod[k] = m->b_inertia[b][k];
+  const float mass = m->b_mass[b];
+  const bool isg = lane < m->ngeom;
+  const int gl = isg ? lane : 0;
+  const int gb = m->g_body[gl], km = markers ? m->g_marker[gl] : -1;
+  const float grb = m->g_rbound[gl];
+  const v3 gp0 = ld3(km >= 0 && gb < 0 ? m->g_lpos[gl] : m->g_pos[gl]);
+  const m3 gR0 = ldm(km >= 0 && gb < 0 ? m->g_lmat[gl] : m->g_mat[gl]);
   m3 R; v3 pos;
   float io[10];
 #pragma unroll
@@ -506,7 +536,7 @@ JDEV void stage_walk(const JacoModelDev* m, L& s, int lane, bool markers, JProfC
     stm(s.xmat[b], R);
     const v3 c = pos + mul(R, ld3(s.mc.b_com[b]));
     // spatial inertia about the world origin [m, m c, I_O], from the frame still in registers
-    const float* I = m->b_inertia[b];
+    const float* I = Imod;
     m3 Il;
     Il.m[0] = I[0]; Il.m[4] = I[1]; Il.m[8] = I[2];
     Il.m[1] = Il.m[3] = I[3]; Il.m[2] = Il.m[6] = I[4]; Il.m[5] = Il.m[7] = I[5];
@@ -515,7 +545,7 @@ JDEV void stage_walk(const JacoModelDev* m, L& s, int lane, bool markers, JProfC
     for (int i = 0; i < 3; i++)
 #pragma unroll
       for (int j = 0; j < 3; j++) Iw.m[3 * i + j] = T.m[3 * i] * R.m[3 * j] + T.m[3 * i + 1] * R.m[3 * j + 1] + T.m[3 * i + 2] * R.m[3 * j + 2];
-    const float mass = m->b_mass[b], cc = dot(c, c);
+    const float cc = dot(c, c);
     io[0] = mass; io[1] = mass * c.x; io[2] = mass * c.y; io[3] = mass * c.z;
     io[4] = Iw.m[0] + mass * (cc - c.x * c.x); io[5] = Iw.m[4] + mass * (cc - c.y * c.y); io[6] = Iw.m[8] + mass * (cc - c.z * c.z);
     io[7] = Iw.m[1] - mass * c.x * c.y; io[8] = Iw.m[2] - mass * c.x * c.z; io[9] = Iw.m[5] - mass * c.y * c.z;
@@ -527,24 +557,20 @@ JDEV void stage_walk(const JacoModelDev* m, L& s, int lane, bool markers, JProfC
 #pragma unroll
     for (int k = 0; k < 10; k++) { s.cinert[b][k] = io[k]; s.crb[b][k] = io[k]; }
   }
-  if (lane < m->ngeom) {   // geom poses (they share LDS with the constraint rows: every substep writes all of them)
-    const int gb = m->g_body[lane], km = markers ? m->g_marker[lane] : -1;
-    v3 gp; m3 gR;
+  if (isg) {   // geom poses (they share LDS with the constraint rows: every substep writes all of them)
+    v3 gp = gp0; m3 gR = gR0;   // static: world pose from the model
     if (gb >= 0) {            // rides on a moving body
       m3 Rg = ldm(s.xmat[gb]);
-      gp = ld3(s.xpos[gb]) + mul(Rg, ld3(m->g_pos[lane]));
-      gR = mul(Rg, ldm(m->g_mat[lane]));
+      gp = ld3(s.xpos[gb]) + mul(Rg, gp0);
+      gR = mul(Rg, gR0);
     } else if (km >= 0) {     // rides on one of the two task-layer markers (set_mocap_xyz / set_mocap_orientation between env steps)
       const float* P = s.mk + 12 * km;
-      m3 R = ldm(P + 3);
-      gp = ld3(P) + mul(R, ld3(m->g_lpos[lane]));
-      gR = mul(R, ldm(m->g_lmat[lane]));
-    } else {                  // static: world pose from the model
-      gp = ld3(m->g_pos[lane]);
-      gR = ldm(m->g_mat[lane]);
+      m3 Rm = ldm(P + 3);
+      gp = ld3(P) + mul(Rm, gp0);
+      gR = mul(Rm, gR0);
     }
     st3(s.gpos[lane], gp);
-    s.gpos[lane][3] = m->g_rbound[lane];
+    s.gpos[lane][3] = grb;
     stm(s.gmat[lane], gR);
   }
   if (lane < nv) {   // S_d: hinge -> world axis through the body origin; free joint -> 3 world translations, 3 body-frame rotations
@@ -561,9 +587,7 @@ JDEV void stage_walk(const JacoModelDev* m, L& s, int lane, bool markers, JProfC
   wave_sync();
   JWSTAMP(11);
   if (isb) {   // body velocity: sum of S_d qvel_d over the dofs that move the body (own + all ancestors'), straight from the mask
-    sv v; v.a = v.b = mk3(0, 0, 0);
-    for (unsigned mm = chain; mm; mm &= mm - 1u) v = v + ldsv(Sq + 6 * __builtin_ctz(mm));
-    stsv(s.cvel[b], v);
+    stsv(s.cvel[b], chain_sum(Sq, chain));
   }
   wave_sync();
   JWSTAMP(12);
@@ -586,7 +610,7 @@ JDEV void stage_walk(const JacoModelDev* m, L& s, int lane, bool markers, JProfC
   if (isb) {   // bias acceleration: -gravity + sum of S_d-dot qvel_d over the same dofs; then the body's RNE force right away
     sv a; a.a = mk3(0, 0, 0);
     a.b = mk3(-m->gravity[0], -m->gravity[1], -m->gravity[2]);
-    for (unsigned mm = chain; mm; mm &= mm - 1u) a = a + ldsv(Sq2 + 6 * __builtin_ctz(mm));
+    a = a + chain_sum(Sq2, chain);
     const sv v = ldsv(s.cvel[b]);
     const sv f = inert_mul(s.cinert[b], a) + cross_force(v, inert_mul(s.cinert[b], v));
     stsv(s.cfrc[b], f);
@@ -599,20 +623,32 @@ JDEV void stage_walk(const JacoModelDev* m, L& s, int lane, bool markers, JProfC
 // crb[a] = sum of cinert over a's subtree (lane = (a, component), 10 components) and RNE forces cacc[a] = sum of cfrc over
 // the subtree (6 components; cacc is dead as an acceleration by now and doubles as the summed force).  Sources and
 // destinations are different arrays, so there is no ordering between lanes.
+// sum of T[stride * x] over the bodies x of a subtree mask (at most JMAXDESC: the arm's links and fingers), loads issued together
+#define JMAXDESC 9
+JDEV float subtree_sum(const float* T, int stride, unsigned mask) {
+  float t[JMAXDESC];
+  bool on[JMAXDESC];
+#pragma unroll
+  for (int k = 0; k < JMAXDESC; k++) {
+    on[k] = mask != 0u;
+    t[k] = T[stride * (on[k] ? __builtin_ctz(mask) : 0)];
+    mask &= mask - 1u;
+  }
+  float acc = 0.f;
+#pragma unroll
+  for (int k = 0; k < JMAXDESC; k++) acc += on[k] ? t[k] : 0.f;
+  return acc;
+}
 template <class L>
 JDEV void stage_accumulate(const JacoModelDev* m, L& s, int lane) {
   const int ni = m->ninner;
   if (lane < 10 * ni) {
     const int a = s.mc.inner_body[lane / 10], c = lane % 10;
-    float acc = 0.f;
-    for (unsigned mm = s.mc.b_descmask[a]; mm; mm &= mm - 1u) acc += s.cinert[__builtin_ctz(mm)][c];
-    s.crb[a][c] = acc;
+    s.crb[a][c] = subtree_sum(&s.cinert[0][0] + c, 10, s.mc.b_descmask[a]);
   }
   if (lane < 6 * ni) {
     const int a = s.mc.inner_body[lane / 6], c = lane % 6;
-    float acc = 0.f;
-    for (unsigned mm = s.mc.b_descmask[a]; mm; mm &= mm - 1u) acc += s.cfrc[__builtin_ctz(mm)][c];
-    s.cacc[a][c] = acc;
+    s.cacc[a][c] = subtree_sum(&s.cfrc[0][0] + c, 6, s.mc.b_descmask[a]);
   }
 }
 
