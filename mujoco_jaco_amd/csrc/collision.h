@@ -485,13 +485,10 @@ JDEV void stage_collision(const JacoStepArgs& A, const JacoModelDev* m, L& s, in
     int k = ci < n1 ? s.cand[ci] : 0;
     bool keep = ci < n1;
     if (keep) {
-      int code = m->pair_code[k];
-      int g1 = code & 255, g2 = (code >> 8) & 255, t1 = (code >> 16) & 15, t2 = (code >> 20) & 15;
-      if (t1 != JG_PLANE) {
-        v3 sa = t1 == JG_SPHERE ? mk3(m->g_size[g1][0], m->g_size[g1][0], m->g_size[g1][0]) : ld3(m->g_size[g1]);
-        v3 sb = t2 == JG_SPHERE ? mk3(m->g_size[g2][0], m->g_size[g2][0], m->g_size[g2][0]) : ld3(m->g_size[g2]);
-        keep = !obb_separated(geom_pose(s, g1), sa, geom_pose(s, g2), sb);
-      }
+      const v4 q0 = ld4(reinterpret_cast<const float*>(&m->pair_obb[k])), q1 = ld4(reinterpret_cast<const float*>(&m->pair_obb[k]) + 4);
+      const int code = __builtin_bit_cast(int, q0.x);
+      int g1 = code & 255, g2 = (code >> 8) & 255, t1 = (code >> 16) & 15;
+      if (t1 != JG_PLANE) keep = !obb_separated(geom_pose(s, g1), mk3(q0.y, q0.z, q0.w), geom_pose(s, g2), mk3(q1.x, q1.y, q1.z));
     }
     wave_sync();
     unsigned long long mask = wave_ballot(keep);

@@ -32,6 +32,15 @@ struct JacoPairParam {
   int ob;            // original (unfused) body id | (fused body + 1) << 8 for g1; the same for g2 in the upper half
 };
 
+// what the oriented-box cull needs about a pair, in one 32-byte record (two 16-byte loads per surviving pair instead of a
+// pair_code load followed by dependent g_size loads)
+struct alignas(16) JacoPairObb {
+  int code;          // = pair_code
+  float sa[3];       // box half sizes of g1 (sphere: r, r, r)
+  float sb[3];       // ... of g2
+  int pad;
+};
+
 struct JacoModelDev {
   int nbody, nv, nq, nu, ngeom, npair, nsensor, nhullvert, nmocap;
   float timestep, gravity[3], tolerance, meaninertia, mpr_tolerance;
@@ -71,6 +80,7 @@ struct JacoModelDev {
 
   JacoPairParam pair[JMAXPAIR];
   int pair_code[JMAXPAIR];   // g1 | g2 << 8 | type(g1) << 16 | type(g2) << 20, for the lane-per-pair broadphase
+  JacoPairObb pair_obb[JMAXPAIR];
 
   // touch sites, one per sensor, in sensordata order
   int s_body[JNSENS], s_type[JNSENS], s_origbody[JNSENS];

@@ -208,6 +208,14 @@ int jaco_model_from_blob(const void* buf, size_t size, JacoModelDev* m, std::vec
     for (int i = 0; i < 5; i++) { P.mu[i] = (float)pmu[5 * k + i]; P.solimp[i] = (float)pimp[5 * k + i]; }
     P.solref[0] = (float)pref[2 * k]; P.solref[1] = (float)pref[2 * k + 1];
     m->pair_code[k] = g1 | (g2 << 8) | (gty[g1] << 16) | (gty[g2] << 20);
+    {
+      JacoPairObb& Q = m->pair_obb[k];
+      Q.code = m->pair_code[k]; Q.pad = 0;
+      for (int i = 0; i < 3; i++) {
+        Q.sa[i] = gty[g1] == JG_SPHERE ? m->g_size[g1][0] : m->g_size[g1][i];
+        Q.sb[i] = gty[g2] == JG_SPHERE ? m->g_size[g2][0] : m->g_size[g2][i];
+      }
+    }
     const int b1 = m->g_body[g1], b2 = m->g_body[g2];
     P.m1 = b1 >= 0 ? m->b_chainmask[b1] : 0u; P.m2 = b2 >= 0 ? m->b_chainmask[b2] : 0u;
     P.ob = m->g_origbody[g1] | ((b1 + 1) << 8) | (m->g_origbody[g2] << 16) | ((b2 + 1) << 24);

@@ -680,15 +680,24 @@ JDEV void stage_mass_bias(const JacoModelDev* m, L& s, int lane) {
     }
   }
 }
+// The actuator's model constants are fetched ahead of their use (act_fetch before the subtree sums, stage_actuation after the mass
+// matrix): one L2 round trip hidden behind two stages instead of a dependent load chain right before the torque is applied.
+struct ActParams { int ctrllimited, position, forcelimited, qadr, dof; float c0, c1, kp, f0, f1; };
+JDEV ActParams act_fetch(const JacoModelDev* m, int lane) {
+  const int a = lane < m->nu ? lane : 0;
+  ActParams P;
+  P.ctrllimited = m->a_ctrllimited[a]; P.position = m->a_position[a]; P.forcelimited = m->a_forcelimited[a]; P.qadr = m->a_qadr[a]; P.dof = m->a_dof[a];
+  P.c0 = m->a_ctrlrange[a][0]; P.c1 = m->a_ctrlrange[a][1]; P.kp = m->a_kp[a]; P.f0 = m->a_forcerange[a][0]; P.f1 = m->a_forcerange[a][1];
+  return P;
+}
 template <class L>
-JDEV void stage_actuation(const JacoModelDev* m, L& s, int lane) {
+JDEV void stage_actuation(const JacoModelDev* m, L& s, int lane, const ActParams& P) {
   if (lane < m->nu) {
-    int a = lane;
-    float c = s.ctrl[a];
-    if (m->a_ctrllimited[a]) c = fmaxf(m->a_ctrlrange[a][0], fminf(m->a_ctrlrange[a][1], c));
-    float f = m->a_position[a] ? m->a_kp[a] * (c - s.qpos[m->a_qadr[a]]) : c;
-    if (m->a_forcelimited[a]) f = fmaxf(m->a_forcerange[a][0], fminf(m->a_forcerange[a][1], f));
-    s.smooth[m->a_dof[a]] += f;
+    float c = s.ctrl[lane];
+    if (P.ctrllimited) c = fmaxf(P.c0, fminf(P.c1, c));
+    float f = P.position ? P.kp * (c - s.qpos[P.qadr]) : c;
+    if (P.forcelimited) f = fmaxf(P.f0, fminf(P.f1, f));
+    s.smooth[P.dof] += f;
   }
 }
 
@@ -723,10 +732,10 @@ JDEV void stage_limit_rows(const JacoModelDev* m, L& s, int lane) {
   bool act = false;
   float dist = 0.f, sgn = 1.f;
   int d = 0;
-  if (lane < m->nbody && m->b_jtype[lane] == JJ_HINGE && m->b_limited[lane]) {
-    float q = s.qpos[m->b_qadr[lane]];
+  if (lane < m->nbody && s.mc.b_jtype[lane] == JJ_HINGE && m->b_limited[lane]) {
+    float q = s.qpos[s.mc.b_qadr[lane]];
     float lo = q - m->b_range[lane][0], hi = m->b_range[lane][1] - q;
-    d = m->b_dadr[lane];
+    d = s.mc.b_dadr[lane];
     if (lo < 0.f) { act = true; dist = lo; sgn = 1.f; }
     else if (hi < 0.f) { act = true; dist = hi; sgn = -1.f; }
   }
@@ -1002,8 +1011,8 @@ template <class L>
 JDEV void stage_integrate_pos(const JacoModelDev* m, L& s, int lane) {
   float h = m->timestep;
   if (lane < m->nbody) {
-    int b = lane, qa = m->b_qadr[b], da = m->b_dadr[b];
-    if (m->b_jtype[b] == JJ_HINGE) {
+    int b = lane, qa = s.mc.b_qadr[b], da = s.mc.b_dadr[b];
+    if (s.mc.b_jtype[b] == JJ_HINGE) {
       s.qpos[qa] += h * s.qvel[da];
     } else {
       for (int k = 0; k < 3; k++) s.qpos[qa + k] += h * s.qvel[da + k];
@@ -1213,6 +1222,7 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
     if (A.dbg && env == A.dbg_env && sub == nsub - 1 && lane < m->ngeom) for (int k = 0; k < 3; k++) A.dbg[JDBG_GPOS + 3 * lane + k] = s.gpos[lane][k];
     JSTAMP(0);
     JSTAMP(1);
+    const ActParams actp = act_fetch(m, lane);
     stage_accumulate(m, s, lane);
     wave_sync();
     stage_mass_bias(m, s, lane);
@@ -1222,7 +1232,7 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
       if (lane >= 6 && lane < nu) s.ctrl[lane] = 0.6f;
       wave_sync();
     }
-    stage_actuation(m, s, lane);
+    stage_actuation(m, s, lane, actp);
     JSTAMP(2);
     // collision first, then the row builders: the constraint rows share LDS with the geom poses and the broadphase survivors,
     // which are dead once the contact list exists.  (Actuation touches neither: no synchronisation of its own.)
