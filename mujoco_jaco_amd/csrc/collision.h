@@ -446,14 +446,11 @@ JDEV bool mpr_penetration(const JacoStepArgs& A, const JacoModelDev* m, const L&
 
 // ---------------------------------------------------------------- stage C
 template <class L>
-JDEV void stage_collision(const JacoStepArgs& A, const JacoModelDev* m, L& s, int lane, unsigned& flags, JProfCtx& pc) {
+JDEV void stage_collision(const JacoStepArgs& A, const JacoModelDev* m, L& s, int lane, unsigned& flags, JProfCtx& pc, const int (&codes)[JMAXPAIR / 64]) {
   (void)pc;
-  // phase 1: bounding spheres, lane = pair; the pair codes of all chunks are fetched up front (independent loads)
+  // phase 1: bounding spheres, lane = pair; the pair codes of all chunks were fetched ahead (stage_prefetch)
   int n1 = 0;
-  int codes[JMAXPAIR / 64];
   const int npair = m->npair;
-#pragma unroll
-  for (int ch = 0; ch < JMAXPAIR / 64; ch++) codes[ch] = m->pair_code[ch * 64 + lane];   // (zero-padded to JMAXPAIR: straight-line loads)
 #pragma unroll
   for (int ch = 0; ch < JMAXPAIR / 64; ch++) {
     if (ch * 64 >= npair) break;

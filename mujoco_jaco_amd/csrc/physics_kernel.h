@@ -652,21 +652,39 @@ JDEV void stage_accumulate(const JacoModelDev* m, L& s, int lane) {
   }
 }
 
+// Per-lane model constants of the stages after the tree walk, fetched in one go right after it: their L2 round trip is hidden
+// behind the subtree sums and the mass matrix instead of being paid, one dependent load at a time, in front of every stage.
+struct StagePrefetch {
+  int codes[JMAXPAIR / 64];   // stage C, phase 1: this lane's pair of every 64-pair chunk
+  int mp0, mp1;               // stage M: this lane's mass-matrix entries
+  float damping;              // joint damping of dof `lane`
+  int limited; float lo, hi;  // joint limit of body `lane`
+};
+JDEV StagePrefetch stage_prefetch(const JacoModelDev* m, int lane) {
+  StagePrefetch P;
+#pragma unroll
+  for (int ch = 0; ch < JMAXPAIR / 64; ch++) P.codes[ch] = m->pair_code[ch * 64 + lane];   // (zero-padded to JMAXPAIR: straight-line loads)
+  P.mp0 = m->mpair[lane]; P.mp1 = m->mpair[64 + lane];                                     // (zero-padded to JMAXMPAIR)
+  P.damping = m->d_damping[lane < JNV ? lane : 0];
+  const int b = lane < JNB ? lane : 0;
+  P.limited = m->b_limited[b]; P.lo = m->b_range[b][0]; P.hi = m->b_range[b][1];
+  return P;
+}
 // ---------------------------------------------------------------- stage M: mass matrix, bias, actuation
 // lane = dof: F_d = Ic(body d) S_d and the bias force; then lane = structurally non-zero entry (d, j), j an ancestor-or-self
 // dof of d: M[d][j] = S_j . F_d.  Scratch: the not-yet-built constraint-row area s.J.
 template <class L>
-JDEV void stage_mass_bias(const JacoModelDev* m, L& s, int lane) {
+JDEV void stage_mass_bias(const JacoModelDev* m, L& s, int lane, const StagePrefetch& pf) {
   float* Fd = s.J;   // [JNV][6]
   const int nmp = m->nmpair;
-  int code0 = m->mpair[lane], code1 = m->mpair[64 + lane];   // (table is zero-padded to JMAXMPAIR)
+  int code0 = pf.mp0, code1 = pf.mp1;
   if (lane < m->nv) {
     int d = lane, b = s.mc.d_body[d];
     sv S = ldsv(s.cdof[d]);
     stsv(Fd + 6 * d, inert_mul(s.crb[b], S));
     float bias = dot(S, ldsv(s.cacc[b]));
     s.bias[d] = bias;
-    s.smooth[d] = -m->d_damping[d] * s.qvel[d] - bias;
+    s.smooth[d] = -pf.damping * s.qvel[d] - bias;
   }
   wave_sync();
 #pragma unroll
@@ -728,13 +746,13 @@ JDEV float row_params(const float* solref, const float* solimp, float pos, float
 
 // joint limits: lane = body; one row per violated limit, compacted with a ballot
 template <class L>
-JDEV void stage_limit_rows(const JacoModelDev* m, L& s, int lane) {
+JDEV void stage_limit_rows(const JacoModelDev* m, L& s, int lane, const StagePrefetch& pf) {
   bool act = false;
   float dist = 0.f, sgn = 1.f;
   int d = 0;
-  if (lane < m->nbody && s.mc.b_jtype[lane] == JJ_HINGE && m->b_limited[lane]) {
+  if (lane < m->nbody && s.mc.b_jtype[lane] == JJ_HINGE && pf.limited) {
     float q = s.qpos[s.mc.b_qadr[lane]];
-    float lo = q - m->b_range[lane][0], hi = m->b_range[lane][1] - q;
+    float lo = q - pf.lo, hi = pf.hi - q;
     d = s.mc.b_dadr[lane];
     if (lo < 0.f) { act = true; dist = lo; sgn = 1.f; }
     else if (hi < 0.f) { act = true; dist = hi; sgn = -1.f; }
@@ -1223,9 +1241,10 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
     JSTAMP(0);
     JSTAMP(1);
     const ActParams actp = act_fetch(m, lane);
+    const StagePrefetch pf = stage_prefetch(m, lane);
     stage_accumulate(m, s, lane);
     wave_sync();
-    stage_mass_bias(m, s, lane);
+    stage_mass_bias(m, s, lane, pf);
     wave_sync();
     if (emode == 3 && !held_pending) {   // every held substep follows a sim.forward(): the controller sees *this* state's M, J, bias
       stage_osc(m, s, lane, flags);
@@ -1238,17 +1257,17 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
     // which are dead once the contact list exists.  (Actuation touches neither: no synchronisation of its own.)
     unsigned cflags = 0;
     if (!A.disable_contact) {
-      stage_collision(A, m, s, lane, cflags, pc);
+      stage_collision(A, m, s, lane, cflags, pc, pf.codes);
       wave_sync();
       JSTAMP(4);
-      stage_limit_rows(m, s, lane);
+      stage_limit_rows(m, s, lane, pf);
       wave_sync();
       JSTAMP(3);
       stage_contact_rows(m, s, lane, cflags);
       wave_sync();
       JSTAMP(5);
     } else {
-      stage_limit_rows(m, s, lane);
+      stage_limit_rows(m, s, lane, pf);
       if (lane == 0) { s.ncon = 0; s.ncand = 0; }
       wave_sync();
     }
@@ -1280,7 +1299,7 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
     float smooth = lane < nv ? s.smooth[lane] : 0.f;
     float qas = 0.f;   // (qacc_smooth is no longer formed; kept in the dump layout)
     wave_sync();
-    const float hdamp = (m->has_damping && lane < nv) ? m->timestep * m->d_damping[lane] : 0.f;
+    const float hdamp = (m->has_damping && lane < nv) ? m->timestep * pf.damping : 0.f;
     NewtonOut nw = stage_newton(m, s, mrow, smooth, hdamp, lane, pc);
     JSTAMP(6);
     iters = nw.iters & 255;
