@@ -88,6 +88,7 @@ JDEV v3 support_geom(const JacoStepArgs& A, const JacoModelDev* m, const L& s, i
     }
     float bv;
     int win = wave_argmax(best, bi, &bv);
+    win = win < nvert ? win : 0;   // (a non-finite direction beats nothing: stay inside the table; the env is quarantined by the epilogue)
     const float* v = A.hull + 4 * (size_t)(adr + win);
     sp = mk3(v[0], v[1], v[2]);
   }
@@ -317,6 +318,7 @@ JDEV Sup mpr_support(const JacoStepArgs& A, const MprGeom& G1, const MprGeom& G2
     int wl;
     if (tab1) { bv = wave_max(best1); wl = ffs64(wave_ballot(best1 == bv && bi1 != 0x7fffffff)); }   // slots are in index order: lowest lane = lowest index
     else { const int win = wave_argmax(best1, bi1, &bv); wl = ffs64(wave_ballot(bi1 == win)); }      // the lane that holds the winning vertex
+    wl = wl < 0 ? 0 : wl;   // (no lane matches for a non-finite direction)
     sp1 = mk3(wave_bcast(c1.x, wl), wave_bcast(c1.y, wl), wave_bcast(c1.z, wl));
   } else sp1 = support_prim(G1, l1);
   if (n2 > 0) {
@@ -324,6 +326,7 @@ JDEV Sup mpr_support(const JacoStepArgs& A, const MprGeom& G1, const MprGeom& G2
     int wl;
     if (tab2) { bv = wave_max(best2); wl = ffs64(wave_ballot(best2 == bv && bi2 != 0x7fffffff)); }
     else { const int win = wave_argmax(best2, bi2, &bv); wl = ffs64(wave_ballot(bi2 == win)); }
+    wl = wl < 0 ? 0 : wl;
     sp2 = mk3(wave_bcast(c2.x, wl), wave_bcast(c2.y, wl), wave_bcast(c2.z, wl));
   } else sp2 = support_prim(G2, l2);
   Sup r;
@@ -496,9 +499,23 @@ JDEV void stage_collision(const JacoStepArgs& A, const JacoModelDev* m, L& s, in
   JSTAMP(10);
   // phase 3: narrowphase, whole wave per candidate
   int ncon = 0;
+  // the first 64 candidates' pair index, code and contact bookkeeping are fetched by lane c in one go and broadcast inside the
+  // loop (instead of an LDS read + two dependent scalar loads in front of every narrowphase call)
+  const int pkA = s.cand[lane < ncand ? lane : 0];
+  const int codeA = m->pair_code[pkA];
+  const unsigned m1A = m->pair[pkA].m1, m2A = m->pair[pkA].m2;
+  const int obA = m->pair[pkA].ob, dimA = m->pair[pkA].condim;
   for (int c = 0; c < ncand; c++) {
-    int pk = wave_uniform_i(s.cand[c]);
-    int code = m->pair_code[pk];
+    int pk, code, pob, pdim;
+    unsigned pm1, pm2;
+    if (c < 64) {
+      pk = wave_bcast_i(pkA, c); code = wave_bcast_i(codeA, c);
+      pm1 = (unsigned)wave_bcast_i((int)m1A, c); pm2 = (unsigned)wave_bcast_i((int)m2A, c); pob = wave_bcast_i(obA, c); pdim = wave_bcast_i(dimA, c);
+    } else {
+      pk = wave_uniform_i(s.cand[c]); code = m->pair_code[pk];
+      const JacoPairParam& P = m->pair[pk];
+      pm1 = P.m1; pm2 = P.m2; pob = P.ob; pdim = P.condim;
+    }
     int g1 = code & 255, g2 = (code >> 8) & 255, t1 = (code >> 16) & 15, t2 = (code >> 20) & 15;
     int before = ncon;
     if (t1 == JG_PLANE) {
@@ -517,9 +534,8 @@ JDEV void stage_collision(const JacoStepArgs& A, const JacoModelDev* m, L& s, in
       push_contacts(s, hit && lane == 0, -depth, pos, dir, pk, ncon, flags, 1);
     }
     if (ncon > before) {   // dof chain masks / body ids of the two geoms, for the row builder and the touch stage
-      const JacoPairParam& P = m->pair[pk];
-      int c = before + lane;
-      if (c < ncon) { s.c_m1[c] = P.m1; s.c_m2[c] = P.m2; s.c_ob[c] = P.ob; s.c_dim[c] = P.condim; }
+      int cc = before + lane;
+      if (cc < ncon) { s.c_m1[cc] = pm1; s.c_m2[cc] = pm2; s.c_ob[cc] = pob; s.c_dim[cc] = pdim; }
     }
   }
   if (lane == 0) { s.ncon = ncon; s.ncand = ncand; }

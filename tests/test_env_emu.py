@@ -176,3 +176,16 @@ def test_reaching_task_matches_oracle_env(names, model_arrays):
     z = np.zeros(6, np.float32)
     _, _, d = e2.env_step(z); assert d[0] == 0
     _, r, d = e2.env_step(z); assert d[0] == 1 and abs(r[0] - (-10.0)) < 0.2
+
+
+def test_non_finite_state_is_quarantined_not_followed_out_of_bounds(names, model_arrays):
+    """A NaN / Inf anywhere in the state must neither index outside a table (a hull support scan used to return index
+    0x7fffffff for a NaN direction) nor loop forever: the env ends its episode with reward 0 and JACO_FLAG_NAN and freezes."""
+    for adr, arr, val in ((2, "qvel", np.nan), (12, "qpos", np.nan), (4, "qvel", np.inf)):
+        e, _ = _pair(names, model_arrays, 4, 6)
+        e.forward()
+        getattr(e, arr)[0, adr] = val
+        obs, rew, done = e.env_step(np.zeros(7, np.float32))
+        assert done[0] == 1 and rew[0] == 0 and (e.flags[0] & 8) and np.isfinite(obs).all(), (arr, adr)
+        obs, rew, done = e.env_step(np.zeros(7, np.float32))
+        assert done[0] == 1 and rew[0] == 0

@@ -402,3 +402,34 @@ def test_full_size_env_level_config3_and_config4():
             del env
         for x, y in zip(*outs):
             assert torch.equal(x, y)                                                         # bitwise deterministic
+
+
+def test_nan_state_is_quarantined():
+    """SURVEY section 5, failure row: an env whose state goes non-finite ends its episode inside jaco_step (done = 1, reward 0,
+    JACO_FLAG_NAN, finite observation row), stays frozen, and the vectorised adapter resets it with the other finished envs."""
+    from mujoco_jaco_amd.vec_env import JacoVecEnv
+    B = 256
+    venv = JacoVecEnv(B, task="picking", seed=4)
+    venv.reset()
+    env = venv.env
+    q, v, w = env.sim.get_state()
+    bad = torch.tensor([3, 77, 200], device=env.device)
+    v[bad, 2] = float("nan")                    # poison three envs' joint velocities (hints are cleared by set_state)
+    env.sim.set_state(q, v, w)
+    a = torch.zeros(B, 7, device=env.device)
+    obs, rew, done, _ = env.step(a)
+    assert done[bad].all() and (rew[bad] == 0).all() and torch.isfinite(obs).all()
+    assert ((env.sim.flags()[bad] & 8) != 0).all() and int(done.sum()) == 3
+    q1 = env.sim.get_state()[0].clone()
+    obs, rew, done, _ = env.step(a)             # frozen until reset
+    assert done[bad].all() and (rew[bad] == 0).all()
+    nanmask = torch.isnan(q1)
+    assert torch.equal(env.sim.get_state()[0][bad][~nanmask[bad]], q1[bad][~nanmask[bad]])
+    # through the adapter: same poison, the finished (quarantined) envs come back reset and are counted
+    venv.reset()
+    q, v, w = env.sim.get_state(); v[bad, 2] = float("nan"); env.sim.set_state(q, v, w)
+    obs, rew, done, infos = venv.step(a)
+    assert infos["quarantined"] == 3 and done[bad].all() and torch.isfinite(obs).all()
+    assert torch.isfinite(env.sim.get_state()[0]).all() and torch.isfinite(env.sim.get_state()[1]).all()
+    obs, rew, done, infos = venv.step(a)
+    assert not done[bad].any() and infos["quarantined"] == 0
