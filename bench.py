@@ -51,6 +51,9 @@ def parse_args(argv=None):
     ap.add_argument("--action-scale", type=float, default=1.0, help="actions are U(-1,1)^7 times this (1.0 = the headline)")
     ap.add_argument("--preroll", type=int, default=40, help="untimed env steps (with masked resets) before warmup")
     ap.add_argument("--extra-scales", default="0.3,0.05", help="action scales also timed (briefly, each in a child process before the headline run); '' = none")
+    ap.add_argument("--policy", default=None,
+                    help="actions from one of the reference's shipped policies instead of U(-1,1): 'picking' | 'placing' (tests/golden/policy_<task>.npz) or a policy.zip / .npz path; the policy's forward pass is inside the timed step")
+    ap.add_argument("--policy-leg", default="picking", help="policy also timed (briefly, in a child process before the headline run); '' = none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--drift-gpu-leg", default=None, help=argparse.SUPPRESS)   # internal: child process that steps the HIP path on the drift workload
     ap.add_argument("--dry-gather", action="store_true",
@@ -90,6 +93,25 @@ def small_action_runs(args):
             out[sc] = None
             print("bench.py: action scale %s run failed: %r" % (sc, e), file=sys.stderr)
     return out
+
+
+def policy_run(args):
+    """Throughput with the reference's shipped policy choosing the actions (deterministic HPC forward pass inside the timed step,
+    episodes in every phase after a long pre-roll): the regime the env is used in once a policy has converged.  Child process, as above."""
+    if not args.policy_leg or args.policy:
+        return None
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--policy", args.policy_leg, "--task", args.policy_leg, "--steps", "10", "--warmup", "2",
+           "--preroll", "180", "--batch", str(args.batch), "--model", args.model, "--no-cpu-baseline", "--extra-scales", "", "--policy-leg", ""]
+    if args.frame_skip is not None:
+        cmd += ["--frame-skip", str(args.frame_skip)]
+    try:
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        line = json.loads(p.stdout.strip().splitlines()[-1])
+        return {"policy": args.policy_leg, "value": line["value"], "ms_per_step": line["ms_per_step"], "done_fraction": line["config"]["done_fraction"],
+                "mean_rows": line["config"]["mean_rows"], "heavy_tier_fraction": line["config"]["heavy_tier_fraction"], "preroll_steps": 180}
+    except Exception as e:
+        print("bench.py: policy run failed: %r" % (e,), file=sys.stderr)
+        return None
 
 
 DRIFT_MARKS = (100, 300, 1000)
@@ -214,6 +236,7 @@ def main():
     if args.drift_gpu_leg:
         sys.exit(drift_gpu_leg(args))
     small = small_action_runs(args) if (args.level == "env" and world == 1 and args.extra_scales) else {}
+    pol_leg = policy_run(args) if (args.level == "env" and world == 1) else None
     drift_npz = None
     if world == 1 and not args.no_cpu_baseline:   # the HIP leg of the drift metric, in a child process before this one touches the GPU
         drift_npz = os.path.join(ROOT, "gpurun_out", "bench_drift_gpu_%d.npz" % os.getpid())
@@ -257,11 +280,22 @@ def main():
         scale = [float(args.action_scale)]
         nact = genv.action_space.shape[0]
 
+        pol, cur_obs = None, [None]
+        if args.policy:
+            from mujoco_jaco_amd.policy import HPCPolicy
+            path = args.policy if os.path.exists(args.policy) else os.path.join(ROOT, "tests", "golden", "policy_%s.npz" % args.policy)
+            pol = HPCPolicy.load(path, device=dev)
+            cur_obs[0] = genv.make_observation()
+
         def step():
-            a = (torch.rand(B, nact, device=dev, generator=gen) * 2 - 1) * scale[0]
+            if pol is not None:
+                a, _ = pol.predict(cur_obs[0])
+            else:
+                a = (torch.rand(B, nact, device=dev, generator=gen) * 2 - 1) * scale[0]
             o, r, d, _ = genv.step(a)
             done_count.add_(d.sum())
-            genv.reset(d)          # masked jaco_reset of the finished envs: no host sync; their obs rows become the new episode's first
+            o = genv.reset(d)      # masked jaco_reset of the finished envs: no host sync; their obs rows become the new episode's first
+            cur_obs[0] = o
             if world > 1:          # one collective per rollout step: concatenate the observation rows of all shards
                 gather(o)
     else:
@@ -328,20 +362,24 @@ def main():
                 wait = pm["SQ_WAIT_ANY"] / pm["SQ_WAVE_CYCLES"]
         except Exception:
             pass
+        if args.level != "env":
+            workload_desc = "random motor ctrl, ctrl-level jaco_physics_step"
+        else:
+            source = ("actions from the reference's shipped '%s' policy (deterministic forward pass inside the timed step)" % args.policy) if args.policy \
+                else "fresh random actions x %g each step" % args.action_scale
+            workload_desc = source + ", env-level jaco_step (OSC + %d substeps + obs/reward/done) + masked reset of finished envs" % fs
         out = {
             "metric": "env-steps/sec at batch 65 536 (full Jaco + gripper + contacts)",
             "value": world * B * args.steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "config3: %d envs/GPU, %s, %s reset distribution, %s"
-                                   % (B, args.model, args.task, "fresh random actions x %g each step, env-level jaco_step (OSC + %d substeps + obs/reward/done) + masked reset of finished envs" % (args.action_scale, fs)
-                                      if args.level == "env" else "random motor ctrl, ctrl-level jaco_physics_step"),
+            "config": {"workload": "config3: %d envs/GPU, %s, %s reset distribution, %s" % (B, args.model, args.task, workload_desc),
                        "level": args.level, "action_scale": args.action_scale, "preroll_steps": args.preroll if args.level == "env" else 0,
                        "envs_per_gpu": B, "frame_skip": fs, "substeps_per_s": world * B * args.steps * fs / dt,
                        "done_fraction": done_fraction,
-                       "small_action_env_steps_per_s": small,
+                       "small_action_env_steps_per_s": small, "policy_driven": pol_leg,
                        "sharding": "independent env shards per rank" + ("; one all_gather of [B,%d] f32 rows per step" % (26 if args.level == "env" else env.nq) if world > 1 else ""),
-                       "mean_contacts": float(stats[0]), "mean_rows": float(stats[1]), "mean_newton_iters": float(stats[2]), "flags_or": flags,
+                       "mean_contacts": float(stats[0]), "mean_rows": float(stats[1]), "mean_newton_iters": float(stats[2]), "flags_or": flags & 0xff,
                        "heavy_tier_fraction": heavy},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "jaco_physics_kernel", "kernel_ms": kern_ms, "launches": launches, "step_launch_set_ms": step_ms,

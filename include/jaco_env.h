@@ -38,6 +38,7 @@ extern "C" {
 #define JACO_FLAG_SOLVER_MAXITER 16u
 #define JACO_FLAG_HEAVY_TIER 32u     /* informational: stepped by the 128- or 256-row tier at least once (not an error) */
 #define JACO_FLAG_TIER_RETURN 128u   /* informational: the heavy tier gave the env back to the light code in mid-step (overflow was transient) */
+#define JACO_FLAG_BAIL_CAUSE_SHIFT 8  /* informational, bits 8..16: which capacity (bit 0 contacts, 1 rows, 2 candidates) made tier 0 / 1 / 2 (3 bits each) hand the env on */
 #define JACO_FLAG_OSC_SINGULAR 64u   /* informational: |det(J M^-1 J^T)| < 1e-3, the controller used its pseudo-inverse branch */
 
 /* task ids (env_script/env_mujoco.py:18-23; only picking/placing return the 4-tuple step() unpacks) */
@@ -147,6 +148,9 @@ int jaco_set_option(JacoHandle* h, const char* name, double value);
  * the last substep (layout: JDBG_* in csrc/physics_kernel.h) to host memory; synchronises. */
 int jaco_physics_step_debug(JacoHandle* h, const float* ctrl_dev, int nsub, int env, float* dump_host, int dump_floats);
 int jaco_debug_dump_floats(void);
+/* Diagnostic: control words of the tier queues after the last launch (per tier: envs queued, slots claimed by resident workers,
+ * workers started / kept in reserve, envs queued before the launch from last step's hints); returns the number of words. */
+int jaco_debug_queue_words(JacoHandle* h, int32_t* out_host, int n);
 
 /* Average device time of the light-tier kernel (jaco_physics_kernel: the dominant kernel, what rocprofv3 --stats lists under that
  * name) over the step launches since jaco_enable_timing, measured with HIP events on the stream the kernel was launched on (bench.py

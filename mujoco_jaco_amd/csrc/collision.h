@@ -448,34 +448,56 @@ JDEV bool mpr_penetration(const JacoStepArgs& A, const JacoModelDev* m, const L&
 }
 
 // ---------------------------------------------------------------- stage C
-template <class L>
-JDEV void stage_collision(const JacoStepArgs& A, const JacoModelDev* m, L& s, int lane, unsigned& flags, JProfCtx& pc, const int (&codes)[JMAXPAIR / 64]) {
-  (void)pc;
-  // phase 1: bounding spheres, lane = pair; the pair codes of all chunks were fetched ahead (stage_prefetch)
-  int n1 = 0;
-  const int npair = m->npair;
+// bounding-sphere test of the pairs of chunks 4 G .. 4 G + 3 (lane = pair); survivors are appended to s.cand in pair order
+template <int G, bool PLANES, class L>
+JDEV void sphere_group(L& s, const int (&codes)[JMAXPAIR / 64], int npair, int lane, int& n1) {
+  v4 pa[4], pb[4];
+  v3 nrm[4];
 #pragma unroll
-  for (int ch = 0; ch < JMAXPAIR / 64; ch++) {
-    if (ch * 64 >= npair) break;
-    int k = ch * 64 + lane;
-    bool valid = k < npair;
-    int code = codes[ch];
-    int g1 = code & 255, g2 = (code >> 8) & 255, t1 = (code >> 16) & 15;
-    v4 pa = ld4(s.gpos[g1]), pb = ld4(s.gpos[g2]);
-    v3 df = mk3(pb.x - pa.x, pb.y - pa.y, pb.z - pa.z);
-    // branch-free: every lane also evaluates the plane form (normal = third column of g1's frame)
-    v3 nrm = mk3(s.gmat[g1][2], s.gmat[g1][5], s.gmat[g1][8]);
-    keep_loaded(nrm.x, nrm.y, nrm.z);
-    float r = pa.w + pb.w, dn = dot(df, nrm), dd = dot(df, df);
-    const bool plane = t1 == JG_PLANE;
-    float lhs = plane ? dn : dd, rhs = plane ? pb.w : r * r;
-    bool pass = !(lhs > rhs) & valid;
-    unsigned long long mask = wave_ballot(pass);
-    int idx = n1 + wave_prefix_count(mask);
+  for (int c = 0; c < 4; c++) {
+    const int code = codes[4 * G + c];
+    const int g1 = code & 255, g2 = (code >> 8) & 255;
+    pa[c] = ld4(s.gpos[g1]); pb[c] = ld4(s.gpos[g2]);
+    if (PLANES) {   // branch-free: every lane also evaluates the plane form (normal = third column of g1's frame)
+      nrm[c] = mk3(s.gmat[g1][2], s.gmat[g1][5], s.gmat[g1][8]);
+      keep_loaded(nrm[c].x, nrm[c].y, nrm[c].z);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    const int k = (4 * G + c) * 64 + lane;
+    const bool valid = k < npair;
+    const int t1 = (codes[4 * G + c] >> 16) & 15;
+    const v3 df = mk3(pb[c].x - pa[c].x, pb[c].y - pa[c].y, pb[c].z - pa[c].z);
+    const float r = pa[c].w + pb[c].w, dd = dot(df, df);
+    float lhs = dd, rhs = r * r;
+    if (PLANES) {
+      const float dn = dot(df, nrm[c]);
+      const bool plane = t1 == JG_PLANE;
+      lhs = plane ? dn : dd; rhs = plane ? pb[c].w : r * r;
+    }
+    const bool pass = !(lhs > rhs) & valid;
+    const unsigned long long mask = wave_ballot(pass);
+    const int idx = n1 + wave_prefix_count(mask);
     if (pass && idx < L::Caps::MAXCAND) s.cand[idx] = k;
     n1 += popc64(mask);
   }
+}
+
+template <class L>
+JDEV void stage_collision(const JacoStepArgs& A, const JacoModelDev* m, L& s, int lane, unsigned& flags, JProfCtx& pc, const int (&codes)[JMAXPAIR / 64]) {
+  (void)pc;
+  // phase 1: bounding spheres, lane = pair; the pair codes of all chunks were fetched ahead (stage_prefetch).  Four chunks per
+  // straight-line group: all their LDS gathers are in flight before the first ballot.  Plane pairs sit in the leading chunks
+  // only (pairs are ordered by geom id and planes are static world geoms), so the groups behind them skip the plane form.
+  int n1 = 0;
+  const int npair = m->npair, plane_chunks = m->plane_chunks;
+  static_assert(JMAXPAIR == 768, "three groups of four 64-pair chunks");
+  if (0 < plane_chunks) sphere_group<0, true>(s, codes, npair, lane, n1); else sphere_group<0, false>(s, codes, npair, lane, n1);
+  if (256 < npair) { if (4 < plane_chunks) sphere_group<1, true>(s, codes, npair, lane, n1); else sphere_group<1, false>(s, codes, npair, lane, n1); }
+  if (512 < npair) { if (8 < plane_chunks) sphere_group<2, true>(s, codes, npair, lane, n1); else sphere_group<2, false>(s, codes, npair, lane, n1); }
   JSTAMP(9);
+  if (lane == 0) s.nsphere = n1;
   if (n1 > L::Caps::MAXCAND) { flags |= JFLAG_CAND_OVERFLOW; n1 = L::Caps::MAXCAND; }
   wave_sync();
   // phase 2: oriented-box cull of the survivors, lane = survivor; compacted in place (order preserved)

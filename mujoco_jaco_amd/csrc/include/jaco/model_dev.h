@@ -43,6 +43,7 @@ struct alignas(16) JacoPairObb {
 
 struct JacoModelDev {
   int nbody, nv, nq, nu, ngeom, npair, nsensor, nhullvert, nmocap;
+  int plane_chunks;   // 64-pair chunks [0, plane_chunks) hold every pair whose first geom is a plane (pairs are in geom order)
   float timestep, gravity[3], tolerance, meaninertia, mpr_tolerance;
   int iterations, ls_iterations, mpr_iterations;
   int mpr_output;   // 1 (default): portal-plane normal + support depth; 0: libccd's closest point of the final portal triangle

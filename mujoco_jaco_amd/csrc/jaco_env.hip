@@ -398,7 +398,7 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
   A.ctrl = ctrl ? ctrl : h->qvel;   // env modes compute ctrl in-kernel; the pointer only has to be readable
   A.sensordata = h->sensordata; A.flags = h->flags; A.stats = h->stats; A.nenv = h->num_envs; A.nsub = nsub;
   A.disable_contact = h->disable_contact; A.no_tier_return = !h->tier_return; A.dbg = dbg; A.dbg_env = dbg_env; A.prof = h->prof;
-  A.remaining = h->remaining; A.light_left = h->qctl + JQ_LIGHT; A.hint = h->use_hints ? h->hint : nullptr;
+  A.remaining = h->remaining; A.light_left = h->qctl + JQ_LIGHT; A.hint = h->use_hints ? h->hint : nullptr; A.hint_mode = h->use_hints;
   for (int t = 0; t < 3; t++) { A.q[t].list = h->qlist + (size_t)t * h->num_envs; A.q[t].count = h->qctl + JQ_COUNT + t; A.q[t].taken = h->qctl + JQ_TAKEN + t; A.q[t].limit = h->qctl + JQ_LIMIT + t; A.q[t].reserve = h->qctl + JQ_RESERVE + t; }
   A.routed_mark = nullptr; A.launch_id = ++h->launch_id;
   A.env_mode = io.mode; A.task_id = h->task; A.nact = h->task == JACO_TASK_REACHING ? 6 : 7; A.seed = h->seed;
@@ -616,6 +616,14 @@ extern "C" int jaco_set_frame_skip(JacoHandle* h, int frame_skip) {
 }
 
 extern "C" int jaco_debug_dump_floats(void) { return JDBG_SIZE; }
+// Diagnostic: the tier queues' control words of the last launch (JQ_* layout above), copied to host; synchronises.
+extern "C" int jaco_debug_queue_words(JacoHandle* h, int32_t* out_host, int n) {
+  if (!h || !out_host || n < JQ_WORDS) return JACO_EINVAL;
+  ENTER(h);
+  HIPCHK(h, hipDeviceSynchronize());
+  HIPCHK(h, hipMemcpy(out_host, h->qctl, JQ_WORDS * sizeof(int), hipMemcpyDeviceToHost));
+  return JQ_WORDS;
+}
 extern "C" int jaco_physics_step_debug(JacoHandle* h, const float* ctrl_dev, int nsub, int env, float* dump_host, int dump_floats) {
   if (!h || !dump_host || dump_floats < JDBG_SIZE || env < 0 || env >= h->num_envs) return JACO_EINVAL;
   ENTER(h);
@@ -661,7 +669,7 @@ extern "C" int jaco_set_option(JacoHandle* h, const char* name, double v) {
   if (!strcmp(name, "concurrent_heavy")) { h->concurrent = v != 0; return JACO_OK; }
   if (!strcmp(name, "tier_return")) { h->tier_return = v != 0; return JACO_OK; }
   if (!strcmp(name, "heavy_workers")) { h->workers = v < 1 ? 1 : (int)v; return JACO_OK; }
-  if (!strcmp(name, "hints")) { h->use_hints = v != 0; return JACO_OK; }
+  if (!strcmp(name, "hints")) { h->use_hints = v < 0 ? 0 : (v > 2 ? 2 : (int)v); return JACO_OK; }   // 0 off, 1 biggest tier of the last step, 2 tier of its last substep
   if (!strcmp(name, "obs_mode")) { if (v != 0 && v != 1) { h->err = "jaco_set_option: obs_mode must be 0 or 1"; return JACO_EINVAL; } h->obs_mode = (int)v; return JACO_OK; }
   else if (!strcmp(name, "iterations")) m.iterations = (int)v;
   else if (!strcmp(name, "tolerance")) m.tolerance = (float)v;

@@ -220,6 +220,8 @@ int jaco_model_from_blob(const void* buf, size_t size, JacoModelDev* m, std::vec
     P.m1 = b1 >= 0 ? m->b_chainmask[b1] : 0u; P.m2 = b2 >= 0 ? m->b_chainmask[b2] : 0u;
     P.ob = m->g_origbody[g1] | ((b1 + 1) << 8) | (m->g_origbody[g2] << 16) | ((b2 + 1) << 24);
   }
+  m->plane_chunks = 0;   // (no assumption on where the plane pairs sit: the last one decides)
+  for (int k = 0; k < np; k++) if (((m->pair_code[k] >> 16) & 15) == JG_PLANE) m->plane_chunks = k / 64 + 1;
   // ---- touch sites
   const int32_t *sb = B.i32("f_site_body", ns), *sty = B.i32("f_site_type", ns), *sob = B.i32("f_site_origbody", ns);
   const double *sp = B.f64("f_site_pos", 3 * ns), *sq = B.f64("f_site_quat", 4 * ns), *ssz = B.f64("f_site_size", 3 * ns);

@@ -26,12 +26,16 @@
 template <int MAXEFC_, int MAXCON_, int MAXCAND_>
 struct JacoCaps {
   static_assert(MAXEFC_ % 64 == 0, "rows are dealt out 64 at a time (one per lane): the row capacity must be a multiple of 64");
+  static_assert(MAXCAND_ <= MAXEFC_ * 25 - 520 - 256 - 576, "the candidate list must fit behind the geom poses in the constraint-row area");
   static constexpr int MAXEFC = MAXEFC_, MAXCON = MAXCON_, MAXCAND = MAXCAND_, NR = MAXEFC_ / 64;
 };
-typedef JacoCaps<64, 32, 128> JacoLight;   // (candidates = bounding-sphere survivors: closed fingers alone contribute > 64)
-typedef JacoCaps<128, 48, 128> JacoMedium;  // 2 rows per lane: the EE axis sticks resting on the "hand" marker's sticks add ~36 rows to the usual 32
-typedef JacoCaps<256, 64, 256> JacoHeavy;
-typedef JacoCaps<512, 128, 256> JacoHuge;    // 8 rows per lane: a reset that puts the hand inside the pedestal (1 % of picking resets: up to ~90 contacts / ~410 rows)
+// Candidates = bounding-sphere survivors (closed fingers alone contribute > 64; with the EE sticks on the marker's sticks 130-200): their
+// list shares LDS with the constraint rows, which are bigger, so its capacity costs nothing -- and it must not be what sends
+// an env to a bigger tier (round 2 found 74 % of the envs of a small-action rollout in the heavy tier because of a 128-entry list).
+typedef JacoCaps<64, 32, 240> JacoLight;
+typedef JacoCaps<128, 48, 512> JacoMedium;  // 2 rows per lane: the EE axis sticks resting on the "hand" marker's sticks add ~36 rows to the usual 32
+typedef JacoCaps<256, 64, 512> JacoHeavy;
+typedef JacoCaps<512, 128, 512> JacoHuge;    // 8 rows per lane: a reset that puts the hand inside the pedestal (1 % of picking resets: up to ~90 contacts / ~410 rows)
 #define JDBG_MAXCON 64
 #define JDBG_MAXEFC 256
 #define JLD (JNV)     // row stride of per-row dof vectors in LDS (21: odd, conflict-free for lane-per-row access)
@@ -44,6 +48,7 @@ typedef JacoCaps<512, 128, 256> JacoHuge;    // 8 rows per lane: a reset that pu
 #define JFLAG_NAN 8u
 #define JFLAG_SOLVER_MAXITER 16u
 #define JFLAG_HEAVY_TIER 32u   // informational: env was stepped by the heavy tier at least once
+#define JFLAG_BAIL_CAUSE_SHIFT 8   // informational, bits 8..16: (contacts | rows | candidates) overflow that made tier 0 / 1 / 2 hand the env on
 #define JFLAG_TIER_RETURN 128u  // informational: the heavy tier handed the env back to the light code in mid-step
 
 #define JMINVAL 1e-15f
@@ -93,6 +98,7 @@ struct JacoStepArgs {
   int* light_left;     // [1] light-tier workgroups still running (0: the resident workers leave, the drains take the rest)
   int* hint;           // [nenv] highest tier (0..3) the env's last step really needed, or nullptr: where its next step starts
   int nenv, nsub, disable_contact;
+  int hint_mode;       // 1: an env's next step starts in the biggest tier this step really needed; 2: in the tier its last substep needed
   int no_tier_return;  // 1: an env handed to the heavy tier stays there for the rest of the launch (option "tier_return" = 0)
   // env-level mode (jaco_step / jaco_reset): nsub = frame_skip
   int env_mode;              // 0 ctrl-level, 1 env step, 2 forward only (reset: fill cache + observation),
@@ -188,7 +194,7 @@ struct JacoLDS {
     };
   };
   float e_x[C::MAXEFC > 64 ? C::MAXEFC : 1];    // heavy tier only: residuals staged for the MFMA pass (light reuses `smooth`)
-  int ncon, nefc, ncand, nlimit;
+  int ncon, nefc, ncand, nlimit, nsphere;      // (ncand: narrowphase candidates after the OBB cull; nsphere: bounding-sphere survivors before it)
   float task[JTASK_FLOATS];                    // (= JTASK_N of env_logic.h)
   float osc_qd[4];                              // target orientation quaternion of the current env step (constant over its substeps)
   // per-launch copy of the small, hot model tables (per-lane gathers from LDS instead of dependent global loads)
@@ -1268,20 +1274,22 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
       JSTAMP(5);
     } else {
       stage_limit_rows(m, s, lane, pf);
-      if (lane == 0) { s.ncon = 0; s.ncand = 0; }
+      if (lane == 0) { s.ncon = 0; s.ncand = 0; s.nsphere = 0; }
       wave_sync();
     }
     if (!LIGHT) {   // would the tier below have coped with this substep?  (huge -> heavy, heavy -> medium, medium -> light)
       constexpr int LCON = TIER == 3 ? JacoHeavy::MAXCON : (TIER == 2 ? JacoMedium::MAXCON : JacoLight::MAXCON);
       constexpr int LEFC = TIER == 3 ? JacoHeavy::MAXEFC : (TIER == 2 ? JacoMedium::MAXEFC : JacoLight::MAXEFC);
-      const bool fits = s.ncon <= LCON && s.nefc <= LEFC && s.ncand <= JacoLight::MAXCAND / 2;   // (head room below the capacity was tried: no gain)
+      constexpr int LCAND = TIER == 3 ? JacoHeavy::MAXCAND : (TIER == 2 ? JacoMedium::MAXCAND : JacoLight::MAXCAND);
+      const bool fits = s.ncon <= LCON && s.nefc <= LEFC && s.nsphere <= LCAND;   // (head room below the capacity was tried: no gain)
       calm = fits ? calm + 1 : 0;
-      if (!fits && !tier_used) { tier_used = true; hint_raise(A, env, TIER, lane); }
+      if (!fits && !tier_used) { tier_used = true; if (A.hint_mode != 2) hint_raise(A, env, TIER, lane); }
     }
     if (TIER == 3) flags |= cflags;   // the last tier has nobody to hand over to: contacts / rows beyond its capacity were dropped, say so
     if (TIER < 3 && cflags) {   // capacity exceeded: leave this substep (and the rest) to the next tier; nothing was mutated
       left = nsub - sub;
       bailed = true;
+      flags |= (cflags & 7u) << (JFLAG_BAIL_CAUSE_SHIFT + 3 * TIER);   // informational: which capacity of which tier sent the env on
       if (emode == 1 || emode == 3) {
         if (lane < nu) s.task[JT_CTRL + lane] = s.ctrl[lane];
         if (lane == 0) { s.task[JT_PENDING] = 1.f; s.task[JT_SUB] = (float)sub; }
@@ -1459,6 +1467,12 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
     unsigned f = flags;
     for (int o = 1; o < 64; o <<= 1) f |= (unsigned)wave_shfl_i((int)f, lane ^ o);
     if (lane == 0 && A.flags) { if (bailed) or_wt(&A.flags[env], f); else A.flags[env] |= f; }
+  }
+  if (!LIGHT && left == 0 && nsub > 0 && lane == 0 && A.hint && A.hint_mode == 2) {   // the tier the state the next step starts from needs
+    const int nc = s.ncon, ne = s.nefc, ns = s.nsphere;
+    A.hint[env] = (nc <= JacoLight::MAXCON && ne <= JacoLight::MAXEFC && ns <= JacoLight::MAXCAND) ? 0
+                : ((nc <= JacoMedium::MAXCON && ne <= JacoMedium::MAXEFC && ns <= JacoMedium::MAXCAND) ? 1
+                : ((nc <= JacoHeavy::MAXCON && ne <= JacoHeavy::MAXEFC && ns <= JacoHeavy::MAXCAND) ? 2 : 3));
   }
   if (left == 0 && lane == 0 && A.stats) {
     A.stats[4 * env] = s.ncon; A.stats[4 * env + 1] = s.nefc; A.stats[4 * env + 2] = iters; A.stats[4 * env + 3] = s.ncand | (nls_last << 16);

@@ -11,7 +11,7 @@ genv = JacoBatchedEnv(num_envs=B, device=0, frame_skip=50, seed=1000, task="pick
 env = genv.sim
 dev = torch.device("cuda:0")
 if "--no-schedule" in sys.argv: env.set_option("schedule", 0)
-for opt in ("heavy_workers", "tier_return", "concurrent_heavy"):
+for opt in ("heavy_workers", "tier_return", "concurrent_heavy", "hints"):
     if "--" + opt in sys.argv: env.set_option(opt, float(sys.argv[sys.argv.index("--" + opt) + 1]))
 genv.reset()
 gen = torch.Generator(device=dev); gen.manual_seed(2000)
@@ -30,6 +30,12 @@ for i in range(n):
     if resets: genv.reset(d)
     torch.cuda.synchronize(); dt = time.perf_counter() - t
     if i >= 4: tot += dt
+    import ctypes
+    qw = (ctypes.c_int * 32)()
+    nq = env.L.jaco_debug_queue_words(env.h, qw, 32)
+    if "--queues" in sys.argv:
+        print("        queues (medium, heavy, huge): queued %s  claimed by workers %s  workers started %s  reserve %s  queued from hints %s" % (
+            list(qw[0:3]), list(qw[3:6]), list(qw[6:9]), list(qw[10:13]), list(qw[14:17])))
     st = env.stats().float()
     fl = env.flags()
     print("step %2d  %.2f ms  done %.4f  ncon mean %.2f max %d  nefc mean %.1f  iters mean %.3f  cand mean %.2f  heavy %.4f  singular %.4f" % (
