@@ -55,6 +55,7 @@ def parse_args(argv=None):
                     help="actions from one of the reference's shipped policies instead of U(-1,1): 'picking' | 'placing' (tests/golden/policy_<task>.npz) or a policy.zip / .npz path; the policy's forward pass is inside the timed step")
     ap.add_argument("--policy-leg", default="picking", help="policy also timed (briefly, in a child process before the headline run); '' = none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--hints", type=int, default=None, help="tier hint mode of the env handle (diagnostic; default = the library's)")
     ap.add_argument("--drift-gpu-leg", default=None, help=argparse.SUPPRESS)   # internal: child process that steps the HIP path on the drift workload
     ap.add_argument("--dry-gather", action="store_true",
                     help="CPU rehearsal of the N > 1 plumbing (spawn, rendezvous, gather, max-over-ranks timing) on gloo: no GPU, no physics")
@@ -269,6 +270,8 @@ def main():
         from mujoco_jaco_amd.sharding import ObsGather, env_seed
         genv = JacoBatchedEnv(num_envs=B, device=local_rank, frame_skip=fs, seed=env_seed(1000, rank), task=args.task, robot_file=args.model)
         env = genv.sim
+        if args.hints is not None:
+            env.set_option("hints", args.hints)
         genv.reset()
         gen = torch.Generator(device=dev); gen.manual_seed(2000 + rank)
         # a rollout in progress: episode ages spread over [0, task_max_steps) so time-outs (and their resets) arrive at the

@@ -528,6 +528,8 @@ JDEV void stage_collision(const JacoStepArgs& A, const JacoModelDev* m, L& s, in
   const unsigned m1A = m->pair[pkA].m1, m2A = m->pair[pkA].m2;
   const int obA = m->pair[pkA].ob, dimA = m->pair[pkA].condim;
   for (int c = 0; c < ncand; c++) {
+    // contact buffer full and a bigger tier to hand the env to: the rest of the narrowphase would be thrown away with the substep
+    if (L::Caps::MAXEFC < JacoHuge::MAXEFC && (wave_uniform_i((int)flags) & (int)JFLAG_CON_OVERFLOW)) break;
     int pk, code, pob, pdim;
     unsigned pm1, pm2;
     if (c < 64) {

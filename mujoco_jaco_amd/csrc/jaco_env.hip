@@ -41,7 +41,7 @@ struct JacoHandle {
   int launch_id = 0;
   hipStream_t side[3] = {nullptr, nullptr, nullptr};   // the tiers' resident workers run here, concurrently with the light grid
   hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
-  int concurrent = 1, workers = 1024, workers_heavy = 256, workers_huge = 32, tier_return = 1, use_hints = 1;   // options "concurrent_heavy", "heavy_workers", "hints"
+  int concurrent = 1, workers = 1024, workers_heavy = 256, workers_huge = 32, tier_return = 1, use_hints = 2;   // options "concurrent_heavy", "heavy_workers", "hints"
   float *task_rows = nullptr, *cache = nullptr;
   float* marker = nullptr;    // [num_envs][2][12] poses of the "hand" / "subgoal_reach" markers (mocap bodies the task layer moves)
   unsigned* cost = nullptr;   // per env: shader-clock ticks its last step took (>> 4)
@@ -463,8 +463,9 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
   HIPCHK(h, hipGetLastError());
   if (conc) for (int t = 0; t < 3; t++) HIPCHK(h, hipStreamWaitEvent(st, h->ev_join[t], 0));
   const unsigned ne = (unsigned)h->num_envs;
-  unsigned mg = ne < 1280 ? ne : 1280, hg = ne < 1024 ? ne : 1024, gg = ne < 128 ? ne : 128;
-  if (io.mode == 2) { mg = mg < 128 ? mg : 128; hg = hg < 64 ? hg : 64; gg = gg < 16 ? gg : 16; }   // (reset-time forward passes: a handful of envs at most)
+  // drain grids = the tiers' full occupancy on 256 CUs (8 / 4 / 2 workgroups per CU by LDS and registers); slots are claimed one at a time
+  unsigned mg = ne < 2048 ? ne : 2048, hg = ne < 1024 ? ne : 1024, gg = ne < 512 ? ne : 512;
+  if (io.mode == 2) { mg = mg < 64 ? mg : 64; hg = hg < 64 ? hg : 64; gg = gg < 256 ? gg : 256; }   // (reset-time forward passes: overflows of the light tier go straight to the last one)
   hipLaunchKernelGGL(jaco_physics_kernel_medium_drain, dim3(mg), dim3(64), 0, st, A);
   hipLaunchKernelGGL(jaco_physics_kernel_heavy_drain, dim3(hg), dim3(64), 0, st, A);
   hipLaunchKernelGGL(jaco_physics_kernel_huge_drain, dim3(gg), dim3(64), 0, st, A);

@@ -33,7 +33,7 @@ struct JacoCaps {
 // list shares LDS with the constraint rows, which are bigger, so its capacity costs nothing -- and it must not be what sends
 // an env to a bigger tier (round 2 found 74 % of the envs of a small-action rollout in the heavy tier because of a 128-entry list).
 typedef JacoCaps<64, 32, 240> JacoLight;
-typedef JacoCaps<128, 48, 512> JacoMedium;  // 2 rows per lane: the EE axis sticks resting on the "hand" marker's sticks add ~36 rows to the usual 32
+typedef JacoCaps<128, 32, 512> JacoMedium;   // (32 contacts x 4 pyramid rows = 128 rows; 20.2 KB -> 8 envs per CU = the 2 waves per SIMD its 256 VGPRs allow)  2 rows per lane: the EE axis sticks resting on the "hand" marker's sticks add ~36 rows to the usual 32
 typedef JacoCaps<256, 64, 512> JacoHeavy;
 typedef JacoCaps<512, 128, 512> JacoHuge;    // 8 rows per lane: a reset that puts the hand inside the pedestal (1 % of picking resets: up to ~90 contacts / ~410 rows)
 #define JDBG_MAXCON 64
@@ -1504,7 +1504,9 @@ JDEV void light_grid(const JacoStepArgs& A, JacoLDS<JacoLight>& s) {
     if (lane == 0 && A.cost && A.env_mode <= 1) { unsigned c = (unsigned)((wave_clock() - t_start) >> 4); if (left > 0) st_wt_u(&A.cost[env], c); else A.cost[env] = c; }
     // hand-off: the env's state went to memory with write-through stores (run_env); once they are acknowledged the env
     // is appended to the medium tier's queue.  Its workgroups run concurrently (jaco_env.hip) and poll the queue.
-    if (left > 0) queue_push(A, 0, env, left, lane);
+    // (a reset's forward pass goes straight to the last tier: one more launch in the chain instead of three, each of which would
+    // redo the narrowphase of a hand-inside-the-pedestal pose up to its own capacity)
+    if (left > 0) queue_push(A, A.env_mode == 2 ? 2 : 0, env, left, lane);
   }
   wave_sync();
   }
@@ -1647,12 +1649,18 @@ JDEV void tier_workers(const JacoStepArgs& A, LDS& u, int lane) {
     wave_sync();
   }
 }
-// drain of tier queue T: after the light grid and the workers have finished (stream order), serve whatever entry is still pending
+// drain of tier queue T: after the light grid and the workers have finished (stream order), serve whatever entry is still pending,
+// i.e. the slots [taken, count).  Workgroups claim them one at a time (the envs' costs differ by an order of magnitude: a strided
+// split leaves most of the grid idle behind the slowest stride); the grid is sized to the tier's full occupancy by the host.
 template <int T, class LDS>
 JDEV void tier_drain(const JacoStepArgs& A, LDS& u, int lane) {
   const JacoStepArgs::Queue& Q = A.q[T];
-  const int count = *Q.count;
-  for (int i = env_id(); i < count; i += grid_size()) {
+  const int count = *Q.count;   // (final: every producer of this queue has finished)
+  for (;;) {
+    int i = 0;
+    if (lane == 0) i = jaco_atomic_inc(Q.taken);
+    i = wave_uniform_i(wave_bcast_i(i, 0));
+    if (i >= count) break;
     int env = Q.list[i];
     if (env < 0) continue;
     tier_serve<T>(A, u, env, lane);
