@@ -22,7 +22,7 @@ static_assert(JFLAG_CON_OVERFLOW == JACO_FLAG_CON_OVERFLOW && JFLAG_EFC_OVERFLOW
 // Queue control words (ints): per tier t (0 medium, 1 heavy, 2 huge) JQ_COUNT + t appended, JQ_TAKEN + t claimed, JQ_LIMIT + t workers
 // that start, JQ_RESERVE + t workers that stay when the queue runs dry; JQ_LIGHT light workgroups still running; JQ_ROUTED envs
 // queued at once by the light grid (hint > 0), JQ_HINTED + t how many of them per tier (counted by the ordering pass).
-enum { JQ_COUNT = 0, JQ_TAKEN = 3, JQ_LIMIT = 6, JQ_LIGHT = 9, JQ_RESERVE = 10, JQ_ROUTED = 13, JQ_HINTED = 14, JQ_PREV_COUNT = 17, JQ_PREV_HINTED = 20, JQ_LASTMODE = 23, JQ_WORDS = 24 };
+enum { JQ_COUNT = 0, JQ_TAKEN = 3, JQ_LIMIT = 6, JQ_LIGHT = 9, JQ_RESERVE = 10, JQ_ROUTED = 13, JQ_HINTED = 14, JQ_PREV_COUNT = 17, JQ_PREV_HINTED = 20, JQ_LASTMODE = 23, JQ_ROUND1 = 24, JQ_WORDS = 26 };   // (JQ_ROUND1 + t, t = 0, 1: the queue's length before the second drain round, -1 = no second round)
 
 struct JacoHandle {
   JacoModelDev model_host;
@@ -41,7 +41,7 @@ struct JacoHandle {
   int launch_id = 0;
   hipStream_t side[3] = {nullptr, nullptr, nullptr};   // the tiers' resident workers run here, concurrently with the light grid
   hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
-  int concurrent = 1, workers = 1024, workers_heavy = 256, workers_huge = 32, tier_return = 1, use_hints = 2;   // options "concurrent_heavy", "heavy_workers", "hints"
+  int concurrent = 1, workers = 1024, workers_heavy = 256, workers_huge = 32, tier_return = 1, use_hints = 2, handdown = 1;   // options "concurrent_heavy", "heavy_workers", "hints"
   float *task_rows = nullptr, *cache = nullptr;
   float* marker = nullptr;    // [num_envs][2][12] poses of the "hand" / "subgoal_reach" markers (mocap bodies the task layer moves)
   unsigned* cost = nullptr;   // per env: shader-clock ticks its last step took (>> 4)
@@ -122,7 +122,7 @@ extern "C" int jaco_create(const JacoConfig* cfg, JacoHandle** out) {
   CREATECHK(hipMalloc(&h->stats, B * 4 * sizeof(int)));
   CREATECHK(hipMalloc(&h->dbg, JDBG_SIZE * sizeof(float)));
   CREATECHK(hipMalloc(&h->remaining, B * sizeof(int)));
-  CREATECHK(hipMalloc(&h->qlist, 3 * B * sizeof(int)));
+  CREATECHK(hipMalloc(&h->qlist, 6 * B * sizeof(int)));   // (per tier 2 B slots: an env can come by twice, see the second drain round)
   CREATECHK(hipMalloc(&h->qctl, JQ_WORDS * sizeof(int)));
   CREATECHK(hipMemset(h->qctl, 0, JQ_WORDS * sizeof(int)));
   CREATECHK(hipMalloc(&h->hint, B * sizeof(int)));
@@ -328,6 +328,14 @@ __global__ __launch_bounds__(1024) void jaco_order_scatter_kernel(const unsigned
 // only show up during the step (a tenth of the previous launch's total demand)
 // Envs whose previous step ended in a bigger tier go there at once: queued here, before the launch, so that the tier's workers
 // find them when they start; the hint is consumed (it is re-earned during the step by whichever tier is really needed).
+// Between the two drain rounds: every workgroup of a drain ends on one claim beyond the queue's end, so `taken` has overshot the
+// end of round one by exactly the grid size; the second round starts where the first one really stopped.
+__global__ void jaco_drain_round2_kernel(int* ctl, int medium_grid, int heavy_grid) {
+  ctl[JQ_TAKEN + 0] -= medium_grid;
+  ctl[JQ_TAKEN + 1] -= heavy_grid;
+  ctl[JQ_ROUND1 + 0] = ctl[JQ_TAKEN + 0];   // = the medium queue's length when its first drain ended
+  ctl[JQ_ROUND1 + 1] = ctl[JQ_COUNT + 1];   // (the heavy queue only grows again in the second medium drain)
+}
 __global__ void jaco_route_kernel(int* hint, int* mark, int launch_id, int* lists, int* ctl, int* remaining, unsigned* cost, int n, int nsub) {
   const int e = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   if (e >= n) return;
@@ -337,7 +345,7 @@ __global__ void jaco_route_kernel(int* hint, int* mark, int launch_id, int* list
   mark[e] = launch_id;
   remaining[e] = nsub;
   cost[e] = 0u;   // (the tiers add what they spend)
-  lists[(size_t)(t - 1) * n + atomicAdd(&ctl[JQ_COUNT + t - 1], 1)] = e;
+  lists[(size_t)(t - 1) * 2 * n + atomicAdd(&ctl[JQ_COUNT + t - 1], 1)] = e;
 }
 // ... and this launch's workers are sized from what has just been queued: per tier, the envs that start there (a medium worker
 // serves ~8 of them in a third of a step, a heavy one ~4, a huge one ~2) plus the reserve for overflows that only show up
@@ -367,14 +375,18 @@ __global__ void jaco_order_finish_kernel(unsigned* oc, int n) {
 // light grid could use): a medium worker serves an env in ~1/20 of a step, a heavy / huge one in ~1/8 - 1/4
 __global__ void jaco_prepare_kernel(int* ctl, int* lists, int n, int wm, int wh, int wg, unsigned* oc, int mode, int light_wgs) {
   int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-  if (i < 3 * n) lists[i] = -1;
+  if (i < 6 * n) lists[i] = -1;
   if (i < 66) oc[i] = 0u;
   if (i == 0) {
     // without the ordering pass (small batches, reset-time launches) nothing is known about this launch's demand: workers as
     // the previous launch would have wanted them, all of them staying to the end
     // (the demand that counts is that of the last real step, not of a reset-time forward pass in between)
-    if (ctl[JQ_LASTMODE] <= 1) for (int t = 0; t < 3; t++) { ctl[JQ_PREV_COUNT + t] = ctl[JQ_COUNT + t]; ctl[JQ_PREV_HINTED + t] = ctl[JQ_HINTED + t]; }
-    ctl[JQ_LASTMODE] = mode;
+    if (ctl[JQ_LASTMODE] <= 1) for (int t = 0; t < 3; t++) {
+      // (what came by a second time -- handed down by the heavy drain, overflowed again after that -- is not new demand)
+      ctl[JQ_PREV_COUNT + t] = (t < 2 && ctl[JQ_ROUND1 + t] >= 0) ? ctl[JQ_ROUND1 + t] : ctl[JQ_COUNT + t];
+      ctl[JQ_PREV_HINTED + t] = ctl[JQ_HINTED + t];
+    }
+    ctl[JQ_LASTMODE] = mode; ctl[JQ_ROUND1] = -1; ctl[JQ_ROUND1 + 1] = -1;
     const int* pc = ctl + JQ_PREV_COUNT;
     int want[3] = {16 + pc[0] / 10, 8 + pc[1] / 4, 2 + pc[2] / 2}, cap[3] = {wm, wh, wg};
     for (int t = 0; t < 3; t++) {
@@ -399,7 +411,7 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
   A.sensordata = h->sensordata; A.flags = h->flags; A.stats = h->stats; A.nenv = h->num_envs; A.nsub = nsub;
   A.disable_contact = h->disable_contact; A.no_tier_return = !h->tier_return; A.dbg = dbg; A.dbg_env = dbg_env; A.prof = h->prof;
   A.remaining = h->remaining; A.light_left = h->qctl + JQ_LIGHT; A.hint = h->use_hints ? h->hint : nullptr; A.hint_mode = h->use_hints;
-  for (int t = 0; t < 3; t++) { A.q[t].list = h->qlist + (size_t)t * h->num_envs; A.q[t].count = h->qctl + JQ_COUNT + t; A.q[t].taken = h->qctl + JQ_TAKEN + t; A.q[t].limit = h->qctl + JQ_LIMIT + t; A.q[t].reserve = h->qctl + JQ_RESERVE + t; }
+  for (int t = 0; t < 3; t++) { A.q[t].list = h->qlist + (size_t)t * 2 * h->num_envs; A.q[t].count = h->qctl + JQ_COUNT + t; A.q[t].taken = h->qctl + JQ_TAKEN + t; A.q[t].limit = h->qctl + JQ_LIMIT + t; A.q[t].reserve = h->qctl + JQ_RESERVE + t; }
   A.routed_mark = nullptr; A.launch_id = ++h->launch_id;
   A.env_mode = io.mode; A.task_id = h->task; A.nact = h->task == JACO_TASK_REACHING ? 6 : 7; A.seed = h->seed;
   A.task = h->task_rows; A.cache = h->cache; A.action = io.action; A.noise = h->noise; A.obs_mode = h->obs_mode; A.subgoal = h->subgoal; A.obs = io.obs; A.reward = io.reward; A.done = io.done; A.mask = io.mask; A.marker = h->marker;
@@ -431,7 +443,7 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
   // frees and would otherwise starve behind the light grid, leaving serial tails of several ms per env step).  The drains that
   // follow in stream order serve whatever the workers did not (all of it when concurrency is off: full grids, which is also
   // what carries the load when most envs overflow).
-  hipLaunchKernelGGL(jaco_prepare_kernel, dim3((unsigned)((3 * h->num_envs + 255) / 256)), dim3(256), 0, st, h->qctl, h->qlist, h->num_envs, h->workers, h->workers_heavy, h->workers_huge, h->order_ctl, io.mode, (int)light_grid);
+  hipLaunchKernelGGL(jaco_prepare_kernel, dim3((unsigned)((6 * h->num_envs + 255) / 256)), dim3(256), 0, st, h->qctl, h->qlist, h->num_envs, h->workers, h->workers_heavy, h->workers_huge, h->order_ctl, io.mode, (int)light_grid);
   HIPCHK(h, hipGetLastError());
   if (A.hint && io.mode <= 1) {   // queue the envs whose last step ended in a bigger tier, size the tiers' workers
     hipLaunchKernelGGL(jaco_route_kernel, dim3((unsigned)((h->num_envs + 255) / 256)), dim3(256), 0, st, h->hint, h->routed_mark, A.launch_id, h->qlist, h->qctl, h->remaining, h->cost, h->num_envs, nsub);
@@ -467,6 +479,15 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
   unsigned mg = ne < 2048 ? ne : 2048, hg = ne < 1024 ? ne : 1024, gg = ne < 512 ? ne : 512;
   if (io.mode == 2) { mg = mg < 64 ? mg : 64; hg = hg < 64 ? hg : 64; gg = gg < 256 ? gg : 256; }   // (reset-time forward passes: overflows of the light tier go straight to the last one)
   hipLaunchKernelGGL(jaco_physics_kernel_medium_drain, dim3(mg), dim3(64), 0, st, A);
+  if (h->handdown && io.mode == 1) {
+    // the heavy tier holds 4 envs per CU: an env that needed it for a few substeps is passed back down to a second medium drain
+    // (8 per CU) rather than kept there for the rest of its step; what overflows again is served by a second, final heavy drain
+    A.handdown = 1;
+    hipLaunchKernelGGL(jaco_physics_kernel_heavy_drain, dim3(hg), dim3(64), 0, st, A);
+    A.handdown = 0;
+    hipLaunchKernelGGL(jaco_drain_round2_kernel, dim3(1), dim3(1), 0, st, h->qctl, (int)mg, (int)hg);
+    hipLaunchKernelGGL(jaco_physics_kernel_medium_drain, dim3(mg), dim3(64), 0, st, A);
+  }
   hipLaunchKernelGGL(jaco_physics_kernel_heavy_drain, dim3(hg), dim3(64), 0, st, A);
   hipLaunchKernelGGL(jaco_physics_kernel_huge_drain, dim3(gg), dim3(64), 0, st, A);
   HIPCHK(h, hipGetLastError());
@@ -670,6 +691,7 @@ extern "C" int jaco_set_option(JacoHandle* h, const char* name, double v) {
   if (!strcmp(name, "concurrent_heavy")) { h->concurrent = v != 0; return JACO_OK; }
   if (!strcmp(name, "tier_return")) { h->tier_return = v != 0; return JACO_OK; }
   if (!strcmp(name, "heavy_workers")) { h->workers = v < 1 ? 1 : (int)v; return JACO_OK; }
+  if (!strcmp(name, "handdown")) { h->handdown = v != 0; return JACO_OK; }
   if (!strcmp(name, "hints")) { h->use_hints = v < 0 ? 0 : (v > 2 ? 2 : (int)v); return JACO_OK; }   // 0 off, 1 biggest tier of the last step, 2 tier of its last substep
   if (!strcmp(name, "obs_mode")) { if (v != 0 && v != 1) { h->err = "jaco_set_option: obs_mode must be 0 or 1"; return JACO_EINVAL; } h->obs_mode = (int)v; return JACO_OK; }
   else if (!strcmp(name, "iterations")) m.iterations = (int)v;

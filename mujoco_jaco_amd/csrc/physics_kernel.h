@@ -98,6 +98,8 @@ struct JacoStepArgs {
   int* light_left;     // [1] light-tier workgroups still running (0: the resident workers leave, the drains take the rest)
   int* hint;           // [nenv] highest tier (0..3) the env's last step really needed, or nullptr: where its next step starts
   int nenv, nsub, disable_contact;
+  int handdown;        // 1: a heavy-tier workgroup (4 per CU) passes an env that has calmed down on to the medium queue instead of running the
+                       //    medium / light code itself for the rest of the step (first heavy drain only: a second medium drain follows it)
   int hint_mode;       // 1: an env's next step starts in the biggest tier this step really needed; 2: in the tier its last substep needed
   int no_tier_return;  // 1: an env handed to the heavy tier stays there for the rest of the launch (option "tier_return" = 0)
   // env-level mode (jaco_step / jaco_reset): nsub = frame_skip
@@ -1550,13 +1552,15 @@ JDEV void medium_env(const JacoStepArgs& A, JacoMediumLDS& u, int env, int lane)
 // heavy tier: heavy code while the env needs more than the medium capacities, then medium <-> light as above.
 // Returns 0 when the env's step is complete, or the substeps left when it outgrew the heavy capacities too (huge tier's turn).
 union JacoAllLDS { JacoLDS<JacoHeavy> heavy; JacoMediumLDS ml; };
-JDEV int heavy_env_run(const JacoStepArgs& A, JacoAllLDS& u, int env, int lane) {
+#define JACO_HANDDOWN_MIN 8   // substeps that must be left for a hand-down to pay (it costs a queue round trip and a fresh model staging)
+JDEV int heavy_env_run(const JacoStepArgs& A, JacoAllLDS& u, int env, int lane, bool allow_down = false) {
   const bool stepmode = A.env_mode == 1 || A.env_mode == 3;
   int left = stepmode ? A.nsub : A.remaining[env], why = 0;
   for (;;) {
     left = run_env<JacoHeavy, 2>(A, u.heavy, env, stepmode ? A.nsub : left, lane, !A.no_tier_return, &why);
     if (left <= 0) return 0;
     if (why == 1) return left;
+    if (allow_down && A.handdown && A.env_mode == 1 && left >= JACO_HANDDOWN_MIN) return -left;   // calm again: the medium tier's turn (caller queues it)
     wave_sync();
     if (!stepmode && lane == 0) A.remaining[env] = left;   // (ctrl level: run_env_tiers reads the substeps left from here)
     wave_sync();
@@ -1569,9 +1573,10 @@ JDEV int heavy_env_run(const JacoStepArgs& A, JacoAllLDS& u, int env, int lane) 
 }
 JDEV void heavy_env(const JacoStepArgs& A, JacoAllLDS& u, int env, int lane) {
   const unsigned long long t_start = wave_clock();
-  const int left = heavy_env_run(A, u, env, lane);
+  const int left = heavy_env_run(A, u, env, lane, true);
   if (lane == 0 && A.cost) A.cost[env] += (unsigned)((wave_clock() - t_start) >> 4);
   if (left > 0) queue_push(A, 2, env, left, lane);   // outgrew the heavy capacities too
+  if (left < 0) queue_push(A, 0, env, -left, lane);  // handed down (the launch that follows this drain serves the medium queue again)
 }
 // huge tier: whatever outgrew the heavy tier (a reset with the hand inside the pedestal) runs here while that lasts, then steps
 // down through heavy / medium / light like everything else

@@ -25,27 +25,38 @@ static int g_use_hints = 0;
 static int g_obs_mode = 0;
 extern "C" void emu_set_obs_mode(int v) { g_obs_mode = v; }
 extern "C" void emu_set_hints(int on) { g_use_hints = on; }
+static int g_handdown = 0, g_handed_down = 0;
+extern "C" void emu_set_handdown(int on) { g_handdown = on; }
+extern "C" int emu_handed_down() { return g_handed_down; }   // envs passed from the heavy drain to the second medium drain so far
 static int emu_launch(JacoStepArgs A, int* heavy_envs) {
   A.no_tier_return = g_no_tier_return_fwd();
   A.obs_mode = g_obs_mode;
-  std::vector<int> remaining(A.nenv, 0), lists(3 * (size_t)A.nenv, -1);
+  std::vector<int> remaining(A.nenv, 0), lists(6 * (size_t)A.nenv, -1);
   int count[3] = {0, 0, 0}, taken[3] = {0, 0, 0}, light_left = A.nenv;
   A.remaining = remaining.data(); A.light_left = &light_left;
-  for (int t = 0; t < 3; t++) { A.q[t].list = lists.data() + (size_t)t * A.nenv; A.q[t].count = &count[t]; A.q[t].taken = &taken[t]; A.q[t].limit = nullptr; A.q[t].reserve = nullptr; }
+  for (int t = 0; t < 3; t++) { A.q[t].list = lists.data() + (size_t)t * 2 * A.nenv; A.q[t].count = &count[t]; A.q[t].taken = &taken[t]; A.q[t].limit = nullptr; A.q[t].reserve = nullptr; }
   A.routed_mark = nullptr; A.launch_id = 1; A.nslots = nullptr;
   if ((int)g_hint.size() != A.nenv) g_hint.assign(A.nenv, 0);
-  A.hint = g_use_hints ? g_hint.data() : nullptr;
+  A.hint = g_use_hints ? g_hint.data() : nullptr; A.hint_mode = g_use_hints;
   emu_grid = A.nenv;
   for (int e = 0; e < A.nenv; e++) emu_run_wave(e, [&]() { jaco_physics_kernel(A); });
   emu_grid = 1;
   // (the resident workers of the GPU build leave as soon as the light grid is done: here that is always the case, so the
-  // drains serve every queue; they are the same serve functions)
+  // drains serve every queue; they are the same serve functions).  Same launch sequence as jaco_env.hip, grids of one workgroup.
   if (count[0] > 0) emu_run_wave(0, [&]() { jaco_physics_kernel_medium(A); });
-  if (count[0] > 0) emu_run_wave(0, [&]() { jaco_physics_kernel_medium_drain(A); });
+  emu_run_wave(0, [&]() { jaco_physics_kernel_medium_drain(A); });
   if (count[1] > 0) emu_run_wave(0, [&]() { jaco_physics_kernel_heavy_workers(A); });
-  if (count[1] > 0) emu_run_wave(0, [&]() { jaco_physics_kernel_heavy_drain(A); });
+  if (g_handdown && A.env_mode == 1) {
+    A.handdown = 1;
+    emu_run_wave(0, [&]() { jaco_physics_kernel_heavy_drain(A); });
+    A.handdown = 0;
+    taken[0] -= 1; taken[1] -= 1;   // (jaco_drain_round2_kernel: each drain workgroup ends one claim beyond the end)
+    g_handed_down += count[0] - taken[0];
+    emu_run_wave(0, [&]() { jaco_physics_kernel_medium_drain(A); });
+  }
+  emu_run_wave(0, [&]() { jaco_physics_kernel_heavy_drain(A); });
   if (count[2] > 0) emu_run_wave(0, [&]() { jaco_physics_kernel_huge_workers(A); });
-  if (count[2] > 0) emu_run_wave(0, [&]() { jaco_physics_kernel_huge_drain(A); });
+  emu_run_wave(0, [&]() { jaco_physics_kernel_huge_drain(A); });
   if (heavy_envs) *heavy_envs = count[0];
   return 0;
 }

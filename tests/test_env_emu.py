@@ -139,6 +139,32 @@ def test_tier_alternation(names, model_arrays):
     assert out[1][2] == odone and out[1][0][0] == oo[0] and np.abs(out[1][0] - oo).max() < 3e-3
 
 
+def test_hand_down_to_second_medium_drain(names, model_arrays):
+    """The same scenario through the two-round drain sequence (jaco_env.hip): the heavy drain does not keep the calmed-down env for
+    the rest of its step but queues it for the medium tier again (a second medium drain, then a final heavy drain).  Which
+    workgroup steps an env must not matter: bit-identical observation, reward and state."""
+    from emu_binding import lib
+    seed = 108
+    rng = np.random.default_rng(seed)
+    a = rng.uniform(-1, 1, 7).astype(np.float32); a[:3] = np.sign(a[:3]) * np.maximum(np.abs(a[:3]), 0.5)
+    nz = np.full((1, 12), 0.5, np.float32)
+    out = {}
+    before = lib().emu_handed_down()
+    try:
+        for down in (0, 1):
+            lib().emu_set_handdown(down)
+            e, oe = _pair(names, model_arrays, seed, 30)
+            e.forward(nz)
+            obs, rew, done = e.env_step(a, nz)
+            out[down] = (obs[0].copy(), float(rew[0]), e.qpos[0].copy(), e.qvel[0].copy(), int(e.flags[0]))
+    finally:
+        lib().emu_set_handdown(0)
+    assert lib().emu_handed_down() > before                     # the env really took the second round
+    assert out[1][4] & 32 and out[1][4] & 128
+    assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1]
+    assert np.array_equal(out[0][2], out[1][2]) and np.array_equal(out[0][3], out[1][3])
+
+
 def test_reaching_task_matches_oracle_env(names, model_arrays):
     """Task 'reaching' (env_mujoco_util.py:192-207, 314-351, 504-520): 6-wide action (gripper held at 0.6), reaching reward,
     reaching termination with the success flag, time-out at 500 steps, and the rulebased_subgoal = False observation
