@@ -36,7 +36,7 @@ extern "C" {
 #define JACO_FLAG_CAND_OVERFLOW 4u  /* more broadphase survivors than the candidate buffer */
 #define JACO_FLAG_NAN 8u            /* non-finite velocity: env should be reset */
 #define JACO_FLAG_SOLVER_MAXITER 16u
-#define JACO_FLAG_HEAVY_TIER 32u     /* informational: stepped by the 128- or 256-row tier at least once (not an error) */
+#define JACO_FLAG_HEAVY_TIER 32u     /* informational: stepped by a bigger tier (128 / 256 / 512 rows) at least once (not an error) */
 #define JACO_FLAG_TIER_RETURN 128u   /* informational: the heavy tier gave the env back to the light code in mid-step (overflow was transient) */
 #define JACO_FLAG_BAIL_CAUSE_SHIFT 8  /* informational, bits 8..16: which capacity (bit 0 contacts, 1 rows, 2 candidates) made tier 0 / 1 / 2 (3 bits each) hand the env on */
 #define JACO_FLAG_OSC_SINGULAR 64u   /* informational: |det(J M^-1 J^T)| < 1e-3, the controller used its pseudo-inverse branch */
@@ -139,9 +139,12 @@ int jaco_set_frame_skip(JacoHandle* h, int frame_skip);
 
 /* Solver / collision options, MuJoCo <option> names: "iterations", "tolerance", "ls_iterations",
  * "disable_contact" (contact flag), "mpr_iterations", "mpr_tolerance".
- * Execution options (no effect on results): "schedule" (1: launch expensive envs first), "concurrent_heavy" (1: heavy-tier
- * workgroups resident next to the light grid), "heavy_workers" (their maximum, default 512; the resident number follows the previous step's hand-overs), "tier_return" (1: a heavy-tier
- * env goes back to the light code when its overflow is over). */
+ * Execution options (no effect on results): "schedule" (1: launch expensive envs first), "concurrent_heavy" (1: medium / heavy / huge
+ * tier workgroups resident next to the light grid), "heavy_workers" (maximum of the medium tier's; the resident number follows the
+ * previous step's hand-overs), "tier_return" (1: a bigger tier gives an env back once its overflow is over), "hints" (where an env
+ * starts its next step: 0 always the light tier, 1 the biggest tier its last step needed, 2 (default) the tier its last substep
+ * needed), "handdown" (1, default: the first heavy drain passes calmed-down envs to a second medium drain instead of keeping them
+ * for the rest of the step). */
 int jaco_set_option(JacoHandle* h, const char* name, double value);
 
 /* Test hook: like jaco_physics_step but also copies the stage dump of environment `env` taken in

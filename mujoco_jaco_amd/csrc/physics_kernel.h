@@ -1672,7 +1672,11 @@ JDEV void tier_drain(const JacoStepArgs& A, LDS& u, int lane) {
     wave_sync();
   }
 }
+// The resident workers run with a raised wave priority (s_setprio): the envs they serve are the step's critical path -- a huge-tier
+// env step (hand inside the pedestal after a reset: ~400 rows) takes as long as the whole light grid, and every issue slot it loses
+// to the three light waves sharing its SIMD is added to the step's tail.
 __global__ __launch_bounds__(64, 2) void jaco_physics_kernel_medium(JacoStepArgs A) {
+  __builtin_amdgcn_s_setprio(1);
   __shared__ JacoMediumLDS u;
   tier_workers<0>(A, u, lane_id());
 }
@@ -1681,6 +1685,7 @@ __global__ __launch_bounds__(64, 2) void jaco_physics_kernel_medium_drain(JacoSt
   tier_drain<0>(A, u, lane_id());
 }
 __global__ __launch_bounds__(64) void jaco_physics_kernel_heavy_workers(JacoStepArgs A) {
+  __builtin_amdgcn_s_setprio(2);
   __shared__ JacoAllLDS u;
   tier_workers<1>(A, u, lane_id());
 }
@@ -1689,10 +1694,12 @@ __global__ __launch_bounds__(64) void jaco_physics_kernel_heavy_drain(JacoStepAr
   tier_drain<1>(A, u, lane_id());
 }
 __global__ __launch_bounds__(64) void jaco_physics_kernel_huge_workers(JacoStepArgs A) {
+  __builtin_amdgcn_s_setprio(3);
   __shared__ JacoHugeLDS u;
   tier_workers<2>(A, u, lane_id());
 }
 __global__ __launch_bounds__(64) void jaco_physics_kernel_huge_drain(JacoStepArgs A) {
+  __builtin_amdgcn_s_setprio(3);
   __shared__ JacoHugeLDS u;
   tier_drain<2>(A, u, lane_id());
 }

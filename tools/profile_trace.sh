@@ -13,7 +13,7 @@ for f in glob.glob("$OUT/*/*kernel_trace.csv"):
 rows.sort()
 step, t0 = -1, 0
 for s, e, k in rows:
-    short = "prepare" if "prepare" in k else "order" if "order" in k else "mdrain" if "medium_drain" in k else "hdrain" if "heavy_drain" in k else "huge" if "huge" in k else "hworkers" if "heavy_workers" in k else "workers" if "medium" in k else "light" if "jaco_physics_kernel" in k else None
+    short = "round2" if "round2" in k else "prepare" if "prepare" in k else "order" if "order" in k else "mdrain" if "medium_drain" in k else "hdrain" if "heavy_drain" in k else "huge" if "huge" in k else "hworkers" if "heavy_workers" in k else "workers" if "medium" in k else "light" if "jaco_physics_kernel" in k else None
     if short is None: continue
     if short == "prepare": step += 1; t0 = s
     if short in ("prepare", "order"): continue
