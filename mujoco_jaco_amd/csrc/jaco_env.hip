@@ -40,7 +40,7 @@ struct JacoHandle {
   int* routed_mark = nullptr;                 // [num_envs] id of the launch that queued the env for a bigger tier before it started
   int launch_id = 0;
   hipStream_t side[3] = {nullptr, nullptr, nullptr};   // the tiers' resident workers run here, concurrently with the light grid
-  hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev_pre = nullptr, ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
   int concurrent = 1, workers = 1024, workers_heavy = 256, workers_huge = 32, tier_return = 1, use_hints = 2, handdown = 1;   // options "concurrent_heavy", "heavy_workers", "hints"
   float *task_rows = nullptr, *cache = nullptr;
   float* marker = nullptr;    // [num_envs][2][12] poses of the "hand" / "subgoal_reach" markers (mocap bodies the task layer moves)
@@ -133,6 +133,7 @@ extern "C" int jaco_create(const JacoConfig* cfg, JacoHandle** out) {
     int lo = 0, hi = 0;
     CREATECHK(hipDeviceGetStreamPriorityRange(&lo, &hi));   // (hi = numerically lowest = highest priority)
     CREATECHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    CREATECHK(hipEventCreateWithFlags(&h->ev_pre, hipEventDisableTiming));
     for (int t = 0; t < 3; t++) {
       CREATECHK(hipStreamCreateWithPriority(&h->side[t], hipStreamNonBlocking, hi));
       CREATECHK(hipEventCreateWithFlags(&h->ev_join[t], hipEventDisableTiming));
@@ -191,6 +192,7 @@ extern "C" int jaco_destroy(JacoHandle* h) {
     if (h->ev_join[t]) (void)hipEventDestroy(h->ev_join[t]);
   }
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  if (h->ev_pre) (void)hipEventDestroy(h->ev_pre);
   void* ptrs[] = {h->model_dev, h->hull_dev, h->qpos, h->qvel, h->qacc_ws, h->sensordata, h->flags, h->stats, h->dbg, h->prof, h->remaining, h->qlist, h->qctl, h->hint, h->routed_mark, h->task_rows, h->cache, h->cost, h->order, h->marker, h->order_ctl, h->qpos0_dev};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   delete h;
@@ -450,14 +452,10 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
     hipLaunchKernelGGL(jaco_route_finish_kernel, dim3(1), dim3(1), 0, st, h->num_envs, h->qctl, h->workers, h->workers_heavy, h->workers_huge);
     A.routed_mark = h->routed_mark;
   }
-  if (reorder) {
-    const unsigned ob = (unsigned)((h->num_envs + 1023) / 1024);
-    hipLaunchKernelGGL(jaco_order_hist_kernel, dim3(ob), dim3(1024), 0, st, h->cost, h->order_ctl, h->num_envs, A.routed_mark, A.launch_id);
-    hipLaunchKernelGGL(jaco_order_scatter_kernel, dim3(ob), dim3(1024), 0, st, h->cost, h->order_ctl, h->order, h->num_envs, A.routed_mark, A.launch_id);
-    hipLaunchKernelGGL(jaco_order_finish_kernel, dim3(1), dim3(1), 0, st, h->order_ctl, h->num_envs);
-    HIPCHK(h, hipGetLastError());
-    A.order = h->order;
-  }
+  // The resident workers go first: their workgroups need 20 - 68 KB of LDS on one CU, and once the light grid (13 KB per workgroup,
+  // 65 536 of them) has filled the chip such a hole only opens when the grid runs out -- a huge-tier env queued at t = 0 would then
+  // start its 10 ms of work when everything else is done.  Launched before the ordering pass, they have three small kernels of
+  // head start on the light grid (and the event record below adds a barrier packet in front of it).
   const bool conc = h->concurrent && io.mode == 1 && nsub >= 8 && h->num_envs >= 4096;
   if (conc) {
     HIPCHK(h, hipEventRecord(h->ev_fork, st));
@@ -468,6 +466,15 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
     HIPCHK(h, hipGetLastError());
     for (int t = 0; t < 3; t++) HIPCHK(h, hipEventRecord(h->ev_join[t], h->side[t]));
   }
+  if (reorder) {
+    const unsigned ob = (unsigned)((h->num_envs + 1023) / 1024);
+    hipLaunchKernelGGL(jaco_order_hist_kernel, dim3(ob), dim3(1024), 0, st, h->cost, h->order_ctl, h->num_envs, A.routed_mark, A.launch_id);
+    hipLaunchKernelGGL(jaco_order_scatter_kernel, dim3(ob), dim3(1024), 0, st, h->cost, h->order_ctl, h->order, h->num_envs, A.routed_mark, A.launch_id);
+    hipLaunchKernelGGL(jaco_order_finish_kernel, dim3(1), dim3(1), 0, st, h->order_ctl, h->num_envs);
+    HIPCHK(h, hipGetLastError());
+    A.order = h->order;
+  }
+  if (conc) HIPCHK(h, hipEventRecord(h->ev_pre, st));
   if (kev) HIPCHK(h, hipEventRecord(kev->first, st));
   if (A.nslots || io.mode >= 2) hipLaunchKernelGGL(jaco_physics_kernel_listed, dim3(light_grid), dim3(64), 0, st, A);   // (resets: forward passes, placing hold)
   else hipLaunchKernelGGL(jaco_physics_kernel, dim3(light_grid), dim3(64), 0, st, A);
