@@ -912,16 +912,17 @@ JDEV NewtonOut stage_newton(const JacoModelDev* m, L& s, const float (&mrow)[JNV
       acc16x16 C;
       acc_zero(C);
       const int uq = lane >> 4, col = lane & 15;
+      // (rows beyond the last one read the last row with weight 0; the column masks are exact multipliers: no selects in the loop)
+      const float cj = col < JNV - JB0 ? 1.f : 0.f, cx = col == JNV - JB0 ? -1.f : 0.f;
+      const float* jcol = s.J + JB0 + (col < JNV - JB0 ? col : 0);
+      const int last = ne - 1;
       for (int r0 = 0; r0 < ne; r0 += 16) {
         float jv[4], wv[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-          int r = r0 + 4 * u + uq;
-          bool ok = r < ne;
-          float xv = ok ? xs[r] : 0.f;
-          jv[u] = (ok && col < JNV - JB0) ? s.J[r * JLD + JB0 + col] : 0.f;
-          jv[u] = col == JNV - JB0 ? -xv : jv[u];
-          wv[u] = ok ? s.e_f[r] : 0.f;
+          const int r = r0 + 4 * u + uq, rc = r < last ? r : last;
+          jv[u] = cj * jcol[rc * JLD] + cx * xs[rc];
+          wv[u] = r < ne ? s.e_f[rc] : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) wave_mfma_16x16x4(jv[u], wv[u] * jv[u], C);
@@ -941,16 +942,16 @@ JDEV NewtonOut stage_newton(const JacoModelDev* m, L& s, const float (&mrow)[JNV
     acc32x32 C;
     acc_zero(C);
     const int uh = lane >> 5, col = lane & 31;
+    const float cj = col < JNV ? 1.f : 0.f, cx = col == JNV ? -1.f : 0.f;
+    const float* jcol = s.J + (col < JNV ? col : 0);
+    const int last = ne - 1;
     for (int r0 = 0; r0 < ne; r0 += 8) {
       float jv[4], wv[4];
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        int r = r0 + 2 * u + uh;
-        bool ok = r < ne;
-        float xv = ok ? xs[r] : 0.f;
-        jv[u] = (ok && col < JNV) ? s.J[r * JLD + col] : 0.f;
-        jv[u] = col == JNV ? -xv : jv[u];
-        wv[u] = ok ? s.e_f[r] : 0.f;
+        const int r = r0 + 2 * u + uh, rc = r < last ? r : last;
+        jv[u] = cj * jcol[rc * JLD] + cx * xs[rc];
+        wv[u] = r < ne ? s.e_f[rc] : 0.f;
       }
 #pragma unroll
       for (int u = 0; u < 4; u++) wave_mfma_32x32x2(jv[u], wv[u] * jv[u], C);
