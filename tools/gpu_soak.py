@@ -7,6 +7,7 @@ from mujoco_jaco_amd.env import JacoBatchedEnv
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 task = sys.argv[3] if len(sys.argv) > 3 else "picking"
+scale = float(sys.argv[4]) if len(sys.argv) > 4 else 1.0   # actions are U(-1, 1) times this
 env = JacoBatchedEnv(num_envs=B, task=task, seed=7)
 env.reset()
 gen = torch.Generator(device=env.device); gen.manual_seed(1)
@@ -14,7 +15,7 @@ ndone = nsucc = 0
 bad = 0
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for s in range(n):
-    a = torch.rand(B, 7, device=env.device, generator=gen) * 2 - 1
+    a = (torch.rand(B, env.action_space.shape[0], device=env.device, generator=gen) * 2 - 1) * scale
     obs, rew, done, _ = env.step(a)
     bad += int((~torch.isfinite(obs).all(1)).sum()) + int((~torch.isfinite(rew)).sum())
     if done.any():
