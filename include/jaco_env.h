@@ -139,7 +139,8 @@ int jaco_set_frame_skip(JacoHandle* h, int frame_skip);
 
 /* Solver / collision options, MuJoCo <option> names: "iterations", "tolerance", "ls_iterations",
  * "disable_contact" (contact flag), "mpr_iterations", "mpr_tolerance".
- * Execution options (no effect on results): "schedule" (1: launch expensive envs first), "concurrent_heavy" (1: medium / heavy / huge
+ * Execution options ("schedule", "concurrent_heavy", "heavy_workers", "handdown": bit-identical results; "hints" / "tier_return" pick which
+ * capacity tier's code steps a substep, and the tiers group their row sums differently: results agree to fp32 rounding): "schedule" (1: launch expensive envs first), "concurrent_heavy" (1: medium / heavy / huge
  * tier workgroups resident next to the light grid), "heavy_workers" (maximum of the medium tier's; the resident number follows the
  * previous step's hand-overs), "tier_return" (1: a bigger tier gives an env back once its overflow is over), "hints" (where an env
  * starts its next step: 0 always the light tier, 1 the biggest tier its last step needed, 2 (default) the tier its last substep

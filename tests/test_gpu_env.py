@@ -244,6 +244,33 @@ def test_launch_order_does_not_change_results():
             assert heavy > B // 200          # the hand-off path really was exercised
 
 
+def test_execution_options():
+    """Hand-down (heavy drain -> second medium drain) only changes which workgroup runs the same code: bit-identical states and
+    outputs.  The start-of-step routing ("hints") changes which capacity tier's code steps a substep; the tiers group their
+    row sums differently (1, 2, 4 or 8 rows per lane), so its three settings agree to fp32 rounding, not bit for bit.
+    Action scale 0.05: nine in ten envs leave the light tier, a quarter reach the heavy tier within a step."""
+    from mujoco_jaco_amd.env import JacoBatchedEnv
+    B = 8192
+    outs = {}
+    for hints, down in ((2, 1), (2, 0), (0, 1), (1, 1)):
+        env = JacoBatchedEnv(num_envs=B, task="picking", seed=33)
+        env.sim.set_option("hints", hints); env.sim.set_option("handdown", down)
+        env.reset()
+        gen = torch.Generator(device=env.device); gen.manual_seed(6)
+        for s in range(2):
+            a = (torch.rand(B, 7, device=env.device, generator=gen) * 2 - 1) * 0.05
+            obs, rew, done, _ = env.step(a)
+        q, v, _ = env.sim.get_state()
+        outs[(hints, down)] = (q.clone(), v.clone(), obs.clone(), rew.clone(), done.clone())
+        del env
+    for x, y in zip(outs[(2, 1)], outs[(2, 0)]):
+        assert torch.equal(x, y)
+    for other in ((0, 1), (1, 1)):
+        dq = (outs[(2, 1)][0] - outs[other][0]).abs().max(1).values
+        print("hints 2 vs %d: qpos difference after 2 env steps: median %.2e, p99 %.2e, max %.2e" % (other[0], dq.median().item(), dq.quantile(0.99).item(), dq.max().item()))
+        assert dq.median().item() < 1e-5 and (dq < 1e-3).float().mean().item() > 0.97
+
+
 def test_vec_env_adapter_autoreset():
     """Learner-side adapter: SB-style step() with in-call reset of finished envs, terminal observation kept in infos."""
     from mujoco_jaco_amd.vec_env import JacoVecEnv
