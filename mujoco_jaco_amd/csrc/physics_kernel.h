@@ -1553,7 +1553,9 @@ JDEV void medium_env(const JacoStepArgs& A, JacoMediumLDS& u, int env, int lane)
 // heavy tier: heavy code while the env needs more than the medium capacities, then medium <-> light as above.
 // Returns 0 when the env's step is complete, or the substeps left when it outgrew the heavy capacities too (huge tier's turn).
 union JacoAllLDS { JacoLDS<JacoHeavy> heavy; JacoMediumLDS ml; };
-#define JACO_HANDDOWN_MIN 8   // substeps that must be left for a hand-down to pay (it costs a queue round trip and a fresh model staging)
+#ifndef JACO_HANDDOWN_MIN
+#define JACO_HANDDOWN_MIN 8
+#endif                      // substeps that must be left for a hand-down to pay (it costs a queue round trip and a fresh model staging)
 JDEV int heavy_env_run(const JacoStepArgs& A, JacoAllLDS& u, int env, int lane, bool allow_down = false) {
   const bool stepmode = A.env_mode == 1 || A.env_mode == 3;
   int left = stepmode ? A.nsub : A.remaining[env], why = 0;
