@@ -22,6 +22,9 @@ static_assert(JFLAG_CON_OVERFLOW == JACO_FLAG_CON_OVERFLOW && JFLAG_EFC_OVERFLOW
 // Queue control words (ints): per tier t (0 medium, 1 heavy, 2 huge) JQ_COUNT + t appended, JQ_TAKEN + t claimed, JQ_LIMIT + t workers
 // that start, JQ_RESERVE + t workers that stay when the queue runs dry; JQ_LIGHT light workgroups still running; JQ_ROUTED envs
 // queued at once by the light grid (hint > 0), JQ_HINTED + t how many of them per tier (counted by the ordering pass).
+#ifndef JACO_HEAVY_GRID
+#define JACO_HEAVY_GRID 1024u   // 4 heavy-tier workgroups per CU
+#endif
 enum { JQ_COUNT = 0, JQ_TAKEN = 3, JQ_LIMIT = 6, JQ_LIGHT = 9, JQ_RESERVE = 10, JQ_ROUTED = 13, JQ_HINTED = 14, JQ_PREV_COUNT = 17, JQ_PREV_HINTED = 20, JQ_LASTMODE = 23, JQ_ROUND1 = 24, JQ_WORDS = 26 };   // (JQ_ROUND1 + t, t = 0, 1: the queue's length before the second drain round, -1 = no second round)
 
 struct JacoHandle {
@@ -483,7 +486,7 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
   if (conc) for (int t = 0; t < 3; t++) HIPCHK(h, hipStreamWaitEvent(st, h->ev_join[t], 0));
   const unsigned ne = (unsigned)h->num_envs;
   // drain grids = the tiers' full occupancy on 256 CUs (8 / 4 / 2 workgroups per CU by LDS and registers); slots are claimed one at a time
-  unsigned mg = ne < 2048 ? ne : 2048, hg = ne < 1024 ? ne : 1024, gg = ne < 512 ? ne : 512;
+  unsigned mg = ne < 2048 ? ne : 2048, hg = ne < JACO_HEAVY_GRID ? ne : JACO_HEAVY_GRID, gg = ne < 512 ? ne : 512;
   if (io.mode == 2) { mg = mg < 64 ? mg : 64; hg = hg < 64 ? hg : 64; gg = gg < 256 ? gg : 256; }   // (reset-time forward passes: overflows of the light tier go straight to the last one)
   hipLaunchKernelGGL(jaco_physics_kernel_medium_drain, dim3(mg), dim3(64), 0, st, A);
   if (h->handdown && io.mode == 1) {

@@ -34,7 +34,12 @@ struct JacoCaps {
 // an env to a bigger tier (round 2 found 74 % of the envs of a small-action rollout in the heavy tier because of a 128-entry list).
 typedef JacoCaps<64, 32, 240> JacoLight;
 typedef JacoCaps<128, 32, 512> JacoMedium;   // (32 contacts x 4 pyramid rows = 128 rows; 20.2 KB -> 8 envs per CU = the 2 waves per SIMD its 256 VGPRs allow)  2 rows per lane: the EE axis sticks resting on the "hand" marker's sticks add ~36 rows to the usual 32
-typedef JacoCaps<256, 64, 512> JacoHeavy;
+#ifndef JACO_HEAVY_ROWS
+#define JACO_HEAVY_ROWS 256
+#define JACO_HEAVY_CON 64
+#define JACO_HEAVY_WAVES 1
+#endif
+typedef JacoCaps<JACO_HEAVY_ROWS, JACO_HEAVY_CON, 512> JacoHeavy;
 typedef JacoCaps<512, 128, 512> JacoHuge;    // 8 rows per lane: a reset that puts the hand inside the pedestal (1 % of picking resets: up to ~90 contacts / ~410 rows)
 #define JDBG_MAXCON 64
 #define JDBG_MAXEFC 256
@@ -1687,12 +1692,12 @@ __global__ __launch_bounds__(64, 2) void jaco_physics_kernel_medium_drain(JacoSt
   __shared__ JacoMediumLDS u;
   tier_drain<0>(A, u, lane_id());
 }
-__global__ __launch_bounds__(64) void jaco_physics_kernel_heavy_workers(JacoStepArgs A) {
+__global__ __launch_bounds__(64, JACO_HEAVY_WAVES) void jaco_physics_kernel_heavy_workers(JacoStepArgs A) {
   __builtin_amdgcn_s_setprio(2);
   __shared__ JacoAllLDS u;
   tier_workers<1>(A, u, lane_id());
 }
-__global__ __launch_bounds__(64) void jaco_physics_kernel_heavy_drain(JacoStepArgs A) {
+__global__ __launch_bounds__(64, JACO_HEAVY_WAVES) void jaco_physics_kernel_heavy_drain(JacoStepArgs A) {
   __shared__ JacoAllLDS u;
   tier_drain<1>(A, u, lane_id());
 }
