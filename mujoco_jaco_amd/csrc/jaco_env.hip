@@ -488,7 +488,7 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
   // drain grids = the tiers' full occupancy on 256 CUs (8 / 4 / 2 workgroups per CU by LDS and registers); slots are claimed one at a time
   unsigned mg = ne < 2048 ? ne : 2048, hg = ne < JACO_HEAVY_GRID ? ne : JACO_HEAVY_GRID, gg = ne < 512 ? ne : 512;
   if (io.mode == 2) { mg = mg < 64 ? mg : 64; hg = hg < 64 ? hg : 64; gg = gg < 256 ? gg : 256; }   // (reset-time forward passes: overflows of the light tier go straight to the last one)
-  hipLaunchKernelGGL(jaco_physics_kernel_medium_drain, dim3(mg), dim3(64), 0, st, A);
+  if (io.mode != 2) hipLaunchKernelGGL(jaco_physics_kernel_medium_drain, dim3(mg), dim3(64), 0, st, A);   // (mode 2 queues for the last tier only)
   if (h->handdown && io.mode == 1) {
     // the heavy tier holds 4 envs per CU: an env that needed it for a few substeps is passed back down to a second medium drain
     // (8 per CU) rather than kept there for the rest of its step; what overflows again is served by a second, final heavy drain
@@ -498,7 +498,7 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
     hipLaunchKernelGGL(jaco_drain_round2_kernel, dim3(1), dim3(1), 0, st, h->qctl, (int)mg, (int)hg);
     hipLaunchKernelGGL(jaco_physics_kernel_medium_drain, dim3(mg), dim3(64), 0, st, A);
   }
-  hipLaunchKernelGGL(jaco_physics_kernel_heavy_drain, dim3(hg), dim3(64), 0, st, A);
+  if (io.mode != 2) hipLaunchKernelGGL(jaco_physics_kernel_heavy_drain, dim3(hg), dim3(64), 0, st, A);
   hipLaunchKernelGGL(jaco_physics_kernel_huge_drain, dim3(gg), dim3(64), 0, st, A);
   HIPCHK(h, hipGetLastError());
   if (ev) HIPCHK(h, hipEventRecord(ev->second, st));

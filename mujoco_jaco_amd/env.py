@@ -141,7 +141,7 @@ class JacoBatchedEnv:
         if a.numel() != self.num_envs * nact or (a.dim() > 1 and a.shape[-1] != nact):
             raise ValueError("action must have shape (%d, %d), got %s" % (self.num_envs, nact, tuple(a.shape)))
         a = a.reshape(self.num_envs, nact)
-        return torch.max(torch.min(a, self._amax), self._amin).contiguous()          # np.clip (env_mujoco.py:117)
+        return torch.clamp(a, self._amin, self._amax).contiguous()                    # np.clip (env_mujoco.py:117)
 
     def take_action(self, a, weight=None, subgoal=None, id=None):
         """env_mujoco.py:158-159 -> _take_action (env_mujoco_util.py:602-646): EE target, gripper command, marker poses; no physics."""
