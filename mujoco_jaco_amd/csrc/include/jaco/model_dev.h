@@ -48,10 +48,13 @@ struct JacoModelDev {
   int iterations, ls_iterations, mpr_iterations;
   int mpr_output;   // 1 (default): portal-plane normal + support depth; 0: libccd's closest point of the final portal triangle
   float ls_tolerance;
+  float timestep_lo;   // timestep - (double)(float)timestep: the integrators carry the state compensated (hi + lo floats) and advance it by the fp64 step
+  int compensated;     // 1 (default): qpos / qvel carried as hi + lo floats (physics_kernel.h, stage E); 0: plain fp32 state (comparison)
 
   // bodies (parents precede children)
   int b_parent[JNB], b_jtype[JNB], b_qadr[JNB], b_dadr[JNB], b_limited[JNB];
   float b_pos[JNB][3], b_mat[JNB][9], b_axis[JNB][3], b_qpos0[JNB];
+  float b_qpos0_lo[JNB];   // joint reference angle: fp64 value - b_qpos0 (ref 3.14 is 1.05e-7 away from its float)
   float b_mass[JNB], b_com[JNB][3], b_inertia[JNB][6];  // xx yy zz xy xz yz about the CoM, body frame
   float b_range[JNB][2], b_solref[JNB][2], b_solimp[JNB][5];  // joint-limit solver parameters
   unsigned b_chainmask[JNB];                       // bit d set: dof d moves body b

@@ -130,6 +130,10 @@ JDEV int dev_load_relaxed(const int* p) { return __hip_atomic_load(p, __ATOMIC_R
 JDEV void dev_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
 JDEV void wave_sleep() { __builtin_amdgcn_s_sleep(127); }   // ~8k cycles
 
+// Individually rounded product (never contracted into an fma with a neighbouring add): the error-free transformations of the
+// compensated state update (physics_kernel.h, comp_add) need the rounded product itself as an operand.
+JDEV float fmul_rn(float a, float b) { return __fmul_rn(a, b); }
+
 // Pin three already-loaded values in VGPRs here: keeps the optimiser from sinking their loads into a (divergent) branch.
 JDEV void keep_loaded(float& a, float& b, float& c) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c)); }
 

@@ -33,6 +33,7 @@ struct JacoHandle {
   float* hull_dev = nullptr;
   float* qpos0_dev = nullptr;   // [nq] reset pose, uploaded once (resets never touch host memory)
   float *qpos = nullptr, *qvel = nullptr, *qacc_ws = nullptr, *sensordata = nullptr, *dbg = nullptr;
+  float *qpos_lo = nullptr, *qvel_lo = nullptr;   // low-order parts of the compensated state (physics_kernel.h, comp_add): zero after any state write from outside
   unsigned* flags = nullptr;
   int* stats = nullptr;
   int* remaining = nullptr;
@@ -120,6 +121,10 @@ extern "C" int jaco_create(const JacoConfig* cfg, JacoHandle** out) {
   CREATECHK(hipMalloc(&h->qpos, B * m.nq * sizeof(float)));
   CREATECHK(hipMalloc(&h->qvel, B * m.nv * sizeof(float)));
   CREATECHK(hipMalloc(&h->qacc_ws, B * m.nv * sizeof(float)));
+  CREATECHK(hipMalloc(&h->qpos_lo, B * m.nq * sizeof(float)));
+  CREATECHK(hipMalloc(&h->qvel_lo, B * m.nv * sizeof(float)));
+  CREATECHK(hipMemset(h->qpos_lo, 0, B * m.nq * sizeof(float)));
+  CREATECHK(hipMemset(h->qvel_lo, 0, B * m.nv * sizeof(float)));
   CREATECHK(hipMalloc(&h->sensordata, B * (m.nsensor > 0 ? m.nsensor : 1) * sizeof(float)));
   CREATECHK(hipMalloc(&h->flags, B * sizeof(unsigned)));
   CREATECHK(hipMalloc(&h->stats, B * 4 * sizeof(int)));
@@ -196,7 +201,7 @@ extern "C" int jaco_destroy(JacoHandle* h) {
   }
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_pre) (void)hipEventDestroy(h->ev_pre);
-  void* ptrs[] = {h->model_dev, h->hull_dev, h->qpos, h->qvel, h->qacc_ws, h->sensordata, h->flags, h->stats, h->dbg, h->prof, h->remaining, h->qlist, h->qctl, h->hint, h->routed_mark, h->task_rows, h->cache, h->cost, h->order, h->marker, h->order_ctl, h->qpos0_dev};
+  void* ptrs[] = {h->model_dev, h->hull_dev, h->qpos, h->qvel, h->qacc_ws, h->qpos_lo, h->qvel_lo, h->sensordata, h->flags, h->stats, h->dbg, h->prof, h->remaining, h->qlist, h->qctl, h->hint, h->routed_mark, h->task_rows, h->cache, h->cost, h->order, h->marker, h->order_ctl, h->qpos0_dev};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   delete h;
   return JACO_OK;
@@ -220,7 +225,9 @@ extern "C" int jaco_set_state(JacoHandle* h, const float* qpos, const float* qve
   hipStream_t st = (hipStream_t)stream;
   size_t B = h->num_envs;
   if (qpos) HIPCHK(h, hipMemcpyAsync(h->qpos, qpos, B * h->model_host.nq * sizeof(float), hipMemcpyDeviceToDevice, st));
-  if (qpos) HIPCHK(h, hipMemsetAsync(h->hint, 0, B * sizeof(int), st));   // a state from outside starts in the light tier: results depend on the state alone
+  if (qpos) HIPCHK(h, hipMemsetAsync(h->hint, 0, B * sizeof(int), st));
+  if (qpos) HIPCHK(h, hipMemsetAsync(h->qpos_lo, 0, B * h->model_host.nq * sizeof(float), st));   // the state handed in is exactly the floats
+  if (qvel) HIPCHK(h, hipMemsetAsync(h->qvel_lo, 0, B * h->model_host.nv * sizeof(float), st));   // a state from outside starts in the light tier: results depend on the state alone
   if (qvel) HIPCHK(h, hipMemcpyAsync(h->qvel, qvel, B * h->model_host.nv * sizeof(float), hipMemcpyDeviceToDevice, st));
   if (qacc_ws) HIPCHK(h, hipMemcpyAsync(h->qacc_ws, qacc_ws, B * h->model_host.nv * sizeof(float), hipMemcpyDeviceToDevice, st));
   return JACO_OK;
@@ -251,6 +258,8 @@ extern "C" int jaco_reset_state(JacoHandle* h, void* stream) {
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipMemsetAsync(h->qvel, 0, B * m.nv * sizeof(float), st));
   HIPCHK(h, hipMemsetAsync(h->qacc_ws, 0, B * m.nv * sizeof(float), st));
+  HIPCHK(h, hipMemsetAsync(h->qpos_lo, 0, B * m.nq * sizeof(float), st));
+  HIPCHK(h, hipMemsetAsync(h->qvel_lo, 0, B * m.nv * sizeof(float), st));
   HIPCHK(h, hipMemsetAsync(h->hint, 0, B * sizeof(int), st));
   // markers back to their XML rest pose (sim.reset() restores mocap_pos / mocap_quat)
   const float* rest = (const float*)((const char*)h->model_dev + offsetof(JacoModelDev, marker_rest));
@@ -411,7 +420,7 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
   if ((!ctrl && io.mode == 0) || nsub <= 0) { h->err = "jaco_physics_step: bad arguments"; return JACO_EINVAL; }
   ENTER(h);
   JacoStepArgs A{};
-  A.model = h->model_dev; A.hull = h->hull_dev; A.qpos = h->qpos; A.qvel = h->qvel; A.qacc_ws = h->qacc_ws;
+  A.model = h->model_dev; A.hull = h->hull_dev; A.qpos = h->qpos; A.qvel = h->qvel; A.qacc_ws = h->qacc_ws; A.qpos_lo = h->qpos_lo; A.qvel_lo = h->qvel_lo;
   A.ctrl = ctrl ? ctrl : h->qvel;   // env modes compute ctrl in-kernel; the pointer only has to be readable
   A.sensordata = h->sensordata; A.flags = h->flags; A.stats = h->stats; A.nenv = h->num_envs; A.nsub = nsub;
   A.disable_contact = h->disable_contact; A.no_tier_return = !h->tier_return; A.dbg = dbg; A.dbg_env = dbg_env; A.prof = h->prof;
@@ -488,6 +497,7 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
   // drain grids = the tiers' full occupancy on 256 CUs (8 / 4 / 2 workgroups per CU by LDS and registers); slots are claimed one at a time
   unsigned mg = ne < 2048 ? ne : 2048, hg = ne < JACO_HEAVY_GRID ? ne : JACO_HEAVY_GRID, gg = ne < 512 ? ne : 512;
   if (io.mode == 2) { mg = mg < 64 ? mg : 64; hg = hg < 64 ? hg : 64; gg = gg < 256 ? gg : 256; }   // (reset-time forward passes: overflows of the light tier go straight to the last one)
+  if (io.mode >= 4) { if (ev) HIPCHK(h, hipEventRecord(ev->second, st)); return JACO_OK; }   // take_action / terminal_inspection run no substep: nothing can overflow
   if (io.mode != 2) hipLaunchKernelGGL(jaco_physics_kernel_medium_drain, dim3(mg), dim3(64), 0, st, A);   // (mode 2 queues for the last tier only)
   if (h->handdown && io.mode == 1) {
     // the heavy tier holds 4 envs per CU: an env that needed it for a few substeps is passed back down to a second medium drain
@@ -511,7 +521,7 @@ extern "C" int jaco_physics_step(JacoHandle* h, const float* ctrl_dev, int nsub,
 }
 // ---- env level: reset / step with the reference's Gym-style semantics, batched -------------------------
 struct JacoResetArgs {
-  const float* qpos0; float* qpos; float* qvel; float* qacc_ws; float* task; const unsigned char* mask; float* marker; const float* marker_rest;
+  const float* qpos0; float* qpos; float* qvel; float* qacc_ws; float* qpos_lo; float* qvel_lo; float* task; const unsigned char* mask; float* marker; const float* marker_rest;
   int nenv, nq, nv, task_id, has_free; unsigned long long seed;
   float base[3];   // link1 position: the reaching goal's orientation looks along base -> goal (env_mujoco_util.py:201-205)
   int* list; unsigned* list_count;   // the reset envs, for the launches that follow (forward pass, placing hold)
@@ -524,8 +534,8 @@ __global__ void jaco_reset_kernel(JacoResetArgs R) {
   unsigned c = __float_as_uint(t[JT_RNG]);
   auto U = [&](float lo, float hi) { float u = rng_uniform(R.seed, (unsigned)e, c++); return lo + (hi - lo) * u; };
   float* q = R.qpos + (size_t)e * R.nq;
-  for (int k = 0; k < R.nq; k++) q[k] = R.qpos0[k];
-  for (int k = 0; k < R.nv; k++) { R.qvel[(size_t)e * R.nv + k] = 0.f; R.qacc_ws[(size_t)e * R.nv + k] = 0.f; }
+  for (int k = 0; k < R.nq; k++) { q[k] = R.qpos0[k]; R.qpos_lo[(size_t)e * R.nq + k] = 0.f; }
+  for (int k = 0; k < R.nv; k++) { R.qvel[(size_t)e * R.nv + k] = 0.f; R.qacc_ws[(size_t)e * R.nv + k] = 0.f; R.qvel_lo[(size_t)e * R.nv + k] = 0.f; }
   for (int k = 0; k < 24; k++) R.marker[(size_t)e * 24 + k] = R.marker_rest[k];   // sim.reset(): markers back to their XML pose
   // _create_init_angle (env_mujoco_util.py:176-185); fingers stay at qpos0 (mujoco.py:342-343)
   if (R.task_id == JACO_TASK_PLACING) {
@@ -577,7 +587,7 @@ extern "C" int jaco_reset(JacoHandle* h, const uint8_t* mask_dev, float* obs_dev
   hipStream_t st = (hipStream_t)stream;
   const JacoModelDev& m = h->model_host;
   const float* rest = (const float*)((const char*)h->model_dev + offsetof(JacoModelDev, marker_rest));
-  JacoResetArgs R{h->qpos0_dev, h->qpos, h->qvel, h->qacc_ws, h->task_rows, mask_dev, h->marker, rest, h->num_envs, m.nq, m.nv, h->task, m.nq >= 23, h->seed, {m.base_pos[0], m.base_pos[1], m.base_pos[2]}, h->order, h->order_ctl + 67};
+  JacoResetArgs R{h->qpos0_dev, h->qpos, h->qvel, h->qacc_ws, h->qpos_lo, h->qvel_lo, h->task_rows, mask_dev, h->marker, rest, h->num_envs, m.nq, m.nv, h->task, m.nq >= 23, h->seed, {m.base_pos[0], m.base_pos[1], m.base_pos[2]}, h->order, h->order_ctl + 67};
   if (mask_dev) HIPCHK(h, hipMemsetAsync(h->order_ctl + 67, 0, sizeof(unsigned), st));
   h->reset_listed = mask_dev != nullptr;
   hipLaunchKernelGGL(jaco_reset_kernel, dim3((unsigned)((h->num_envs + 255) / 256)), dim3(256), 0, st, R);
@@ -710,6 +720,7 @@ extern "C" int jaco_set_option(JacoHandle* h, const char* name, double v) {
   else if (!strcmp(name, "mpr_iterations")) m.mpr_iterations = (int)v;
   else if (!strcmp(name, "mpr_tolerance")) m.mpr_tolerance = (float)v;
   else if (!strcmp(name, "mpr_output")) m.mpr_output = (int)v;
+  else if (!strcmp(name, "compensated")) m.compensated = v != 0;
   else { h->err = std::string("jaco_set_option: unknown option ") + name; return JACO_EINVAL; }
   HIPCHK(h, hipDeviceSynchronize());
   return upload_model(h);

@@ -78,7 +78,7 @@ int jaco_model_from_blob(const void* buf, size_t size, JacoModelDev* m, std::vec
   const double *mi = B.f64("meaninertia", 1), *mt = B.f64("opt_mpr_tolerance", 1);
   const int32_t *it = B.i32("opt_iterations", 1), *mpi = B.i32("opt_mpr_iterations", 1);
   if (!ts || !gr || !tol || !mi || !mt || !it || !mpi) FAIL(B.err);
-  m->timestep = (float)*ts; cp3(m->gravity, gr); m->tolerance = (float)*tol; m->meaninertia = (float)*mi;
+  m->timestep = (float)*ts; m->timestep_lo = (float)(*ts - (double)m->timestep); m->compensated = 1; cp3(m->gravity, gr); m->tolerance = (float)*tol; m->meaninertia = (float)*mi;
   m->mpr_tolerance = (float)*mt; m->iterations = *it; m->mpr_iterations = *mpi; m->ls_iterations = 50; m->ls_tolerance = 0.01f; m->mpr_output = 1;
 
   // ---- bodies
@@ -96,7 +96,7 @@ int jaco_model_from_blob(const void* buf, size_t size, JacoModelDev* m, std::vec
     if (jt[b] == JJ_FREE && par[b] != -1) FAIL("free joint must hang off the world");
     m->b_parent[b] = par[b]; m->b_jtype[b] = jt[b]; m->b_qadr[b] = qa[b]; m->b_dadr[b] = da[b]; m->b_limited[b] = lim[b];
     cp3(m->b_pos[b], pos + 3 * b); quat2mat(quat + 4 * b, m->b_mat[b]); cp3(m->b_axis[b], axis + 3 * b);
-    m->b_qpos0[b] = (float)q0[b]; m->b_mass[b] = (float)mass[b]; cp3(m->b_com[b], com + 3 * b);
+    m->b_qpos0[b] = (float)q0[b]; m->b_qpos0_lo[b] = (float)(q0[b] - (double)m->b_qpos0[b]); m->b_mass[b] = (float)mass[b]; cp3(m->b_com[b], com + 3 * b);
     for (int k = 0; k < 6; k++) m->b_inertia[b][k] = (float)inr[6 * b + k];
     m->b_range[b][0] = (float)rng[2 * b]; m->b_range[b][1] = (float)rng[2 * b + 1];
     m->b_solref[b][0] = (float)fmax(jsr[2 * b], 2 * *ts); m->b_solref[b][1] = (float)jsr[2 * b + 1];  // refsafe

@@ -82,6 +82,8 @@ struct JacoStepArgs {
   const float* hull;   // float4 per hull vertex
   float* qpos;         // [nenv][nq]
   float* qvel;         // [nenv][nv]
+  float* qpos_lo;      // [nenv][nq] low-order part of the compensated state (qpos + qpos_lo is the state; |lo| <= ulp(qpos) / 2), or nullptr:
+  float* qvel_lo;      // [nenv][nv]   starts at 0 and is dropped at the end of the launch
   float* qacc_ws;      // [nenv][nv]  warm start (= last qacc)
   const float* ctrl;   // [nenv][nu]
   float* sensordata;   // [nenv][nsensor]
@@ -167,6 +169,7 @@ template <class C>
 struct JacoLDS {
   typedef C Caps;
   float qpos[24], qvel[24], qacc_ws[24], ctrl[12];
+  float qpos_lo[24], qvel_lo[24];               // compensated state: what every stage reads is the fp32 rounding (qpos, qvel) of hi + lo
   float xpos[JNB][3], xmat[JNB][9];
   float cdof[JNV][6];
   float cvel[JNB][6];
@@ -212,6 +215,7 @@ struct JacoLDS {
     unsigned b_descmask[JNB];
     int b_anc[JNB][3];                          // ancestors 1, 2 and 4 levels up (-1: none), for the pointer-jumping tree stages
     int d_body[JNV], d_parent[JNV];
+    int q_dof[JNQ + 1];                         // dof that advances position coordinate q linearly (hinge angle, free-body translation), -1: quaternion component
   } mc;
 };
 static_assert(JB1 - JB0 == 6 && JNV - JB1 == 6, "dof blocks");
@@ -228,6 +232,11 @@ JDEV void stage_model(const JacoModelDev* m, L& s, int lane) {
     s.mc.b_descmask[b] = m->b_descmask[b];
     if (b < JMAXINNER) s.mc.inner_body[b] = m->inner_body[b];
     s.mc.b_anc[b][0] = p1; s.mc.b_anc[b][1] = p2; s.mc.b_anc[b][2] = p4;
+    const int qa = m->b_qadr[b], da = m->b_dadr[b];
+    if (b < m->nbody) {
+      if (m->b_jtype[b] == JJ_HINGE) s.mc.q_dof[qa] = da;
+      else { for (int k = 0; k < 3; k++) s.mc.q_dof[qa + k] = da + k; for (int k = 3; k < 7; k++) s.mc.q_dof[qa + k] = -1; }
+    }
   }
   if (lane < JNV) { s.mc.d_body[lane] = m->d_body[lane]; s.mc.d_parent[lane] = m->d_parent[lane]; }
 }
@@ -293,9 +302,10 @@ JDEV void joint_sincos(float x, float* sn, float* cs) {
   *cs = ((q + 1) & 2) ? -b : b;
 }
 // rotation by angle about unit axis (Rodrigues)
-JDEV m3 axis_rot(v3 a, float ang) {
+JDEV m3 axis_rot(v3 a, float ang, float ang_lo = 0.f) {
   float s, c;
   joint_sincos(ang, &s, &c);
+  { const float s0 = s; s = fmaf(ang_lo, c, s); c = fmaf(-ang_lo, s0, c); }   // first-order in the low part of the angle (|ang_lo| < 3e-7)
   float t = 1.f - c;
   m3 r;
   r.m[0] = c + t * a.x * a.x; r.m[1] = t * a.x * a.y - s * a.z; r.m[2] = t * a.x * a.z + s * a.y;
@@ -321,6 +331,28 @@ JDEV sv inert_mul(const float* I, sv mv) {
   r.a = mk3(I[4] * mv.a.x + I[7] * mv.a.y + I[8] * mv.a.z + t.x, I[7] * mv.a.x + I[5] * mv.a.y + I[9] * mv.a.z + t.y,
             I[8] * mv.a.x + I[9] * mv.a.y + I[6] * mv.a.z + t.z);
   return r;
+}
+
+// ---------------------------------------------------------------- compensated state (hi + lo floats)
+// The state the integrators advance is the unevaluated sum hi + lo (|lo| <= ulp(hi) / 2, ~48 significant bits): per-step fp32
+// rounding of qpos (2.4e-7 at q ~ 4 rad) would otherwise be ~4 000 x the rounding of the increment h * qvel itself and
+// random-walks the state away from the fp64 trajectory (tools/drift_control.py variants B / E / F).
+// Every stage still computes in fp32 on the rounded view `hi`; rounding perturbs each evaluation but no longer accumulates.
+struct f2 { float hi, lo; };
+// (hi, lo) + (inc + inc_lo): Knuth two-sum for the leading parts, then renormalisation.  No products inside (nothing to contract).
+JDEV f2 comp_add(float hi, float lo, float inc, float inc_lo) {
+  const float s = hi + inc, bb = s - hi;
+  const float e = (hi - (s - bb)) + (inc - bb);
+  const float l = lo + (e + inc_lo);
+  f2 r;
+  r.hi = s + l;
+  r.lo = l - (r.hi - s);
+  return r;
+}
+// (hi, lo) + h * (v + v_lo) with the step h = hh + hl (the fp64 value of opt.timestep): exact product error by fma
+JDEV f2 comp_advance(float hi, float lo, float hh, float hl, float v, float v_lo) {
+  const float p = fmul_rn(hh, v), pe = fmaf(hh, v, -p);
+  return comp_add(hi, lo, p, pe + fmaf(hh, v_lo, hl * v));
 }
 
 // ---------------------------------------------------------------- LDL^T solve, one matrix row per lane
@@ -499,9 +531,10 @@ JDEV void stage_walk(const JacoModelDev* m, L& s, int lane, bool markers, JProfC
   float* Sq2 = s.J + JNV * 6;    // [JNV][6] S_d-dot * qvel_d
   const bool isb = lane < nb;
   const int b = isb ? lane : 0;
-  const int jt = s.mc.b_jtype[b], qa = s.mc.b_qadr[b], da = s.mc.b_dadr[b];
+  const int jt = s.mc.b_jtype[b], qa = s.mc.b_qadr[b];
   const int a1 = s.mc.b_anc[b][0], a2 = s.mc.b_anc[b][1], a4 = s.mc.b_anc[b][2];
   const unsigned chain = isb ? m->b_chainmask[b] : 0u;   // dofs that move this body (used two stages further down)
+  const float q0lo = m->b_qpos0_lo[b];
   // Model constants of the later phases, issued now: their L2 latency overlaps the frame composition below instead of being paid
   // right before their use (nothing may cross the wave_sync fences on its own).
   float Imod[6];
@@ -520,7 +553,12 @@ JDEV void stage_walk(const JacoModelDev* m, L& s, int lane, bool markers, JProfC
   for (int k = 0; k < 10; k++) io[k] = 0.f;
   if (isb) {
     if (jt == JJ_HINGE) {
-      R = mul(ldm(s.mc.b_mat[b]), axis_rot(ld3(s.mc.b_axis[b]), s.qpos[qa] - s.mc.b_qpos0[b]));
+      // joint angle relative to the reference, from the compensated state: hi part q - q0 with its exact rounding error (two-sum),
+      // low part = state's low part - reference's low part (ref 3.14: 1.05e-7 off its float) + that error
+      const float q = s.qpos[qa], q0 = s.mc.b_qpos0[b];
+      const float ah = q - q0, bb = ah - q;
+      const float al = ((q - (ah - bb)) + (-q0 - bb)) + (s.qpos_lo[qa] - q0lo);
+      R = mul(ldm(s.mc.b_mat[b]), axis_rot(ld3(s.mc.b_axis[b]), ah, al));
       pos = ld3(s.mc.b_pos[b]);
     } else {
       float w = s.qpos[qa + 3], x = s.qpos[qa + 4], y = s.qpos[qa + 5], z = s.qpos[qa + 6];
@@ -1041,36 +1079,66 @@ JDEV NewtonOut stage_newton(const JacoModelDev* m, L& s, const float (&mrow)[JNV
 // ---------------------------------------------------------------- stage E: integration
 template <class L>
 JDEV void stage_integrate_pos(const JacoModelDev* m, L& s, int lane) {
-  float h = m->timestep;
-  if (lane < m->nbody) {
-    int b = lane, qa = s.mc.b_qadr[b], da = s.mc.b_dadr[b];
-    if (s.mc.b_jtype[b] == JJ_HINGE) {
-      s.qpos[qa] += h * s.qvel[da];
-    } else {
-      for (int k = 0; k < 3; k++) s.qpos[qa + k] += h * s.qvel[da + k];
-      v3 w = ld3(&s.qvel[da + 3]);
-      float wn = norm(w), ang = h * wn;
-      float q0 = s.qpos[qa + 3], q1 = s.qpos[qa + 4], q2 = s.qpos[qa + 5], q3 = s.qpos[qa + 6];
-      if (ang > 0.f) {
-        v3 ax = w * (1.f / wn);
-        float sn, c;
-        sincosf(0.5f * ang, &sn, &c);
-        float d1 = ax.x * sn, d2 = ax.y * sn, d3 = ax.z * sn;
-        float n0 = q0 * c - q1 * d1 - q2 * d2 - q3 * d3;
-        float n1 = q0 * d1 + q1 * c + q2 * d3 - q3 * d2;
-        float n2 = q0 * d2 - q1 * d3 + q2 * c + q3 * d1;
-        float n3 = q0 * d3 + q1 * d2 - q2 * d1 + q3 * c;
-        q0 = n0; q1 = n1; q2 = n2; q3 = n3;
-      }
-      float n = sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
-      if (n < JMINVAL) { q0 = 1.f; q1 = q2 = q3 = 0.f; } else { float in = 1.f / n; q0 *= in; q1 *= in; q2 *= in; q3 *= in; }
-      s.qpos[qa + 3] = q0; s.qpos[qa + 4] = q1; s.qpos[qa + 5] = q2; s.qpos[qa + 6] = q3;
+  const float h = m->timestep, hl = m->timestep_lo;
+  const bool comp = m->compensated != 0;
+  // lane = position coordinate: hinge angles and free-body translations advance by h * (their dof's velocity)
+  if (lane < m->nq) {
+    const int d = s.mc.q_dof[lane];
+    if (d >= 0) {
+      if (comp) { const f2 r = comp_advance(s.qpos[lane], s.qpos_lo[lane], h, hl, s.qvel[d], s.qvel_lo[d]); s.qpos[lane] = r.hi; s.qpos_lo[lane] = r.lo; }
+      else s.qpos[lane] += h * s.qvel[d];
     }
   }
+  // lane = free body: quaternion integration with the body-frame angular velocity, then normalisation
+  if (lane < m->nbody && s.mc.b_jtype[lane] != JJ_HINGE) {
+    const int qa = s.mc.b_qadr[lane], da = s.mc.b_dadr[lane];
+    const v3 w = ld3(&s.qvel[da + 3]);
+    const float ww = dot(w, w), x2 = 0.25f * h * h * ww;   // (ang / 2)^2, ang = h |w|
+    float q0 = s.qpos[qa + 3], q1 = s.qpos[qa + 4], q2 = s.qpos[qa + 5], q3 = s.qpos[qa + 6];
+    float l0 = comp ? s.qpos_lo[qa + 3] : 0.f, l1 = comp ? s.qpos_lo[qa + 4] : 0.f, l2 = comp ? s.qpos_lo[qa + 5] : 0.f, l3 = comp ? s.qpos_lo[qa + 6] : 0.f;
+    if (ww > 0.f) {
+      // q <- q (x) dq,  dq = (cos(ang/2), axis sin(ang/2)), written as the increment  q (cos(ang/2) - 1) + q (x) (0, d)  with
+      // d = w (h/2) sinc(ang/2): no axis normalisation, and cos - 1 without cancellation
+      float sc, cm1;   // sin(x) / x and cos(x) - 1 at x = ang / 2
+      if (x2 < 0.01f) {   // |x| < 0.1 (angular velocity < 200 rad/s at h = 1 ms): series, truncation < 1e-13
+        sc = 1.f + x2 * (-1.f / 6.f + x2 * (1.f / 120.f - x2 * (1.f / 5040.f)));
+        cm1 = x2 * (-0.5f + x2 * (1.f / 24.f - x2 * (1.f / 720.f)));
+      } else {
+        const float x = sqrtf(x2), s4 = sinf(0.5f * x);
+        sc = sinf(x) / x; cm1 = -2.f * s4 * s4;
+      }
+      const float k = 0.5f * h * sc, d1 = w.x * k, d2 = w.y * k, d3 = w.z * k;
+      const float e0 = q0 * cm1 - q1 * d1 - q2 * d2 - q3 * d3;
+      const float e1 = q1 * cm1 + q0 * d1 + q2 * d3 - q3 * d2;
+      const float e2 = q2 * cm1 + q0 * d2 - q1 * d3 + q3 * d1;
+      const float e3 = q3 * cm1 + q0 * d3 + q1 * d2 - q2 * d1;
+      if (comp) {
+        f2 r;
+        r = comp_add(q0, l0, e0, 0.f); q0 = r.hi; l0 = r.lo;
+        r = comp_add(q1, l1, e1, 0.f); q1 = r.hi; l1 = r.lo;
+        r = comp_add(q2, l2, e2, 0.f); q2 = r.hi; l2 = r.lo;
+        r = comp_add(q3, l3, e3, 0.f); q3 = r.hi; l3 = r.lo;
+      } else { q0 += e0; q1 += e1; q2 += e2; q3 += e3; }
+    }
+    // |q|^2 - 1 (fma chain: ~1e-7 absolute, which is all a norm needs -- a common scale factor does not touch the rotation, and the
+    // scaling itself is applied to the compensated pair, so the direction of q keeps its ~48 bits)
+    const float r2 = fmaf(q3, q3, fmaf(q2, q2, fmaf(q1, q1, fmaf(q0, q0, -1.f)))) + 2.f * (q0 * l0 + q1 * l1 + q2 * l2 + q3 * l3);
+    if (comp && fabsf(r2) < 1e-3f) {
+      const float k = r2 * (-0.5f + 0.375f * r2);   // 1 / sqrt(1 + r2) - 1
+      f2 r;
+      r = comp_add(q0, l0, q0 * k, 0.f); q0 = r.hi; l0 = r.lo;
+      r = comp_add(q1, l1, q1 * k, 0.f); q1 = r.hi; l1 = r.lo;
+      r = comp_add(q2, l2, q2 * k, 0.f); q2 = r.hi; l2 = r.lo;
+      r = comp_add(q3, l3, q3 * k, 0.f); q3 = r.hi; l3 = r.lo;
+    } else {   // plain state, or a quaternion handed in un-normalised (set_state; the reference's zero quaternion, env_mujoco_util.py:119-121)
+      const float n = sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
+      if (n < JMINVAL) { q0 = 1.f; q1 = q2 = q3 = 0.f; } else { const float in = 1.f / n; q0 *= in; q1 *= in; q2 *= in; q3 *= in; }
+      l0 = l1 = l2 = l3 = 0.f;
+    }
+    s.qpos[qa + 3] = q0; s.qpos[qa + 4] = q1; s.qpos[qa + 5] = q2; s.qpos[qa + 6] = q3;
+    if (comp) { s.qpos_lo[qa + 3] = l0; s.qpos_lo[qa + 4] = l1; s.qpos_lo[qa + 5] = l2; s.qpos_lo[qa + 6] = l3; }
+  }
 }
-
-#include "collision.h"
-#include "env_logic.h"
 
 #include "collision.h"
 #include "env_logic.h"
@@ -1103,8 +1171,8 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
   const JacoModelDev* m = opaque_ptr(A.model);
   const int nq = m->nq, nv = m->nv, nu = m->nu, ns = m->nsensor;
   if ((A.env_mode == 3 || A.env_mode == 2) && A.mask && !A.mask[env]) return 0;   // masked reset: the other envs are not touched
-  if (lane < nq) s.qpos[lane] = A.qpos[(size_t)env * nq + lane];
-  if (lane < nv) { s.qvel[lane] = A.qvel[(size_t)env * nv + lane]; s.qacc_ws[lane] = A.qacc_ws[(size_t)env * nv + lane]; }
+  if (lane < nq) { s.qpos[lane] = A.qpos[(size_t)env * nq + lane]; s.qpos_lo[lane] = A.qpos_lo ? A.qpos_lo[(size_t)env * nq + lane] : 0.f; }
+  if (lane < nv) { s.qvel[lane] = A.qvel[(size_t)env * nv + lane]; s.qacc_ws[lane] = A.qacc_ws[(size_t)env * nv + lane]; s.qvel_lo[lane] = A.qvel_lo ? A.qvel_lo[(size_t)env * nv + lane] : 0.f; }
   if (lane < nu) s.ctrl[lane] = A.ctrl[(size_t)env * nu + lane];
   stage_model(m, s, lane);
   unsigned flags = LIGHT ? 0u : JFLAG_HEAVY_TIER;
@@ -1124,13 +1192,17 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
     if (lane < 9) s.xmat[m->ee_body][lane] = CR[JC_EEMAT + lane];
   }
   wave_sync();
-  if (emode == 1 || emode == 4) {
-    if (s.task[JT_DONE] != 0.f) {   // finished and not yet reset: frozen (no auto-reset)
-      if (lane == 0 && emode == 1) { A.reward[env] = 0.f; A.done[env] = 1; }
+  if (emode == 1 || emode == 4 || emode == 5) {
+    if (s.task[JT_DONE] != 0.f) {   // finished (or quarantined) and not yet reset: frozen (no auto-reset); counters untouched
+      if (lane == 0 && emode != 4) { A.reward[env] = 0.f; A.done[env] = 1; }
       return 0;
     }
+  }
+  if (emode == 1 || emode == 4) {
     sub0 = wave_uniform_i((int)s.task[JT_SUB]);
-    if (sub0 == 0) {
+    // (a step that overflowed this tier in its very first substep comes back with JT_SUB = 0 and the interrupted substep pending:
+    // its action has been taken already -- taking it again would add the gripper increment twice and shift the draw counter)
+    if (sub0 == 0 && s.task[JT_PENDING] == 0.f) {
       // _take_action: the marker placement consumes 6 draws (a8), then the EE target and the gripper ramp
       // the previous target (subgoal_reach = policy sub-goal + self.target_pos, :609, reads it before the new one is set)
       float prev_tg[6];
@@ -1200,8 +1272,8 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
         t[JT_GRIP] = 0.6f; t[JT_GRIP_PREV] = 0.6f;
       }
       wave_sync();
-      if (lane >= 9 && lane < 16) s.qpos[lane] = pinv;
-      if (lane >= 9 && lane < nv) s.qvel[lane] = 0.f;
+      if (lane >= 9 && lane < 16) { s.qpos[lane] = pinv; s.qpos_lo[lane] = 0.f; }
+      if (lane >= 9 && lane < nv) { s.qvel[lane] = 0.f; s.qvel_lo[lane] = 0.f; }
     } else if (lane >= 9 && lane < 16) pinv = PIN[lane - 9];   // resumed by the heavy tier
     wave_sync();
     osc_target_quat(s, lane);
@@ -1368,7 +1440,11 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
     wave_sync();
     if (emode == 2) break;   // sim.forward(): derived quantities only, no integration
     if (lane < nv) {
-      float v = s.qvel[lane] + m->timestep * qacc_e;
+      float v;
+      if (m->compensated) {   // qvel += h qacc on the compensated pair
+        const f2 nvl = comp_advance(s.qvel[lane], s.qvel_lo[lane], m->timestep, m->timestep_lo, qacc_e, 0.f);
+        v = nvl.hi; s.qvel_lo[lane] = nvl.lo;
+      } else v = s.qvel[lane] + m->timestep * qacc_e;
       s.qvel[lane] = v;
       s.qacc_ws[lane] = nw.qacc;
       if (!(v == v) || fabsf(v) > 1e10f) flags |= JFLAG_NAN;
@@ -1377,8 +1453,8 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
     stage_integrate_pos(m, s, lane);
     wave_sync();
     if (emode == 3) {   // set_obj_xyz (mujoco.py:217-227): object back to the pinned pose, all free-body velocities zeroed
-      if (lane >= 9 && lane < 16) s.qpos[lane] = pinv;
-      if (lane >= 9 && lane < nv) s.qvel[lane] = 0.f;
+      if (lane >= 9 && lane < 16) { s.qpos[lane] = pinv; s.qpos_lo[lane] = 0.f; }
+      if (lane >= 9 && lane < nv) { s.qvel[lane] = 0.f; s.qvel_lo[lane] = 0.f; }
       wave_sync();
     }
     JSTAMP(8);
@@ -1393,11 +1469,11 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
   }
   if (emode != 2) {
     if (bailed) {   // handed over to another workgroup (possibly on another XCD): write-through stores
-      if (lane < nq) st_wt(&A.qpos[(size_t)env * nq + lane], s.qpos[lane]);
-      if (lane < nv) { st_wt(&A.qvel[(size_t)env * nv + lane], s.qvel[lane]); st_wt(&A.qacc_ws[(size_t)env * nv + lane], s.qacc_ws[lane]); }
+      if (lane < nq) { st_wt(&A.qpos[(size_t)env * nq + lane], s.qpos[lane]); if (A.qpos_lo) st_wt(&A.qpos_lo[(size_t)env * nq + lane], s.qpos_lo[lane]); }
+      if (lane < nv) { st_wt(&A.qvel[(size_t)env * nv + lane], s.qvel[lane]); st_wt(&A.qacc_ws[(size_t)env * nv + lane], s.qacc_ws[lane]); if (A.qvel_lo) st_wt(&A.qvel_lo[(size_t)env * nv + lane], s.qvel_lo[lane]); }
     } else {
-      if (lane < nq) A.qpos[(size_t)env * nq + lane] = s.qpos[lane];
-      if (lane < nv) { A.qvel[(size_t)env * nv + lane] = s.qvel[lane]; A.qacc_ws[(size_t)env * nv + lane] = s.qacc_ws[lane]; }
+      if (lane < nq) { A.qpos[(size_t)env * nq + lane] = s.qpos[lane]; if (A.qpos_lo) A.qpos_lo[(size_t)env * nq + lane] = s.qpos_lo[lane]; }
+      if (lane < nv) { A.qvel[(size_t)env * nv + lane] = s.qvel[lane]; A.qacc_ws[(size_t)env * nv + lane] = s.qacc_ws[lane]; if (A.qvel_lo) A.qvel_lo[(size_t)env * nv + lane] = s.qvel_lo[lane]; }
     }
   }
   if (left == 0 && lane < ns && A.sensordata && emode < 4) A.sensordata[(size_t)env * ns + lane] = sens;
@@ -1505,7 +1581,7 @@ JDEV void light_grid(const JacoStepArgs& A, JacoLDS<JacoLight>& s) {
   const bool masked_out = (A.env_mode == 2 || A.env_mode == 3) && A.mask && !A.mask[env];
   int left = 0;
   if (!masked_out) {
-    if (A.hint && A.env_mode >= 2 && lane == 0) st_wt_i(&A.hint[env], 0);   // a reset env starts from scratch (its forward pass may raise it again)
+    if (A.hint && (A.env_mode == 2 || A.env_mode == 3) && lane == 0) st_wt_i(&A.hint[env], 0);   // a reset env starts from scratch (its forward pass may raise it again)
     const unsigned long long t_start = wave_clock();
     left = run_env<JacoLight, 0>(A, s, env, A.nsub, lane);
     // (only real steps record their cost: the masked forward pass of a reset must not wipe the launch-order heuristic's input)

@@ -39,13 +39,55 @@ class _Box:
         self.__dict__.update(d)
 
 
+class _Opaque:
+    """Stand-in for objects the table carries but the forward pass never reads (the Box's numpy RandomState)."""
+
+    def __init__(self, *a, **k):
+        pass
+
+    def __setstate__(self, d):
+        self.state = d
+
+
+def _allowed_globals():
+    import collections
+    import copyreg
+    import _codecs
+    try:
+        from numpy._core import multiarray as ma   # numpy >= 2
+    except ImportError:   # pragma: no cover
+        from numpy.core import multiarray as ma
+    table = {}
+    for mod in ("numpy.core.multiarray", "numpy._core.multiarray"):
+        table[(mod, "_reconstruct")] = ma._reconstruct
+        table[(mod, "scalar")] = ma.scalar
+    table[("numpy", "ndarray")] = np.ndarray
+    table[("numpy", "dtype")] = np.dtype
+    for name in ("__randomstate_ctor", "__bit_generator_ctor", "__generator_ctor"):
+        table[("numpy.random._pickle", name)] = _Opaque
+    for name in ("dict", "list", "tuple", "set", "frozenset", "int", "float", "str", "bytes", "bool", "slice", "range", "complex"):
+        table[("builtins", name)] = getattr(__import__("builtins"), name)
+    table[("collections", "OrderedDict")] = collections.OrderedDict
+    table[("copyreg", "_reconstructor")] = copyreg._reconstructor
+    table[("_codecs", "encode")] = _codecs.encode
+    return table
+
+
 class _Unpickler(pickle.Unpickler):
+    """Exact (module, name) allowlist: the `primitives` blob of a policy.zip is untrusted input (a pickle), and anything beyond the
+    handful of constructors the reference's own zips use -- numpy array / dtype reconstruction, gym's Box, plain containers -- is
+    refused.  No module prefix is trusted: `builtins.eval`, `numpy.testing...` etc. raise."""
+    _table = None
+
     def find_class(self, module, name):
-        if module.startswith("gym.spaces"):
+        if module in ("gym.spaces.box", "gym.spaces", "gym.spaces.space") and name in ("Box", "Space"):
             return _Box
-        if module.startswith("numpy") or module in ("builtins", "collections", "copyreg", "_codecs"):
-            return super().find_class(module, name)
-        raise pickle.UnpicklingError("refusing %s.%s" % (module, name))
+        if _Unpickler._table is None:
+            _Unpickler._table = _allowed_globals()
+        try:
+            return _Unpickler._table[(module, name)]
+        except KeyError:
+            raise pickle.UnpicklingError("policy.zip primitives table: refusing global %s.%s" % (module, name))
 
 
 def _tail_from_params(P, prefix):

@@ -25,7 +25,8 @@ struct OrcModel {
   double timestep, gravity[3], tolerance, mpr_tolerance, meaninertia;
   int iterations, mpr_iterations, disable_contact, solver, ls_iterations;
   int mpr_output;  /* 0: libccd's closest point of the final portal triangle; 1 (default): portal plane (see mpr_penetration) */
-  int round_state; /* control experiment: 1 = qpos/qvel/qacc_warmstart are rounded to fp32 after every step (an fp64 engine carrying fp32 state) */
+  int round_state; /* control experiments: 1 = qpos/qvel/qacc_warmstart are rounded to fp32 after every step (an fp64 engine carrying fp32 state);
+                      2 = fp64 state, but the forward pass sees its fp32 rounding (an engine that carries its state compensated) */
   double ls_tolerance;
   int *body_parentid, *body_weldid, *body_mocapid, *body_jntadr, *body_jntnum, *body_dofadr, *body_dofnum;
   double *body_pos, *body_quat, *body_ipos, *body_inertia, *body_mass, *body_invweight0;
@@ -1303,9 +1304,24 @@ static void integrate(const OrcModel* m, OrcData* d) {
   free(qacc);
 }
 void orc_step(const OrcModel* m, OrcData* d) {
+  if (m->round_state >= 2) {
+    /* control experiment: the STATE stays fp64, but everything the forward pass derives (kinematics, contacts, forces, qacc)
+     * sees its fp32 rounding -- the ceiling for an fp32 engine that carries its state compensated (hi + lo floats): rounding
+     * then perturbs each evaluation but never accumulates in the state */
+    double q[64], v[64];
+    memcpy(q, d->qpos, sizeof(double) * m->nq);
+    memcpy(v, d->qvel, sizeof(double) * m->nv);
+    for (int i = 0; i < m->nq; i++) if (!(m->round_state == 3 && i == 18)) d->qpos[i] = (double)(float)d->qpos[i];   /* (3: the pedestal's height keeps its exact value -- its bottom face starts exactly on the floor plane, see tools/drift_control.py variant D) */
+    for (int i = 0; i < m->nv; i++) d->qvel[i] = (double)(float)d->qvel[i];
+    orc_forward(m, d);
+    memcpy(d->qpos, q, sizeof(double) * m->nq);
+    memcpy(d->qvel, v, sizeof(double) * m->nv);
+    integrate(m, d);
+    return;
+  }
   orc_forward(m, d);
   integrate(m, d);
-  if (m->round_state) { /* control experiment (tools/drift_control.py): what an fp32-state engine loses per step, nothing else */
+  if (m->round_state == 1) { /* control experiment (tools/drift_control.py): what an fp32-state engine loses per step, nothing else */
     for (int i = 0; i < m->nq; i++) d->qpos[i] = (double)(float)d->qpos[i];
     for (int i = 0; i < m->nv; i++) { d->qvel[i] = (double)(float)d->qvel[i]; d->qacc_warmstart[i] = (double)(float)d->qacc_warmstart[i]; }
   }

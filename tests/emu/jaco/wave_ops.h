@@ -33,6 +33,7 @@ JDEV void wave_sleep() {}
 JDEV unsigned long long wave_clock() { return 0ull; }
 JDEV int wave_uniform_i(int v) { return wave_bcast_i(v, 0); }
 JDEV void keep_loaded(float&, float&, float&) {}
+JDEV float fmul_rn(float a, float b) { volatile float p = a * b; return p; }
 JDEV int wave_opaque_i(int v) { return v; }
 JDEV float wave_shfl(float v, int src) { int p = emu_post_f(v); emu_collective(); return emu_x[p][src & 63].f; }
 JDEV int wave_shfl_i(int v, int src) { int p = emu_post_i(v); emu_collective(); return emu_x[p][src & 63].i; }

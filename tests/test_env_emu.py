@@ -215,3 +215,21 @@ def test_non_finite_state_is_quarantined_not_followed_out_of_bounds(names, model
         assert done[0] == 1 and rew[0] == 0 and (e.flags[0] & 8) and np.isfinite(obs).all(), (arr, adr)
         obs, rew, done = e.env_step(np.zeros(7, np.float32))
         assert done[0] == 1 and rew[0] == 0
+
+
+def test_action_taken_once_when_a_step_overflows_in_its_first_substep(names, model_arrays):
+    """A zero motion action puts the "hand" marker's sticks onto the EE's axis sticks (env_mujoco_util.py:644-646): ~46 contacts /
+    184 rows in the very first substep, so the light tier hands the env on before any substep has run -- and so do the medium
+    and heavy tiers.  Each tier used to run _take_action again for the resumed step (JT_SUB == 0): the gripper command moved by
+    a[6] / 10 once per tier (found by the closed-loop drift leg, tools/env_drift.py: finger angles 0.03 rad off the oracle)."""
+    e, oe = _pair(names, model_arrays, 3, 6)
+    nz = np.full((1, 12), 0.5, np.float32)
+    e.forward(nz)
+    a = np.array([0, 0, 0, 0, 0, 0, 1.0], np.float32)
+    for step in range(2):
+        obs, rew, done = e.env_step(a, nz)
+        oo, orew, odone, _ = oe.step(a.astype(np.float64), nz[0].astype(np.float64))
+        assert e.flags[0] & 32 and e.stats[0, 1] > 128                       # the scenario really left the light and the medium tier
+        assert abs(e.task[0, 0] - (0.7 + 0.1 * step)) < 1e-6 and abs(e.task[0, 16] - (0.6 + 0.1 * step)) < 1e-6   # gripper: one increment per step
+        assert abs(obs[0, 7] - oo[7]) < 1e-6 and np.abs(e.qpos[0, 6:9] - oe.o.get("qpos")[6:9]).max() < 1e-4
+        assert int(e.task[0, 18:19].view(np.uint32)[0]) == 12 * (step + 1) + 6   # draw counter: 6 (reset obs) + 12 per step

@@ -60,6 +60,35 @@ def test_policy_fixture_forward_matches_numpy(task):
     assert t["act_index"] == [0, 1, 2, 3, 4, 5, 6] and [x for x in P["tails"] if not x["is_weight"]][0]["act_index"] == [0, 1, 2, 3, 4, 5]
 
 
+def test_policy_unpickler_refuses_everything_but_the_table_constructors():
+    """The `primitives` blob of a policy.zip is a pickle, i.e. untrusted input: only the exact constructors the reference's own zips
+    use may be resolved (a module-prefix allowlist let builtins.eval and every numpy.* callable through)."""
+    import io, pickle
+    from mujoco_jaco_amd import policy
+
+    class Evil:
+        def __reduce__(self):
+            return (eval, ("1 + 1",))
+
+    class NumpyCallable:
+        def __reduce__(self):
+            import numpy.testing
+            return (numpy.testing.assert_equal, (1, 1))
+
+    class Importer:
+        def __reduce__(self):
+            return (__import__, ("os",))
+
+    for obj in (Evil(), NumpyCallable(), Importer(), getattr):
+        with pytest.raises(pickle.UnpicklingError):
+            policy._Unpickler(io.BytesIO(pickle.dumps(obj))).load()
+    # what the table really holds still loads: arrays, dtypes, containers
+    import collections
+    ok = {"obs": ("x", np.arange(6)), "act_scale": np.float64(0.5), "od": collections.OrderedDict(a=1)}
+    back = policy._Unpickler(io.BytesIO(pickle.dumps(ok))).load()
+    assert back["obs"][1].tolist() == list(range(6)) and float(back["act_scale"]) == 0.5 and back["od"]["a"] == 1
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("task,band", [("picking", (0.70, 1.0)), ("placing", (0.67, 1.0))])
 def test_shipped_policy_success_rate_on_hip_env(task, band):

@@ -9,7 +9,10 @@ Controls, all run by the SAME fp64 code on the SAME envs / ctrl as tools/gpu_dri
   D  fp64 oracle handed the pedestal height as the fp32 number 0.09f instead of 0.09 (3.6e-9 higher): the pedestal's bottom
      face sits exactly on the floor plane by construction (0.09 + 0.07 - 0.16), so this decides whether its 4 floor contacts
      exist in the very first step -- the knife edge every reset of the reference starts on
-B, C and D contain no fp32 arithmetic at all: every force, contact and solve is fp64.  Whatever divergence they show is the
+  E  fp64 oracle whose STATE stays fp64 while every forward pass (kinematics .. qacc) is evaluated at the fp32 rounding of it: the
+     ceiling for an fp32 engine that carries qpos / qvel compensated (hi + lo floats) -- rounding perturbs each evaluation but
+     never accumulates in the state (VERDICT r02 "next" item 1a)
+B, C, D and E contain no fp32 arithmetic at all: every force, contact and solve is fp64.  Whatever divergence they show is the
 floor for any engine that carries fp32 state (B) or is handed inputs that differ in the last fp32 bit (C).
 Writes per-env errors at 100 / 300 / 1000 steps + the oracle's max contact / row counts to an .npz for the attribution.
 """
@@ -34,6 +37,10 @@ def run(model, B, contact, scale, variant, seed=41):
         o.option("disable_contact", 1)
     if variant == "B":
         o.option("round_state", 1)
+    if variant == "E":
+        o.option("round_state", 2)
+    if variant == "F":
+        o.option("round_state", 3)
     if variant == "C":
         q[:, :6] = np.nextafter(q[:, :6].astype(np.float32), np.float32(np.inf)).astype(np.float64)
     if variant == "D" and q.shape[1] >= 23:
@@ -65,8 +72,10 @@ if __name__ == "__main__":
         ref, smax = run(model, B, contact, 0.2, "A")
         save[model + "_maxcon"] = smax[:, 0]; save[model + "_maxefc"] = smax[:, 1]
         for variant, what in (("B", "fp64 oracle, fp32-rounded state"), ("C", "fp64 oracle, +1 ulp(fp32) initial arm angles"),
-                              ("D", "fp64 oracle, pedestal height 0.09f instead of 0.09")):
-            if variant == "D" and not contact:
+                              ("D", "fp64 oracle, pedestal height 0.09f instead of 0.09"),
+                              ("E", "fp64 state, forward pass sees its fp32 rounding"),
+                              ("F", "as E, pedestal height seen exactly (no knife edge)")):
+            if variant in "DF" and not contact:
                 continue
             got, _ = run(model, B, contact, 0.2, variant)
             err = {k: np.abs(got[k] - ref[k]).max(1) for k in MARKS}
