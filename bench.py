@@ -35,7 +35,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2   # wave-instructions/s: 1 024 SIMD-32 units, one wave64 VALU instruction per 2 cycles, 2.4 GHz
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc.json")
 
 
 def parse_args(argv=None):
@@ -57,6 +57,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--hints", type=int, default=None, help="tier hint mode of the env handle (diagnostic; default = the library's)")
     ap.add_argument("--drift-gpu-leg", default=None, help=argparse.SUPPRESS)   # internal: child process that steps the HIP path on the drift workload
+    ap.add_argument("--env-drift-gpu-leg", default=None, help=argparse.SUPPRESS)   # internal: child process, HIP leg of the env-level closed-loop drift
+    ap.add_argument("--no-reset", action="store_true", help="finished envs stay frozen (BASELINE config 4: termination masking, no auto-reset)")
+    ap.add_argument("--no-contact", action="store_true", help="contacts disabled (BASELINE config 2: arm-only model)")
+    ap.add_argument("--config-legs", default="2,4", help="BASELINE configs also timed (briefly, each in a child process before the headline run); '' = none")
     ap.add_argument("--dry-gather", action="store_true",
                     help="CPU rehearsal of the N > 1 plumbing (spawn, rendezvous, gather, max-over-ranks timing) on gloo: no GPU, no physics")
     return ap.parse_args(argv)
@@ -64,17 +68,43 @@ def parse_args(argv=None):
 
 def self_launch(args):
     """--gpus N > 1 outside a launcher: N child ranks, started before this process has made any GPU call."""
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    # (bind-close-reuse leaves a window in which another process may take the port: the ranks then fail their rendezvous, the
+    # poll below reports it and the caller can re-run; SO_REUSEADDR keeps the port usable right after the close)
+    s = socket.socket(); s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     procs = []
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
+    # poll all ranks: the first one that fails takes the others down (a rank that died before or inside the RCCL rendezvous would
+    # otherwise leave rank 0 -- and this launcher -- waiting for ever); overall time limit as a last resort
+    import threading
+    out = []
+    reader = threading.Thread(target=lambda: out.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.time() + float(os.environ.get("JACO_BENCH_LAUNCH_TIMEOUT", "3000"))
+    failed = None
+    while any(p.poll() is None for p in procs):
+        bad = [r for r, p in enumerate(procs) if p.poll() not in (None, 0)]
+        if bad or time.time() > deadline:
+            failed = ("rank %d exited with %d" % (bad[0], procs[bad[0]].returncode)) if bad else "time limit"
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            break
+        time.sleep(0.2)
+    reader.join(timeout=10)
+    sys.stdout.write((out[0] if out else b"").decode())
     sys.stdout.flush()
-    return max(abs(rc) for rc in rcs)
+    if failed:
+        print("bench.py: multi-rank launch failed: %s" % failed, file=sys.stderr)
+        return 1
+    return max(abs(p.returncode) for p in procs)
 
 
 def small_action_runs(args):
@@ -113,6 +143,30 @@ def policy_run(args):
     except Exception as e:
         print("bench.py: policy run failed: %r" % (e,), file=sys.stderr)
         return None
+
+
+def config_legs(args):
+    """BASELINE.json configs 2 and 4 (child processes, as above):
+    config 2: 4 096 envs, arm-only model (gripper frozen, no free bodies, contacts disabled), random motor torques, ctrl level, one
+              launch = `frame_skip` (50) substeps;
+    config 4: 65 536 envs, full model, env-level step with frame_skip 4 and termination masking (finished envs stay frozen, no reset)."""
+    out = {}
+    common = ["--gpus", "1", "--no-cpu-baseline", "--extra-scales", "", "--policy-leg", "", "--config-legs", ""]
+    legs = {"2": ["--level", "ctrl", "--model", "jaco2_reaching_torque", "--batch", "4096", "--frame-skip", "50", "--no-contact", "--steps", "200", "--warmup", "20"],
+            "4": ["--level", "env", "--model", args.model, "--task", args.task, "--batch", str(args.batch), "--frame-skip", "4", "--no-reset", "--steps", "60", "--warmup", "10", "--preroll", "60"]}
+    for c in [x for x in args.config_legs.split(",") if x]:
+        if c not in legs:
+            continue
+        try:
+            p = subprocess.run([sys.executable, os.path.abspath(__file__)] + legs[c] + common, capture_output=True, text=True, timeout=600)
+            line = json.loads(p.stdout.strip().splitlines()[-1])
+            out["config%s" % c] = {"env_steps_per_s": line["value"], "ms_per_step": line["ms_per_step"], "kernel_ms": line["roofline"]["kernel_ms"],
+                                   "frame_skip": line["config"]["frame_skip"], "envs": line["config"]["envs_per_gpu"], "substeps_per_s": line["config"]["substeps_per_s"],
+                                   "launches_per_step": line["config"].get("launches_per_step"), "done_fraction": line["config"]["done_fraction"]}
+        except Exception as e:
+            out["config%s" % c] = None
+            print("bench.py: config %s leg failed: %r" % (c, e), file=sys.stderr)
+    return out
 
 
 DRIFT_MARKS = (100, 300, 1000)
@@ -181,19 +235,48 @@ def cpu_baseline_and_drift(model, frame_skip, gpu_npz):
         e = np.abs(got[mk] - ref[mk]).max(1)
         drift["after_%d_substeps" % mk] = {"median": float(np.median(e)), "p90": float(np.percentile(e, 90)), "max": float(e.max()),
                                             "frac_le_1e-4": float(np.mean(e <= 1e-4))}
-    # control: the same fp64 code carrying fp32-rounded state (no fp32 arithmetic anywhere) against itself -- the floor for any
-    # engine that keeps its state in fp32
-    oc = Oracle(model); oc.option("round_state", 1)
-    q, v, w = np.ascontiguousarray(q0.copy()), np.zeros((nenv, o.nv)), np.zeros((nenv, o.nv))
-    done, ctl = 0, {}
-    for mk in marks:
-        oc.step_batch(q, v, w, c, nsub=mk - done, nthreads=cores)
-        done = mk
-        e = np.abs(q - ref[mk]).max(1)
-        ctl["after_%d_substeps" % mk] = {"median": float(np.median(e)), "frac_le_1e-4": float(np.mean(e <= 1e-4))}
-    drift["control_fp64_oracle_with_fp32_rounded_state"] = ctl
-    drift["note"] = "contact dynamics amplify last-bit differences: the fp64 oracle carrying fp32-rounded state parts from itself the same way (control above; per-env attribution in profiles/r02_drift_attribution.txt)"
+    # controls: the same fp64 code (no fp32 arithmetic anywhere) against itself, (1) carrying fp32-rounded state -- what an engine
+    # with a plain fp32 state is bound by (rounds 1-2) -- and (3) keeping its state in fp64 but evaluating every forward pass at the
+    # fp32 rounding of it -- the ceiling of an fp32 engine that carries its state compensated, as this one does
+    for mode, key in ((1, "control_fp64_oracle_with_fp32_rounded_state"), (3, "control_fp64_state_fp32_rounded_evaluation")):
+        oc = Oracle(model); oc.option("round_state", mode)
+        q, v, w = np.ascontiguousarray(q0.copy()), np.zeros((nenv, o.nv)), np.zeros((nenv, o.nv))
+        done, ctl = 0, {}
+        for mk in marks:
+            oc.step_batch(q, v, w, c, nsub=mk - done, nthreads=cores)
+            done = mk
+            e = np.abs(q - ref[mk]).max(1)
+            ctl["after_%d_substeps" % mk] = {"median": float(np.median(e)), "frac_le_1e-4": float(np.mean(e <= 1e-4))}
+        drift[key] = ctl
+    drift["note"] = "qpos / qvel are carried as compensated float pairs (hi + lo): rounding perturbs each evaluation but does not accumulate in the state; what remains is the contact dynamics amplifying last-bit differences -- the fp64 oracle evaluated at fp32-rounded state parts from itself the same way (second control; the first is the bound of a plain fp32 state)"
     return base, drift
+
+
+ENV_DRIFT_ENVS, ENV_DRIFT_STEPS = 256, 20   # 20 env steps x 50 substeps = 1 000 substeps
+
+
+def env_level_drift(args):
+    """Closed-loop drift (tools/env_drift.py): JacoBatchedEnv (child process, HIP) against the fp64 oracle env (process pool on the
+    host cores, forked here BEFORE this process touches the GPU) on the same actions and injected noise; the reference's loop is
+    env_mujoco_util.py:73-90 (the controller runs every substep)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import numpy as np
+        import env_drift
+        path = os.path.join(ROOT, "gpurun_out", "bench_env_drift_gpu_%d.npz" % os.getpid())
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        subprocess.run([sys.executable, os.path.abspath(__file__), "--env-drift-gpu-leg", path], timeout=600, check=True, stdout=subprocess.DEVNULL)
+        t = time.time()
+        ref = env_drift.oracle_leg(ENV_DRIFT_ENVS, ENV_DRIFT_STEPS)
+        res = env_drift.summarize(dict(np.load(path)), ref)
+        os.remove(path)
+        res["metric"] = "max-abs qpos error of the HIP env vs the fp64 oracle env, same actions + injected noise, env level (OSC every substep), frame_skip 50"
+        res["oracle"] = "port (parity unpinned: no MuJoCo)"
+        res["oracle_seconds"] = time.time() - t
+        return res
+    except Exception as e:
+        print("bench.py: env-level drift leg failed: %r" % (e,), file=sys.stderr)
+        return None
 
 
 def dry_rank(args, world, rank):
@@ -236,9 +319,18 @@ def main():
         sys.exit(dry_rank(args, world, rank))
     if args.drift_gpu_leg:
         sys.exit(drift_gpu_leg(args))
+    if args.env_drift_gpu_leg:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import env_drift
+        env_drift.gpu_leg(args.env_drift_gpu_leg, ENV_DRIFT_ENVS, ENV_DRIFT_STEPS)
+        sys.exit(0)
     small = small_action_runs(args) if (args.level == "env" and world == 1 and args.extra_scales) else {}
     pol_leg = policy_run(args) if (args.level == "env" and world == 1) else None
+    cfg_legs = config_legs(args) if (world == 1 and args.config_legs) else {}
     drift_npz = None
+    env_drift_res = None
+    if world == 1 and not args.no_cpu_baseline and args.level == "env":
+        env_drift_res = env_level_drift(args)
     if world == 1 and not args.no_cpu_baseline:   # the HIP leg of the drift metric, in a child process before this one touches the GPU
         drift_npz = os.path.join(ROOT, "gpurun_out", "bench_drift_gpu_%d.npz" % os.getpid())
         os.makedirs(os.path.dirname(drift_npz), exist_ok=True)
@@ -297,15 +389,18 @@ def main():
                 a = (torch.rand(B, nact, device=dev, generator=gen) * 2 - 1) * scale[0]
             o, r, d, _ = genv.step(a)
             done_count.add_(d.sum())
-            o = genv.reset(d)      # masked jaco_reset of the finished envs: no host sync; their obs rows become the new episode's first
+            if not args.no_reset:
+                o = genv.reset(d)  # masked jaco_reset of the finished envs: no host sync; their obs rows become the new episode's first
             cur_obs[0] = o
-            if world > 1:          # one collective per rollout step: concatenate the observation rows of all shards
-                gather(o)
+            if world > 1:          # one collective per rollout step: concatenate the observation rows of all shards (issued on a
+                gather.start(o)    # side stream: it overlaps the next step's launch set; the timed region ends on a full device sync)
     else:
         env = BatchedMujoco(B, robot_file=args.model, device=local_rank, frame_skip=fs, seed=rank)
         q = torch.tensor(workload.reset_states(M["qpos0"], B, seed=1000 + rank), dtype=torch.float32, device=dev)
         ctrl = torch.tensor(workload.random_ctrl(B, seed=2000 + rank, scale=0.2)[:, :env.nu].copy(), dtype=torch.float32, device=dev)
         env.set_state(q, None, None)
+        if args.no_contact:
+            env.set_option("disable_contact", 1)
         gathered = torch.empty(world * B, env.nq, device=dev) if world > 1 else None
 
         def step():
@@ -334,13 +429,15 @@ def main():
     for _ in range((args.preroll if args.level == "env" else 0) + args.warmup):
         step()
     done_count.zero_()
+    env.launch_count()   # (reset the kernel-launch counter)
     env.enable_timing(True)
     dt = timed(args.steps)
     step_ms = env.step_time_ms()
     kern_ms, launches = env.kernel_time_ms()
     env.enable_timing(False)
     done_fraction = float(done_count.item()) / (B * args.steps)
-    flags = int(env.flags().max().item())
+    launches_per_step = env.launch_count() / float(args.steps)
+    flags = int(np.bitwise_or.reduce(env.flags().cpu().numpy().astype(np.uint32)))   # OR over the batch (a max would let a big informational bit hide a small error bit)
     stats = env.stats().float().mean(0).cpu().numpy()
     heavy = float(((env.flags() & 32) != 0).float().mean().item())
 
@@ -350,21 +447,25 @@ def main():
         # in addition: warm start in/out, sensordata, the task row and the controller-cache row in and out.
         if args.level == "env":
             a_survey = 4 * (2 * env.nq + 2 * env.nv + 7 + 26 + 1) + 1
-            a_impl = 4 * (2 * env.nq + 4 * env.nv + env.nsensor + 7 + 26 + 1 + 2 * 32 + 2 * 104) + 1
+            a_impl = 4 * (4 * env.nq + 6 * env.nv + env.nsensor + 7 + 26 + 1 + 2 * env.L.jaco_task_row_floats() + 2 * 104) + 1   # (state as hi + lo pairs)
         else:
             a_survey = 4 * (2 * env.nq + 2 * env.nv + env.nu)
-            a_impl = 4 * (2 * env.nq + 4 * env.nv + env.nu + env.nsensor)
+            a_impl = 4 * (4 * env.nq + 6 * env.nv + env.nu + env.nsensor)
         achieved = a_survey * B / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
-        traffic = valu = wait = None
-        try:  # counters of the same command from the committed rocprofv3 PMC passes (tools/profile_pmc.sh)
-            pm = json.load(open(PMC_FILE)).get("%s_B%d_fs%d" % (args.level, B, fs), {})
+        # PMC counters cannot be collected inside this run (rocprofv3 --pmc passes are separate runs of the same command,
+        # tools/profile_pmc.sh): what is reported is a REPLAY of the committed pass, named as such, with the commit and the kernel
+        # time it was captured at -- `traffic` is that pass's fabric bytes per launch
+        traffic, replay = None, None
+        try:
+            pmc_all = json.load(open(PMC_FILE))
+            pm = pmc_all.get("%s_B%d_fs%d" % (args.level, B, fs), {})
             traffic = pm.get("hbm_bytes_per_launch")
-            if pm.get("SQ_INSTS_VALU") and pm.get("kernel_ms"):
-                valu = pm["SQ_INSTS_VALU"] / (pm["kernel_ms"] * 1e-3) / VALU_ISSUE_PEAK
-            if pm.get("SQ_WAIT_ANY") and pm.get("SQ_WAVE_CYCLES"):
-                wait = pm["SQ_WAIT_ANY"] / pm["SQ_WAVE_CYCLES"]
+            replay = {"file": os.path.relpath(PMC_FILE, ROOT), "commit": pmc_all.get("commit"), "kernel_ms": pm.get("kernel_ms"), "hbm_bytes_per_launch": traffic,
+                      "valu_issue_frac": (pm["SQ_INSTS_VALU"] / (pm["kernel_ms"] * 1e-3) / VALU_ISSUE_PEAK) if pm.get("SQ_INSTS_VALU") and pm.get("kernel_ms") else None,
+                      "wait_frac": (pm["SQ_WAIT_ANY"] / pm["SQ_WAVE_CYCLES"]) if pm.get("SQ_WAIT_ANY") and pm.get("SQ_WAVE_CYCLES") else None}
         except Exception:
             pass
+        cfgname = "config2" if (args.no_contact and args.level == "ctrl") else ("config4" if (args.no_reset and fs == 4) else "config3")
         if args.level != "env":
             workload_desc = "random motor ctrl, ctrl-level jaco_physics_step"
         else:
@@ -376,22 +477,29 @@ def main():
             "value": world * B * args.steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "config3: %d envs/GPU, %s, %s reset distribution, %s" % (B, args.model, args.task, workload_desc),
+            "config": {"workload": "%s: %d envs/GPU, %s, %s reset distribution, %s" % (cfgname, B, args.model, args.task, workload_desc),
                        "level": args.level, "action_scale": args.action_scale, "preroll_steps": args.preroll if args.level == "env" else 0,
                        "envs_per_gpu": B, "frame_skip": fs, "substeps_per_s": world * B * args.steps * fs / dt,
                        "done_fraction": done_fraction,
                        "small_action_env_steps_per_s": small, "policy_driven": pol_leg,
                        "sharding": "independent env shards per rank" + ("; one all_gather of [B,%d] f32 rows per step" % (26 if args.level == "env" else env.nq) if world > 1 else ""),
-                       "mean_contacts": float(stats[0]), "mean_rows": float(stats[1]), "mean_newton_iters": float(stats[2]), "flags_or": flags & 0xff,
+                       "collective": ({"backend": dist.get_backend(), "world_size": dist.get_world_size(), "rank0_device": torch.cuda.get_device_name(local_rank),
+                                       "devices_visible": torch.cuda.device_count(), "overlapped_on_side_stream": args.level == "env"} if world > 1 else None),
+                       "mean_contacts": float(stats[0]), "mean_rows": float(stats[1]), "mean_newton_iters": float(stats[2]),
+                       "error_flags_or": flags & 31, "info_flags_or": flags & ~31, "launches_per_step": launches_per_step,
+                       "config2_env_steps_per_s": (cfg_legs.get("config2") or {}).get("env_steps_per_s"), "config4_env_steps_per_s": (cfg_legs.get("config4") or {}).get("env_steps_per_s"),
+                       "config_legs": cfg_legs,
                        "heavy_tier_fraction": heavy},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "jaco_physics_kernel", "kernel_ms": kern_ms, "launches": launches, "step_launch_set_ms": step_ms,
                          "algorithmic_bytes_per_env_launch": a_survey, "implementation_bytes_per_env_launch": a_impl,
-                         "valu_issue_frac": valu, "wait_frac": wait,
-                         "note": "latency/occupancy-bound by design (SURVEY 8d): algorithmic traffic is ~0.5 KB per env per launch, so the HBM fraction is ~1e-4 whatever the kernel does; the meaningful ceilings are VALU issue (valu_issue_frac: wave-instructions issued / 1.23e12 per s) and exposed latency (wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES), both from the committed PMC pass of this command (profiles/)"},
+                         "pmc_replayed": replay,
+                         "note": "latency/occupancy-bound by design (SURVEY 8d): algorithmic traffic is ~0.5 KB per env per launch, so the HBM fraction is ~1e-4 whatever the kernel does; the meaningful ceilings are VALU issue (wave-instructions issued / 1.23e12 per s) and exposed latency (SQ_WAIT_ANY / SQ_WAVE_CYCLES): `pmc_replayed` holds them, and `traffic`, from the committed separate --pmc passes of this command (not measured in this run; see its commit / kernel_ms)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], out["drift"] = cpu_baseline_and_drift(args.model, fs, drift_npz)
+            if out["drift"] is not None:
+                out["drift"]["env_level_closed_loop"] = env_drift_res
             if drift_npz and os.path.exists(drift_npz):
                 os.remove(drift_npz)
         print(json.dumps(out))

@@ -71,7 +71,11 @@ int jaco_num_envs(const JacoHandle* h);
 
 /* sim.get_state()/set_state() + sim.data.qpos/qvel writes (mujoco.py:213-246,332-347).
  * Any pointer may be NULL to skip that field.  qacc_warmstart is part of the state because the
- * constraint solver is warm-started from it, as in MuJoCo. Device-to-device copies on `stream`. */
+ * constraint solver is warm-started from it, as in MuJoCo. Device-to-device copies on `stream`.
+ * Precision: the library carries qpos / qvel as compensated pairs of floats (hi + lo, ~48 significant bits: the integrators
+ * advance the pair, every other computation reads the fp32 value `hi`; option "compensated" = 0 turns that off).  get_state
+ * returns `hi`, the fp32 rounding of the state; set_state writes `hi` and clears `lo` (the state becomes exactly the floats
+ * handed in), so a get -> set round trip rounds the state to fp32 once. */
 int jaco_set_state(JacoHandle* h, const float* qpos_dev, const float* qvel_dev, const float* qacc_ws_dev, void* stream);
 int jaco_get_state(JacoHandle* h, float* qpos_dev, float* qvel_dev, float* qacc_ws_dev, void* stream);
 /* sim.reset() for every env: qpos0, zero velocities (env_mujoco_util.py:93). */
@@ -121,6 +125,9 @@ int jaco_forward(JacoHandle* h, float* obs_dev, void* stream);
  *   additional_reward); get_wb / the success flag are then in the task row (JT_WB, JT_SUCC).  Finished envs freeze as in jaco_step. */
 int jaco_take_action(JacoHandle* h, const float* action_dev, void* stream);
 int jaco_terminal_inspection(JacoHandle* h, uint8_t* done_dev, float* bonus_dev, void* stream);
+/* Lifetime: jaco_set_noise / jaco_set_subgoal only record the pointer in the handle; the buffer is read by every later jaco_step /
+ * jaco_take_action / jaco_forward / jaco_reset on whatever stream that call uses.  It must stay allocated and unchanged until
+ * those calls have completed on the device or the pointer has been replaced (NULL detaches it). */
 int jaco_set_noise(JacoHandle* h, const float* noise_dev);
 /* Observation branch rulebased_subgoal = False (env_mujoco_util.py:255-270; option "obs_mode" = 1): obs[17:23] is the reaching goal
  * drawn at reset, and _take_action moves the "subgoal_reach" marker to subgoal + previous target (:609) when the caller passes the
@@ -138,7 +145,9 @@ int jaco_set_markers(JacoHandle* h, const float* in_dev, void* stream);
 int jaco_set_frame_skip(JacoHandle* h, int frame_skip);
 
 /* Solver / collision options, MuJoCo <option> names: "iterations", "tolerance", "ls_iterations",
- * "disable_contact" (contact flag), "mpr_iterations", "mpr_tolerance".
+ * "disable_contact" (contact flag), "mpr_iterations", "mpr_tolerance", "mpr_output"; "compensated" (1 default, see jaco_set_state).
+ * Setting a model option (everything in this first group except "disable_contact") SYNCHRONISES the device before the model
+ * constants are re-uploaded: it is the one entry point besides the *_debug / *_time_ms hooks that does.
  * Execution options ("schedule", "concurrent_heavy", "heavy_workers", "handdown": bit-identical results; "hints" / "tier_return" pick which
  * capacity tier's code steps a substep, and the tiers group their row sums differently: results agree to fp32 rounding): "schedule" (1: launch expensive envs first), "concurrent_heavy" (1: medium / heavy / huge
  * tier workgroups resident next to the light grid), "heavy_workers" (maximum of the medium tier's; the resident number follows the
@@ -152,6 +161,9 @@ int jaco_set_option(JacoHandle* h, const char* name, double value);
  * the last substep (layout: JDBG_* in csrc/physics_kernel.h) to host memory; synchronises. */
 int jaco_physics_step_debug(JacoHandle* h, const float* ctrl_dev, int nsub, int env, float* dump_host, int dump_floats);
 int jaco_debug_dump_floats(void);
+/* Kernel launches issued for this handle since the previous call of this function (host-side counter, no device work):
+ * bench.py's launches_per_step. */
+long long jaco_launch_count(JacoHandle* h);
 /* Diagnostic: control words of the tier queues after the last launch (per tier: envs queued, slots claimed by resident workers,
  * workers started / kept in reserve, envs queued before the launch from last step's hints); returns the number of words. */
 int jaco_debug_queue_words(JacoHandle* h, int32_t* out_host, int n);

@@ -50,6 +50,7 @@ SYMBOLS = {
     "jaco_set_frame_skip": (_ci, [_vp, _ci]),
     "jaco_physics_step_debug": (_ci, [_vp, _vp, _ci, _ci, ctypes.POINTER(ctypes.c_float), _ci]),
     "jaco_debug_dump_floats": (_ci, []),
+    "jaco_launch_count": (ctypes.c_longlong, [_vp]),
     "jaco_debug_queue_words": (_ci, [_vp, _ip, _ci]),
     "jaco_kernel_time_ms": (_ci, [_vp, ctypes.POINTER(_cd), _ip]),
     "jaco_enable_timing": (_ci, [_vp, _ci]),

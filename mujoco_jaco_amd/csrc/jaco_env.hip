@@ -64,9 +64,13 @@ struct JacoHandle {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;        // around a whole step launch set (routing .. drains)
   std::vector<std::pair<hipEvent_t, hipEvent_t>> kevents;       // around the light-tier kernel alone (what rocprofv3 reports for it)
   size_t events_used = 0;
+  long long nlaunch = 0;   // kernel launches since the last jaco_launch_count
 };
 
 static std::string g_create_error;
+
+// every kernel launch of the library goes through here: counted per handle (jaco_launch_count: bench.py's launches_per_step)
+#define JLAUNCH(h, ...) do { hipLaunchKernelGGL(__VA_ARGS__); (h)->nlaunch++; } while (0)
 
 #define HIPCHK(h, call)                                                                              \
   do {                                                                                               \
@@ -254,7 +258,7 @@ extern "C" int jaco_reset_state(JacoHandle* h, void* stream) {
   const JacoModelDev& m = h->model_host;
   size_t B = h->num_envs;
   size_t total = B * m.nq;
-  hipLaunchKernelGGL(jaco_fill_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, h->qpos, h->qpos0_dev, m.nq, (int)B);
+  JLAUNCH(h, jaco_fill_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, h->qpos, h->qpos0_dev, m.nq, (int)B);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipMemsetAsync(h->qvel, 0, B * m.nv * sizeof(float), st));
   HIPCHK(h, hipMemsetAsync(h->qacc_ws, 0, B * m.nv * sizeof(float), st));
@@ -263,7 +267,7 @@ extern "C" int jaco_reset_state(JacoHandle* h, void* stream) {
   HIPCHK(h, hipMemsetAsync(h->hint, 0, B * sizeof(int), st));
   // markers back to their XML rest pose (sim.reset() restores mocap_pos / mocap_quat)
   const float* rest = (const float*)((const char*)h->model_dev + offsetof(JacoModelDev, marker_rest));
-  hipLaunchKernelGGL(jaco_fill_rows_kernel, dim3((unsigned)((B * 24 + 255) / 256)), dim3(256), 0, st, h->marker, rest, 24, (int)B);
+  JLAUNCH(h, jaco_fill_rows_kernel, dim3((unsigned)((B * 24 + 255) / 256)), dim3(256), 0, st, h->marker, rest, 24, (int)B);
   HIPCHK(h, hipGetLastError());
   return JACO_OK;
 }
@@ -457,11 +461,11 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
   // frees and would otherwise starve behind the light grid, leaving serial tails of several ms per env step).  The drains that
   // follow in stream order serve whatever the workers did not (all of it when concurrency is off: full grids, which is also
   // what carries the load when most envs overflow).
-  hipLaunchKernelGGL(jaco_prepare_kernel, dim3((unsigned)((6 * h->num_envs + 255) / 256)), dim3(256), 0, st, h->qctl, h->qlist, h->num_envs, h->workers, h->workers_heavy, h->workers_huge, h->order_ctl, io.mode, (int)light_grid);
+  JLAUNCH(h, jaco_prepare_kernel, dim3((unsigned)((6 * h->num_envs + 255) / 256)), dim3(256), 0, st, h->qctl, h->qlist, h->num_envs, h->workers, h->workers_heavy, h->workers_huge, h->order_ctl, io.mode, (int)light_grid);
   HIPCHK(h, hipGetLastError());
   if (A.hint && io.mode <= 1) {   // queue the envs whose last step ended in a bigger tier, size the tiers' workers
-    hipLaunchKernelGGL(jaco_route_kernel, dim3((unsigned)((h->num_envs + 255) / 256)), dim3(256), 0, st, h->hint, h->routed_mark, A.launch_id, h->qlist, h->qctl, h->remaining, h->cost, h->num_envs, nsub);
-    hipLaunchKernelGGL(jaco_route_finish_kernel, dim3(1), dim3(1), 0, st, h->num_envs, h->qctl, h->workers, h->workers_heavy, h->workers_huge);
+    JLAUNCH(h, jaco_route_kernel, dim3((unsigned)((h->num_envs + 255) / 256)), dim3(256), 0, st, h->hint, h->routed_mark, A.launch_id, h->qlist, h->qctl, h->remaining, h->cost, h->num_envs, nsub);
+    JLAUNCH(h, jaco_route_finish_kernel, dim3(1), dim3(1), 0, st, h->num_envs, h->qctl, h->workers, h->workers_heavy, h->workers_huge);
     A.routed_mark = h->routed_mark;
   }
   // The resident workers go first: their workgroups need 20 - 68 KB of LDS on one CU, and once the light grid (13 KB per workgroup,
@@ -472,24 +476,24 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
   if (conc) {
     HIPCHK(h, hipEventRecord(h->ev_fork, st));
     for (int t = 2; t >= 0; t--) HIPCHK(h, hipStreamWaitEvent(h->side[t], h->ev_fork, 0));
-    hipLaunchKernelGGL(jaco_physics_kernel_huge_workers, dim3((unsigned)h->workers_huge), dim3(64), 0, h->side[2], A);
-    hipLaunchKernelGGL(jaco_physics_kernel_heavy_workers, dim3((unsigned)h->workers_heavy), dim3(64), 0, h->side[1], A);
-    hipLaunchKernelGGL(jaco_physics_kernel_medium, dim3((unsigned)h->workers), dim3(64), 0, h->side[0], A);
+    JLAUNCH(h, jaco_physics_kernel_huge_workers, dim3((unsigned)h->workers_huge), dim3(64), 0, h->side[2], A);
+    JLAUNCH(h, jaco_physics_kernel_heavy_workers, dim3((unsigned)h->workers_heavy), dim3(64), 0, h->side[1], A);
+    JLAUNCH(h, jaco_physics_kernel_medium, dim3((unsigned)h->workers), dim3(64), 0, h->side[0], A);
     HIPCHK(h, hipGetLastError());
     for (int t = 0; t < 3; t++) HIPCHK(h, hipEventRecord(h->ev_join[t], h->side[t]));
   }
   if (reorder) {
     const unsigned ob = (unsigned)((h->num_envs + 1023) / 1024);
-    hipLaunchKernelGGL(jaco_order_hist_kernel, dim3(ob), dim3(1024), 0, st, h->cost, h->order_ctl, h->num_envs, A.routed_mark, A.launch_id);
-    hipLaunchKernelGGL(jaco_order_scatter_kernel, dim3(ob), dim3(1024), 0, st, h->cost, h->order_ctl, h->order, h->num_envs, A.routed_mark, A.launch_id);
-    hipLaunchKernelGGL(jaco_order_finish_kernel, dim3(1), dim3(1), 0, st, h->order_ctl, h->num_envs);
+    JLAUNCH(h, jaco_order_hist_kernel, dim3(ob), dim3(1024), 0, st, h->cost, h->order_ctl, h->num_envs, A.routed_mark, A.launch_id);
+    JLAUNCH(h, jaco_order_scatter_kernel, dim3(ob), dim3(1024), 0, st, h->cost, h->order_ctl, h->order, h->num_envs, A.routed_mark, A.launch_id);
+    JLAUNCH(h, jaco_order_finish_kernel, dim3(1), dim3(1), 0, st, h->order_ctl, h->num_envs);
     HIPCHK(h, hipGetLastError());
     A.order = h->order;
   }
   if (conc) HIPCHK(h, hipEventRecord(h->ev_pre, st));
   if (kev) HIPCHK(h, hipEventRecord(kev->first, st));
-  if (A.nslots || io.mode >= 2) hipLaunchKernelGGL(jaco_physics_kernel_listed, dim3(light_grid), dim3(64), 0, st, A);   // (resets: forward passes, placing hold)
-  else hipLaunchKernelGGL(jaco_physics_kernel, dim3(light_grid), dim3(64), 0, st, A);
+  if (A.nslots || io.mode >= 2) JLAUNCH(h, jaco_physics_kernel_listed, dim3(light_grid), dim3(64), 0, st, A);   // (resets: forward passes, placing hold)
+  else JLAUNCH(h, jaco_physics_kernel, dim3(light_grid), dim3(64), 0, st, A);
   if (kev) HIPCHK(h, hipEventRecord(kev->second, st));
   HIPCHK(h, hipGetLastError());
   if (conc) for (int t = 0; t < 3; t++) HIPCHK(h, hipStreamWaitEvent(st, h->ev_join[t], 0));
@@ -498,18 +502,18 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
   unsigned mg = ne < 2048 ? ne : 2048, hg = ne < JACO_HEAVY_GRID ? ne : JACO_HEAVY_GRID, gg = ne < 512 ? ne : 512;
   if (io.mode == 2) { mg = mg < 64 ? mg : 64; hg = hg < 64 ? hg : 64; gg = gg < 256 ? gg : 256; }   // (reset-time forward passes: overflows of the light tier go straight to the last one)
   if (io.mode >= 4) { if (ev) HIPCHK(h, hipEventRecord(ev->second, st)); return JACO_OK; }   // take_action / terminal_inspection run no substep: nothing can overflow
-  if (io.mode != 2) hipLaunchKernelGGL(jaco_physics_kernel_medium_drain, dim3(mg), dim3(64), 0, st, A);   // (mode 2 queues for the last tier only)
+  if (io.mode != 2) JLAUNCH(h, jaco_physics_kernel_medium_drain, dim3(mg), dim3(64), 0, st, A);   // (mode 2 queues for the last tier only)
   if (h->handdown && io.mode == 1) {
     // the heavy tier holds 4 envs per CU: an env that needed it for a few substeps is passed back down to a second medium drain
     // (8 per CU) rather than kept there for the rest of its step; what overflows again is served by a second, final heavy drain
     A.handdown = 1;
-    hipLaunchKernelGGL(jaco_physics_kernel_heavy_drain, dim3(hg), dim3(64), 0, st, A);
+    JLAUNCH(h, jaco_physics_kernel_heavy_drain, dim3(hg), dim3(64), 0, st, A);
     A.handdown = 0;
-    hipLaunchKernelGGL(jaco_drain_round2_kernel, dim3(1), dim3(1), 0, st, h->qctl, (int)mg, (int)hg);
-    hipLaunchKernelGGL(jaco_physics_kernel_medium_drain, dim3(mg), dim3(64), 0, st, A);
+    JLAUNCH(h, jaco_drain_round2_kernel, dim3(1), dim3(1), 0, st, h->qctl, (int)mg, (int)hg);
+    JLAUNCH(h, jaco_physics_kernel_medium_drain, dim3(mg), dim3(64), 0, st, A);
   }
-  if (io.mode != 2) hipLaunchKernelGGL(jaco_physics_kernel_heavy_drain, dim3(hg), dim3(64), 0, st, A);
-  hipLaunchKernelGGL(jaco_physics_kernel_huge_drain, dim3(gg), dim3(64), 0, st, A);
+  if (io.mode != 2) JLAUNCH(h, jaco_physics_kernel_heavy_drain, dim3(hg), dim3(64), 0, st, A);
+  JLAUNCH(h, jaco_physics_kernel_huge_drain, dim3(gg), dim3(64), 0, st, A);
   HIPCHK(h, hipGetLastError());
   if (ev) HIPCHK(h, hipEventRecord(ev->second, st));
   return JACO_OK;
@@ -590,7 +594,7 @@ extern "C" int jaco_reset(JacoHandle* h, const uint8_t* mask_dev, float* obs_dev
   JacoResetArgs R{h->qpos0_dev, h->qpos, h->qvel, h->qacc_ws, h->qpos_lo, h->qvel_lo, h->task_rows, mask_dev, h->marker, rest, h->num_envs, m.nq, m.nv, h->task, m.nq >= 23, h->seed, {m.base_pos[0], m.base_pos[1], m.base_pos[2]}, h->order, h->order_ctl + 67};
   if (mask_dev) HIPCHK(h, hipMemsetAsync(h->order_ctl + 67, 0, sizeof(unsigned), st));
   h->reset_listed = mask_dev != nullptr;
-  hipLaunchKernelGGL(jaco_reset_kernel, dim3((unsigned)((h->num_envs + 255) / 256)), dim3(256), 0, st, R);
+  JLAUNCH(h, jaco_reset_kernel, dim3((unsigned)((h->num_envs + 255) / 256)), dim3(256), 0, st, R);
   HIPCHK(h, hipGetLastError());
   if (h->task == JACO_TASK_PLACING) {   // object into the hand, 150 held substeps while the fingers close (env_mujoco_util.py:106-117)
     int rc = jaco_placing_hold(h, mask_dev, JACO_PLACING_HOLD_SUBSTEPS, stream);
@@ -657,6 +661,12 @@ extern "C" int jaco_set_frame_skip(JacoHandle* h, int frame_skip) {
   return JACO_OK;
 }
 
+extern "C" long long jaco_launch_count(JacoHandle* h) {
+  if (!h) return JACO_EINVAL;
+  const long long n = h->nlaunch;
+  h->nlaunch = 0;
+  return n;
+}
 extern "C" int jaco_debug_dump_floats(void) { return JDBG_SIZE; }
 // Diagnostic: the tier queues' control words of the last launch (JQ_* layout above), copied to host; synchronises.
 extern "C" int jaco_debug_queue_words(JacoHandle* h, int32_t* out_host, int n) {

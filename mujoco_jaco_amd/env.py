@@ -219,6 +219,11 @@ class JacoBatchedEnv:
     def seed(self, seed):
         pass  # the reference's seed() is a no-op too (env_mujoco.py:163-164); pass `seed=` to the constructor instead
 
+    def set_capture_path(self, path):
+        """JacoMujocoEnvUtil.set_capture_path (env_mujoco_util.py:683): where the reference's renderer writes frames.  Rendering is out
+        of scope here (no viewer); the path is kept so callers that set it unconditionally keep working."""
+        self.capture_path = path
+
     def close(self):
         self.sim.close()
         return None

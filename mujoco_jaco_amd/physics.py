@@ -112,6 +112,10 @@ class BatchedMujoco:
     def set_option(self, name, value):
         self._chk(self.L.jaco_set_option(self.h, name.encode(), float(value)))
 
+    def launch_count(self):
+        """Kernel launches issued for this handle since the previous call (host-side counter)."""
+        return int(self.L.jaco_launch_count(self.h))
+
     def enable_timing(self, on=True):
         self._chk(self.L.jaco_enable_timing(self.h, int(on)))
 

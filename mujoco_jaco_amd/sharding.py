@@ -22,16 +22,49 @@ def env_seed(base_seed, rank):
 
 
 class ObsGather:
-    """Pre-allocated all_gather of equally sized observation shards."""
+    """Pre-allocated all_gather of equally sized observation shards.
+
+    `gather(local)` is the plain blocking form.  `start(local)` / `wait()` is the overlapped form for a rollout loop on a GPU: the
+    local rows are copied into a staging buffer on the caller's stream (the env step's own stream, so the copy is ordered behind
+    the kernels that wrote them and the rows may be overwritten by the next step right away), and the collective itself is issued
+    on a side stream -- RCCL's transfers over xGMI then run under the next step's launch set instead of in front of it.  `wait()`
+    makes the caller's stream wait for the last started gather and returns the concatenated rows [world * local_rows, width]."""
 
     def __init__(self, local_rows, width, device, dtype=torch.float32, group=None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.out = torch.empty(self.world * local_rows, width, device=device, dtype=dtype)
+        self.device = torch.device(device)
+        self._overlap = self.device.type == "cuda" and self.world > 1
+        if self._overlap:
+            self.stage = torch.empty(local_rows, width, device=device, dtype=dtype)
+            self.side = torch.cuda.Stream(device=device)
+            self._ready = torch.cuda.Event()
+            self._done = None
 
     def __call__(self, local_obs):
         if self.world == 1:
             self.out.copy_(local_obs)
         else:
             dist.all_gather_into_tensor(self.out, local_obs.contiguous(), group=self.group)
+        return self.out
+
+    def start(self, local_obs):
+        if not self._overlap:
+            self(local_obs)
+            return
+        cur = torch.cuda.current_stream(self.device)
+        if self._done is not None:
+            cur.wait_event(self._done)          # the previous gather has read the staging buffer (it finished a whole step ago)
+        self.stage.copy_(local_obs)
+        self._ready.record(cur)
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(self._ready)
+            dist.all_gather_into_tensor(self.out, self.stage, group=self.group)
+            self._done = torch.cuda.Event()
+            self._done.record(self.side)
+
+    def wait(self):
+        if self._overlap and self._done is not None:
+            torch.cuda.current_stream(self.device).wait_event(self._done)
         return self.out

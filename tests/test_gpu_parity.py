@@ -4,9 +4,10 @@ Tolerances (stated per BASELINE.json's "stated fp32 tolerance"; measured in prof
   * single step from identical state, MAX over every env whose contact set is the oracle's (same contact and row counts,
     no capacity flag):  |dqpos| <= 2e-6, |dqvel| <= 2e-3 (h = 1e-3; finger dofs accelerate at ~1e3 rad/s^2).
     The other envs (a contact switching on or off exactly at this step: <= 3 %) are counted, not bounded.
-  * free-running over N substeps: contact dynamics amplify last-bit differences, so the bar is the fp64 oracle carrying
-    fp32-rounded state ("control", no fp32 arithmetic at all): the HIP path must lose no more envs than the control does,
-    and stay <= 1e-4 (MAX) on every env the control keeps <= 1e-5 and that raised no capacity flag.
+  * free-running over N substeps: the state is carried compensated (hi + lo floats), so rounding perturbs each evaluation but
+    does not accumulate; what remains is the contact dynamics amplifying last-bit differences.  100 substeps: MAX over the whole
+    batch <= 4e-5 (measured 1.2e-5).  1 000 substeps: >= 75 % of the envs <= 1e-4 (measured 83.6 %), within 8 points of the
+    fp64 control that evaluates every forward pass at the fp32 rounding of its fp64 state (86.7 %).
   * integer-like outputs (contact count, row count, flags) exact on the single-step check.
 Full-size (65 536 env) checks use size-independent properties: bitwise determinism, independence of an env from
 its batch neighbours, nsub composition, unit quaternions, finite state.
@@ -107,41 +108,54 @@ def test_stage_dump_and_counts_match(model_arrays):
             assert dh[0] < 1e-5 and dh[1] < 1e-4 and dh[2] < 1e-3
 
 
-def _drift_vs_control(model_arrays, B, nsub, seed):
+def _drift_vs_control(model_arrays, B, nsub, seed, compensated=1, control=3):
+    """HIP path vs fp64 oracle, and the fp64 control: control = 1: fp64 arithmetic carrying fp32-rounded state (the floor of a plain
+    fp32-state engine), 3: fp64 state, every forward pass evaluated at its fp32 rounding (the ceiling of an engine that carries
+    its state compensated; the pedestal's exact height kept, tools/drift_control.py variant F)."""
     from mujoco_jaco_amd import workload
+    from oracle_binding import Oracle
+    import os
     q = workload.reset_states(model_arrays["qpos0"], B, seed=seed, f32_draws=True)
     c = workload.random_ctrl(B, seed=seed + 1, scale=0.2).astype(np.float32).astype(np.float64)
     env = _env(B)
+    env.set_option("compensated", compensated)
     env.set_state(_t(q, env.device), None, None)
     env.send_forces(_t(c, env.device), nsub=nsub)
     gq = env.get_state()[0].cpu().numpy().astype(np.float64)
     z = np.zeros((B, 21))
     qo, _, _, _ = _oracle_batch_stats("jaco2_curtain_torque", q, z, z, c, nsub)
-    qc, _, _, _ = _oracle_batch_stats("jaco2_curtain_torque", q, z, z, c, nsub, round_state=True)   # control: fp64 arithmetic, fp32 state
+    oc = Oracle("jaco2_curtain_torque"); oc.option("round_state", control)
+    qc = q.copy(); vc = z.copy(); wc = z.copy()
+    oc.step_batch(qc, vc, wc, np.ascontiguousarray(c), nsub=nsub, nthreads=os.cpu_count())
     err, ctl = np.abs(gq - qo).max(1), np.abs(qc - qo).max(1)
     fl = env.flags().cpu().numpy()
-    print("drift after %d substeps: HIP median %.2e p90 %.2e max %.2e (<= 1e-4: %.1f %%) | fp64 control with fp32 state: median %.2e p90 %.2e max %.2e (<= 1e-4: %.1f %%)" % (
-        nsub, np.median(err), np.percentile(err, 90), err.max(), 100 * np.mean(err <= 1e-4), np.median(ctl), np.percentile(ctl, 90), ctl.max(), 100 * np.mean(ctl <= 1e-4)))
+    print("drift after %d substeps (compensated %d): HIP median %.2e p90 %.2e max %.2e (<= 1e-4: %.1f %%) | fp64 control %d: median %.2e p90 %.2e max %.2e (<= 1e-4: %.1f %%)" % (
+        nsub, compensated, np.median(err), np.percentile(err, 90), err.max(), 100 * np.mean(err <= 1e-4), control, np.median(ctl), np.percentile(ctl, 90), ctl.max(), 100 * np.mean(ctl <= 1e-4)))
     return err, ctl, fl
 
 
 def test_free_running_drift_100_substeps(model_arrays):
+    """Measured (MI355X, round 3, compensated state): median 1.0e-7, p99 3.7e-6, max 1.2e-5 over all 256 envs."""
     err, ctl, fl = _drift_vs_control(model_arrays, 256, 100, 41)
-    calm = (ctl <= 1e-5) & ((fl & 7) == 0)       # envs the control itself keeps together, no dropped rows / contacts
-    assert calm.mean() >= 0.95
-    assert err[calm].max() <= 1e-4, err[calm].max()                          # MAX over the attributed-clean set
-    assert np.median(err) <= 2 * np.median(ctl) + 1e-7
-    assert np.mean(err <= 1e-4) >= np.mean(ctl <= 1e-4) - 0.02
+    assert (fl & 15).max() == 0
+    assert err.max() <= 4e-5, err.max()                                       # MAX over the whole batch (3x the measured value)
+    assert np.median(err) <= 3e-7 and np.percentile(err, 99) <= 1.2e-5
 
 
-def test_free_running_drift_1000_substeps_matches_fp64_control(model_arrays):
-    """The headline drift metric: after 1 000 substeps most contact-rich envs have parted from the oracle by more than
-    1e-4 -- and so has the fp64 oracle from itself when its state is rounded to fp32 every step.  The HIP path must not
-    lose more envs than that control (within sampling noise), nor be further out in the bulk."""
+def test_free_running_drift_1000_substeps(model_arrays):
+    """The headline drift metric (BASELINE.json: <= 1e-4 over 1 000 steps), ctrl level, constant random torques, 256 envs of the
+    picking reset distribution.  Measured: 83.6 % of the envs <= 1e-4 (median 1.0e-5); the fp64 control that evaluates every
+    forward pass at the fp32 rounding of its (fp64) state keeps 86.7 %; a plain fp32 state (rounds 1-2) kept 33-35 %, its
+    fp64 control 38 %.  The envs that part are the ones in which unactuated impacts amplify last-bit differences (the fp64 oracle
+    started 1 ulp(fp32) away parts from itself in 15.6 % of them)."""
     err, ctl, fl = _drift_vs_control(model_arrays, 256, 1000, 41)
-    assert np.mean(err <= 1e-4) >= np.mean(ctl <= 1e-4) - 0.06
-    assert np.median(err) <= 3 * np.median(ctl)
-    assert np.percentile(err, 25) <= 1e-4
+    assert np.mean(err <= 1e-4) >= 0.75, np.mean(err <= 1e-4)
+    assert np.mean(err <= 1e-4) >= np.mean(ctl <= 1e-4) - 0.08                 # no further from the oracle than the compensated-state ceiling
+    assert np.median(err) <= 3e-5 and np.percentile(err, 25) <= 3e-6
+    # ... and the compensated state is what buys it: the same kernel carrying a plain fp32 state loses most envs, like its control
+    err0, ctl0, _ = _drift_vs_control(model_arrays, 256, 1000, 41, compensated=0, control=1)
+    assert np.mean(err0 <= 1e-4) <= np.mean(err <= 1e-4) - 0.3
+    assert np.mean(err0 <= 1e-4) >= np.mean(ctl0 <= 1e-4) - 0.08
 
 
 def test_arm_only_config2_4096_envs():
@@ -164,6 +178,7 @@ def test_arm_only_config2_4096_envs():
     qo = q[sub].astype(np.float32).astype(np.float64); vo = np.zeros((256, 9)); wo = np.zeros((256, 9))
     o.step_batch(qo, vo, wo, np.ascontiguousarray(c[sub].astype(np.float32).astype(np.float64)), nsub=nsub, nthreads=16)
     err = np.abs(gq[sub] - qo).max(1)
+    print("arm-only, 100 substeps, full-scale torques: qpos err median %.2e p99 %.2e max %.2e" % (np.median(err), np.percentile(err, 99), err.max()))
     assert np.percentile(err, 99) <= 1e-4 and np.median(err) <= 2e-5, (np.median(err), err.max())
 
 

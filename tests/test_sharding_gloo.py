@@ -32,7 +32,10 @@ def _worker(rank, world, port, out):
         # each rank "steps" its own shard: rows are a pure function of (global env id, step)
         ids = torch.arange(lo, hi, dtype=torch.float32)[:, None]
         local = ids * 100 + step + torch.arange(width, dtype=torch.float32)[None, :] * 0.01
-        full = g(local)
+        if step == 1:                       # the overlapped form (side stream on a GPU; plain call on CPU): same result
+            g.start(local); full = g.wait()
+        else:
+            full = g(local)
         ref = torch.arange(total, dtype=torch.float32)[:, None] * 100 + step + torch.arange(width, dtype=torch.float32)[None, :] * 0.01
         assert torch.equal(full, ref), (rank, step)
     # max-over-ranks timing reduction used by bench.py

@@ -118,6 +118,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "gpu":
         gpu_leg(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]) if len(sys.argv) > 5 else 1)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "oracle":   # the oracle leg alone -> .npz (a fresh process: its pool forks before any GPU use)
+        np.savez(sys.argv[2], **oracle_leg(int(sys.argv[3]), int(sys.argv[4])))
+        sys.exit(0)
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     nstep = int(sys.argv[2]) if len(sys.argv) > 2 else 20
     ref = oracle_leg(B, nstep)
