@@ -40,11 +40,14 @@ extern "C" {
 #define JACO_FLAG_TIER_RETURN 128u   /* informational: the heavy tier gave the env back to the light code in mid-step (overflow was transient) */
 #define JACO_FLAG_BAIL_CAUSE_SHIFT 8  /* informational, bits 8..16: which capacity (bit 0 contacts, 1 rows, 2 candidates) made tier 0 / 1 / 2 (3 bits each) hand the env on */
 #define JACO_FLAG_OSC_SINGULAR 64u   /* informational: |det(J M^-1 J^T)| < 1e-3, the controller used its pseudo-inverse branch */
+#define JACO_FLAG_PREREACH_CAP 0x20000u /* the grasping reset's pre-reach loops (unbounded in the reference) stopped at the substep cap */
 
 /* task ids (env_script/env_mujoco.py:18-23; only picking/placing return the 4-tuple step() unpacks) */
 #define JACO_TASK_PICKING 0
 #define JACO_TASK_PLACING 1
 #define JACO_TASK_REACHING 2
+#define JACO_TASK_GRASPING 3       /* reward env_mujoco_util.py:352-391, termination :521-536 (+ the success flag its 3-tuple lacks), reset pre-reach :123-170 */
+#define JACO_TASK_PICKANDPLACE 4   /* reward 0, termination :585-600 with the `picked` flag, 1200-step episodes */
 
 typedef struct JacoHandle JacoHandle;
 
@@ -115,6 +118,12 @@ int jaco_get_stats(JacoHandle* h, int32_t* out_dev, void* stream);
  *   counters, goals and the success flag (get_wb / accum_succ bookkeeping stay on the host side). */
 int jaco_reset(JacoHandle* h, const uint8_t* mask_dev, float* obs_dev, void* stream);
 int jaco_placing_hold(JacoHandle* h, const uint8_t* mask_dev, int nsub, void* stream);
+/* The pre-reach part of the grasping reset (env_mujoco_util.py:123-170), run by jaco_reset for task grasping after the draws: EE target =
+ * [object goal, orientation looking along EE -> object (float16 angles, yaw drawn)]; loop 1 { stop_obj, controller + sim.step } until the
+ * EE is within 0.2 m of the object goal or its orientation within pi/6 of the sampled reaching goal's; loop 2 { controller + sim.step }
+ * until within 0.15 m; then _get_observation into the masked rows of obs_dev.  The reference's loops are unbounded: max_substeps caps
+ * them (jaco_reset uses 4000; an env that hits the cap gets JACO_FLAG_PREREACH_CAP). */
+int jaco_grasping_prereach(JacoHandle* h, const uint8_t* mask_dev, int max_substeps, float* obs_dev, void* stream);
 int jaco_step(JacoHandle* h, const float* action_dev, float* obs_dev, float* reward_dev, uint8_t* done_dev, void* stream);
 int jaco_forward(JacoHandle* h, float* obs_dev, void* stream);
 /* The two halves of jaco_step the reference also exposes as public methods of JacoMujocoEnv (env_mujoco.py:144-161):

@@ -36,6 +36,7 @@ SYMBOLS = {
     "jaco_set_option": (_ci, [_vp, _cp, _cd]),
     "jaco_reset": (_ci, [_vp, _vp, _vp, _vp]),
     "jaco_placing_hold": (_ci, [_vp, _vp, _ci, _vp]),
+    "jaco_grasping_prereach": (_ci, [_vp, _vp, _ci, _vp, _vp]),
     "jaco_step": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "jaco_forward": (_ci, [_vp, _vp, _vp]),
     "jaco_take_action": (_ci, [_vp, _vp, _vp]),

@@ -23,7 +23,9 @@
 #define JT_CTRL 20       // [9]
 #define JT_SUCC 29       // success flag of the last terminal step
 #define JT_WB 30         // last |EE - base| (get_wb)
+#define JT_PICKED 31     // task pickAndplace: self.picked (env_mujoco_util.py:587-590)
 #define JT_REACHGOAL 32  // [6] reaching goal: position + Euler rxyz (drawn at reset, env_mujoco_util.py:199-207)
+#define JT_PHASE 38      // task grasping, reset only: 0 pre-reach not started, 1 in its first loop (:138-159), 2 in its second (:160-170), 3 done
 #define JTASK_N 40
 static_assert(JTASK_N == JTASK_FLOATS, "task row size");
 // per-env cache row: what the controller reads one substep late
@@ -37,6 +39,14 @@ static_assert(JTASK_N == JTASK_FLOATS, "task row size");
 #define JCACHE_N 104
 
 #define JFLAG_OSC_SINGULAR 64u
+#define JFLAG_PREREACH_CAP 0x20000u   // the grasping reset's pre-reach loops (unbounded `while True` in the reference) hit the substep cap
+
+// task ids (include/jaco_env.h JACO_TASK_*)
+#define JTASK_PICKING 0
+#define JTASK_PLACING 1
+#define JTASK_REACHING 2
+#define JTASK_GRASPING 3
+#define JTASK_PICKANDPLACE 4
 
 #define JOSC_KP 50.f
 #define JOSC_KO 180.f
@@ -150,7 +160,8 @@ JDEV int touch_class(float sens, int lane) {
 }
 
 // ---------------------------------------------------------------- a10: picking reward (env_mujoco_util.py:392-431)
-JDEV float reward_picking(v3 ee, const float* eul, v3 obj, int touch) {
+// task 'grasping' (env_mujoco_util.py:352-391) has the same shape with touch terms 0.75 / -0.75 / 2.5 and scale 0.05 (picking: 0.01)
+JDEV float reward_picking(v3 ee, const float* eul, v3 obj, int touch, float scale = 0.01f) {
   float cr = cosf(eul[0]), sr = sinf(eul[0]), cp = cosf(eul[1]), sp = sinf(eul[1]);
   // Rx(r) Ry(p) Rz(y) applied to (0,0,-1): third column negated
   v3 ee_vec = mk3(-sp, sr * cp, -cr * cp);
@@ -168,7 +179,7 @@ JDEV float reward_picking(v3 ee, const float* eul, v3 obj, int touch) {
   float r = 2.5f * expf(-dn / 0.2f) + expf(-ang / 0.52359877559829887f) / (dn * 15.f + 1.f);
   r += touch == 1 ? 0.75f : (touch == 2 ? -0.75f : (touch == 3 ? 2.5f : 0.f));
   r += 100.f * (obj.z - 0.1898f);
-  return r * 0.01f;
+  return r * scale;
 }
 
 // ---------------------------------------------------------------- a10 / a11 for task 'reaching' (env_mujoco_util.py:314-351, 504-520)
@@ -194,10 +205,11 @@ JDEV float reward_reaching(v3 ee, const float* eul, const float* goal, v3 base) 
 // ---------------------------------------------------------------- a11: termination (env_mujoco.py:144-150, env_mujoco_util.py:492-582)
 // returns done; *bonus, *succ; updates steps / episodes counters in the task row
 JDEV bool terminal_inspection(int task, float* trow, float q2, v3 ee, v3 base, v3 obj, v3 dest_goal, int touch, float* bonus, int* succ, float* wb,
-                              const float* eul = nullptr, const float* reachgoal = nullptr) {
+                              const float* eul = nullptr, const float* reachgoal = nullptr, float* picked = nullptr) {
   float steps = trow[JT_STEPS] + 1.f;
   trow[JT_STEPS] = steps;
-  const float task_max = task == 2 ? 500.f : 700.f;   // picking / placing 700, everything else 500 (env_mujoco.py:20-21)
+  // picking / placing 700, pickAndplace 1200, reaching / grasping 500 (env_mujoco.py:18-23)
+  const float task_max = (task == JTASK_PICKING || task == JTASK_PLACING) ? 700.f : (task == JTASK_PICKANDPLACE ? 1200.f : 500.f);
   *succ = 0; *wb = 0.f;
   if (!(steps < task_max)) { *bonus = -10.f; return true; }
   float n = trow[JT_EPISODES] + 1.f;
@@ -208,6 +220,21 @@ JDEV bool terminal_inspection(int task, float* trow, float q2, v3 ee, v3 base, v
   if (task == 2) {   // reaching (:504-520; the reference returns a 3-tuple here, which env_mujoco.py:125 cannot unpack: the success flag is the fix)
     const float dist = norm(ee - mk3(reachgoal[0], reachgoal[1], reachgoal[2]));
     if (dist < 0.025f && reach_ang_diff(eul, reachgoal + 3) < PI / 6.f) { *bonus = 200.f - n * 0.1f; *succ = 1; return true; }
+    *bonus = 0.f;
+    return false;
+  }
+  if (task == JTASK_GRASPING) {   // :521-536 (3-tuple in the reference: the success flag is the fix)
+    if (norm(ee - obj) > 0.2f) { *bonus = -20.f; return true; }             // gripper too far away from the object
+    if (obj.z > 0.1898f + 0.07f && (touch == 1 || touch == 3)) { *bonus = 200.f - n * 0.1f; *succ = 1; return true; }
+    if (obj.z < 0.1f) { *bonus = -20.f; return true; }
+    *bonus = 0.f;
+    return false;
+  }
+  if (task == JTASK_PICKANDPLACE) {   // :585-600, with the `picked` flag carried in the task row
+    const float dx = dest_goal.x - obj.x, dy = dest_goal.y - obj.y, dd = sqrtf(dx * dx + dy * dy);
+    if (obj.z > 0.1898f + 0.07f && (touch == 1 || touch == 3) && *picked == 0.f) { *picked = 1.f; *bonus = 20.f; return false; }
+    if (dd < 0.04f && touch == 0 && obj.z < 0.35f) { *bonus = 180.f; *succ = 1; return true; }
+    if (obj.z < 0.1f) { *bonus = -20.f; return true; }
     *bonus = 0.f;
     return false;
   }
@@ -223,6 +250,40 @@ JDEV bool terminal_inspection(int task, float* trow, float q2, v3 ee, v3 base, v
   if (dd > 0.02f && touch == 0 && obj.z < 0.20f) { *bonus = -20.f; return true; }
   *bonus = 0.f;
   return false;
+}
+
+// ---------------------------------------------------------------- a12 (grasping): pre-reach target / loop conditions (env_mujoco_util.py:123-170)
+// value of np.float16(x) as a float: round to nearest even on 11 significant bits (normal range; |x| < 65504, subnormals flushed
+// like values that small never matter here: the angles are O(1))
+JDEV float f16_round(float x) {
+  unsigned u = __float_as_uint(x);
+  const unsigned sign = u & 0x80000000u;
+  u &= 0x7FFFFFFFu;
+  if (u < 0x38800000u) {   // below the smallest normal half (6.1e-5): subnormal halves are multiples of 2^-24
+    const float q = rintf(__uint_as_float(u) * 16777216.f) * (1.f / 16777216.f);
+    return __uint_as_float(__float_as_uint(q) | sign);
+  }
+  u += 0x00000FFFu + ((u >> 13) & 1u);   // round to nearest even at bit 13
+  u &= 0xFFFFE000u;
+  return __uint_as_float(u | sign);
+}
+// orientation part of the pre-reach target: looks along EE -> object, yaw = the drawn gamma; float16 like the reference's array
+JDEV void grasp_reach_ori(v3 ee, v3 obj_goal, float gamma, float* ori) {
+  const v3 d = obj_goal - ee;
+  const float sx = d.x > 0.f ? 1.f : (d.x < 0.f ? -1.f : 0.f);
+  ori[0] = f16_round(-asinf(d.y / sqrtf(d.y * d.y + d.z * d.z)) * sx);
+  ori[1] = f16_round(acosf(d.x / norm(d)) * sx);
+  ori[2] = f16_round(gamma);
+}
+// |unit(quat_from_euler(EE euler)) - unit(quat_from_euler(goal euler))| (:144-150)
+JDEV float grasp_ang_diff(const float* eul_ee, const float* eul_goal) {
+  float a[4], b[4];
+  euler_rxyz_to_quat(eul_ee[0], eul_ee[1], eul_ee[2], a);
+  euler_rxyz_to_quat(eul_goal[0], eul_goal[1], eul_goal[2], b);
+  const float na = rsqrtf(a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3]), nb = rsqrtf(b[0] * b[0] + b[1] * b[1] + b[2] * b[2] + b[3] * b[3]);
+  float s = 0.f;
+  for (int k = 0; k < 4; k++) { const float d = a[k] * na - b[k] * nb; s += d * d; }
+  return sqrtf(s);
 }
 
 // ---------------------------------------------------------------- a4/a5: operational-space controller on the wave
@@ -324,8 +385,9 @@ JDEV void osc_target_quat(L& s, int lane) {
 }
 
 // Writes the six arm torques into s.ctrl[0..5].  Scratch: the (not yet built) constraint-row area s.J.
+// General form, as abr_control writes it: Mx = (J M^-1 J^T)^-1 (or its thresholded pseudo-inverse), u = -kv M dq - J^T Mx u_task + bias.
 template <class L>
-JDEV void stage_osc(const JacoModelDev* m, L& s, int lane, unsigned& flags) {
+JDEV void stage_osc_general(const JacoModelDev* m, L& s, int lane, unsigned& flags) {
   float* Jm = s.J;            // [6][6] J[r][c], rows: 3 translational, 3 rotational; columns: arm dofs
   float* T = s.J + 72;        // M^-1 J^T
   float* X = s.J + 108;       // J M^-1 J^T, then its (pseudo-)inverse Mx
@@ -397,6 +459,105 @@ JDEV void stage_osc(const JacoModelDev* m, L& s, int lane, unsigned& flags) {
   }
   wave_sync();
 }
+
+// Direct form for the regular case.  J is square (6 task dimensions, 6 arm dofs), so wherever J M^-1 J^T is invertible
+//     J^T (J M^-1 J^T)^-1 = J^T J^-T M J^-1 = M J^-1        and        det(J M^-1 J^T) = det(J)^2 / det(M):
+// one 6x6 solve J x = u_task (partial pivoting: J is not definite) and one pivot product of M replace the elimination on [M | J^T], the
+// 6x6x6 product and the second elimination of the general form -- and the solve is better conditioned (cond(J) instead of
+// cond(J)^2 cond(M)).  The branch rule stays abr_control's: |det(J M^-1 J^T)| < 1e-3 -> the general form with its pseudo-inverse.
+#ifndef JACO_OSC_GENERAL_ONLY
+template <class L>
+JDEV void stage_osc(const JacoModelDev* m, L& s, int lane, unsigned& flags) {
+  float* Jm = s.J;            // [6][6] J[r][c], rows: 3 translational, 3 rotational; columns: arm dofs (same layout as the general form)
+  v3 pe; m3 Re;
+  ee_frame(m, s, &pe, &Re);
+  if (lane < 6) {
+    sv S = ldsv(s.cdof[lane]);
+    v3 jp = S.b + cross(S.a, pe);
+    Jm[0 * 6 + lane] = jp.x; Jm[1 * 6 + lane] = jp.y; Jm[2 * 6 + lane] = jp.z;
+    Jm[3 * 6 + lane] = S.a.x; Jm[4 * 6 + lane] = S.a.y; Jm[5 * 6 + lane] = S.a.z;
+  }
+  const int i = lane < 6 ? lane : 0;
+  // det(M): pivot product of the (SPD) arm block, no pivoting
+  float Am[6], detM = 1.f;
+#pragma unroll
+  for (int j = 0; j < 6; j++) Am[j] = s.M[m_index(i, j)];
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    const float piv = wave_bcast(Am[k], k);
+    detM *= piv;
+    const float f = lane > k ? Am[k] / piv : 0.f;
+#pragma unroll
+    for (int j = k + 1; j < 6; j++) Am[j] -= f * wave_bcast(Am[j], k);
+  }
+  // task-space error and its gains (uniform across lanes), as in the general form
+  const float* tg = s.task + JT_TARGET;
+  float ut[6];
+  ut[0] = pe.x - tg[0]; ut[1] = pe.y - tg[1]; ut[2] = pe.z - tg[2];
+  float qd[4] = {s.osc_qd[0], s.osc_qd[1], s.osc_qd[2], s.osc_qd[3]}, qe[4];
+  mat_to_quat(Re, qe);
+  float cw = qe[0], cx = -qe[1], cy = -qe[2], cz = -qe[3];
+  float ew = qd[0] * cw - qd[1] * cx - qd[2] * cy - qd[3] * cz;
+  float ex = qd[0] * cx + qd[1] * cw + qd[2] * cz - qd[3] * cy;
+  float ey = qd[0] * cy - qd[1] * cz + qd[2] * cw + qd[3] * cx;
+  float ez = qd[0] * cz + qd[1] * cy - qd[2] * cx + qd[3] * cw;
+  float sg = ew > 0.f ? 1.f : (ew < 0.f ? -1.f : 0.f);
+  ut[3] = -ex * sg; ut[4] = -ey * sg; ut[5] = -ez * sg;
+  float nx = sqrtf(ut[0] * ut[0] + ut[1] * ut[1] + ut[2] * ut[2]), na = sqrtf(ut[3] * ut[3] + ut[4] * ut[4] + ut[5] * ut[5]);
+  const float sat_xyz = JOSC_VMAX_XYZ / JOSC_KP * JOSC_KV, sat_abg = JOSC_VMAX_ABG / JOSC_KO * JOSC_KV;
+  float sx = nx > sat_xyz ? sat_xyz / nx : 1.f, sa = na > sat_abg ? sat_abg / na : 1.f;
+  for (int k = 0; k < 3; k++) { ut[k] *= JOSC_KP * sx; ut[3 + k] *= JOSC_KO * sa; }
+  wave_sync();   // Jm visible
+  // J x = u_task: Gauss-Jordan over lanes 0..5 (lane = row), implicit partial pivoting (the pivot row of column k is the unused lane with
+  // the largest |entry|; rows are never moved)
+  float A[6], b = ut[0];
+#pragma unroll
+  for (int j = 0; j < 6; j++) A[j] = Jm[i * 6 + j];
+#pragma unroll
+  for (int j = 1; j < 6; j++) b = i == j ? ut[j] : b;
+  bool used = lane >= 6;
+  float detJ = 1.f, xs = 0.f;
+  int prow[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    const float cand = used ? -1.f : fabsf(A[k]);
+    float best = -1.f;
+    int p = 0;
+#pragma unroll
+    for (int j = 0; j < 6; j++) { const float v = wave_bcast(cand, j); if (v > best) { best = v; p = j; } }
+    prow[k] = p;
+    const float piv = wave_bcast(A[k], p);
+    detJ *= piv;
+    const float inv = 1.f / piv;
+    const float f = lane == p ? 0.f : A[k] * inv;
+#pragma unroll
+    for (int j = k + 1; j < 6; j++) A[j] -= f * wave_bcast(A[j], p);
+    b -= f * wave_bcast(b, p);
+    if (lane == p) { used = true; xs = inv; }
+  }
+  const float detX = detJ * detJ / detM;
+  if (fabsf(detX) < 1e-3f || !(detX == detX)) {   // (wave-uniform) abr_control's SVD branch: rare
+    wave_sync();
+    stage_osc_general(m, s, lane, flags);
+    return;
+  }
+  xs *= b;   // the lane that was pivot row of column k holds x_k
+  float x[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) x[k] = wave_bcast(xs, prow[k]);
+  wave_sync();
+  if (lane < 6) {   // u = bias - M (kv dq + x)
+    float u = s.bias[lane];
+#pragma unroll
+    for (int k = 0; k < 6; k++) u -= s.M[m_index(lane, k)] * (JOSC_KV * s.qvel[k] + x[k]);
+    s.ctrl[lane] = u;
+  }
+  wave_sync();
+}
+#else
+template <class L>
+JDEV void stage_osc(const JacoModelDev* m, L& s, int lane, unsigned& flags) { stage_osc_general(m, s, lane, flags); }
+#endif
 
 // ---------------------------------------------------------------- a2: action -> target / gripper ramp (env_mujoco_util.py:602-646)
 template <class L>

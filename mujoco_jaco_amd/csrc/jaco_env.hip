@@ -52,6 +52,7 @@ struct JacoHandle {
   int* order = nullptr;       // launch order of the env-level light kernel: expensive envs first
   unsigned* order_ctl = nullptr;   // histogram / cursors / cost sum / bucket reference of the ordering passes
   int schedule = 1;           // option "schedule": 0 = launch envs in index order
+  int min_nsub_sched = 2;     // option "min_nsub_sched": shortest step (substeps) that gets the cost-ordered launch and the resident tier workers
   const float* noise = nullptr;
   const float* subgoal = nullptr;   // obs_mode 1: the policy's sub-goal offsets for the "subgoal_reach" marker
   int obs_mode = 0;
@@ -434,7 +435,7 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
   A.env_mode = io.mode; A.task_id = h->task; A.nact = h->task == JACO_TASK_REACHING ? 6 : 7; A.seed = h->seed;
   A.task = h->task_rows; A.cache = h->cache; A.action = io.action; A.noise = h->noise; A.obs_mode = h->obs_mode; A.subgoal = h->subgoal; A.obs = io.obs; A.reward = io.reward; A.done = io.done; A.mask = io.mask; A.marker = h->marker;
   A.cost = h->cost;
-  const bool reorder = io.mode == 1 && h->schedule && nsub >= 8 && h->num_envs >= 4096;
+  const bool reorder = io.mode == 1 && h->schedule && nsub >= h->min_nsub_sched && h->num_envs >= 4096;
   std::pair<hipEvent_t, hipEvent_t>*ev = nullptr, *kev = nullptr;
   if (h->timing && io.mode <= 1) {   // (the masked forward passes of resets are not the kernel being measured)
     if (h->events_used == h->events.size()) {
@@ -472,7 +473,8 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
   // 65 536 of them) has filled the chip such a hole only opens when the grid runs out -- a huge-tier env queued at t = 0 would then
   // start its 10 ms of work when everything else is done.  Launched before the ordering pass, they have three small kernels of
   // head start on the light grid (and the event record below adds a barrier packet in front of it).
-  const bool conc = h->concurrent && io.mode == 1 && nsub >= 8 && h->num_envs >= 4096;
+  // (short steps too: at frame_skip 4 the serial drains behind the light grid were 1.2 ms of a 5.1 ms step, profiles/r03_trace_fs4.txt)
+  const bool conc = h->concurrent && io.mode == 1 && nsub >= h->min_nsub_sched && h->num_envs >= 4096;
   if (conc) {
     HIPCHK(h, hipEventRecord(h->ev_fork, st));
     for (int t = 2; t >= 0; t--) HIPCHK(h, hipStreamWaitEvent(h->side[t], h->ev_fork, 0));
@@ -501,7 +503,7 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
   // drain grids = the tiers' full occupancy on 256 CUs (8 / 4 / 2 workgroups per CU by LDS and registers); slots are claimed one at a time
   unsigned mg = ne < 2048 ? ne : 2048, hg = ne < JACO_HEAVY_GRID ? ne : JACO_HEAVY_GRID, gg = ne < 512 ? ne : 512;
   if (io.mode == 2) { mg = mg < 64 ? mg : 64; hg = hg < 64 ? hg : 64; gg = gg < 256 ? gg : 256; }   // (reset-time forward passes: overflows of the light tier go straight to the last one)
-  if (io.mode >= 4) { if (ev) HIPCHK(h, hipEventRecord(ev->second, st)); return JACO_OK; }   // take_action / terminal_inspection run no substep: nothing can overflow
+  if (io.mode == 4 || io.mode == 5) { if (ev) HIPCHK(h, hipEventRecord(ev->second, st)); return JACO_OK; }   // take_action / terminal_inspection run no substep: nothing can overflow
   if (io.mode != 2) JLAUNCH(h, jaco_physics_kernel_medium_drain, dim3(mg), dim3(64), 0, st, A);   // (mode 2 queues for the last tier only)
   if (h->handdown && io.mode == 1) {
     // the heavy tier holds 4 envs per CU: an env that needed it for a few substeps is passed back down to a second medium drain
@@ -542,7 +544,7 @@ __global__ void jaco_reset_kernel(JacoResetArgs R) {
   for (int k = 0; k < R.nv; k++) { R.qvel[(size_t)e * R.nv + k] = 0.f; R.qacc_ws[(size_t)e * R.nv + k] = 0.f; R.qvel_lo[(size_t)e * R.nv + k] = 0.f; }
   for (int k = 0; k < 24; k++) R.marker[(size_t)e * 24 + k] = R.marker_rest[k];   // sim.reset(): markers back to their XML pose
   // _create_init_angle (env_mujoco_util.py:176-185); fingers stay at qpos0 (mujoco.py:342-343)
-  if (R.task_id == JACO_TASK_PLACING) {
+  if (R.task_id == JACO_TASK_PLACING || R.task_id == JACO_TASK_GRASPING) {   // 'carrying', 'grasping', 'placing' (:181-185)
     const float PI = 3.14159265358979323846f;
     float a0 = U(0.f, 1.f) < 0.5f ? U(3.f * PI / 8.f, PI / 2.f) : U(PI / 2.f, 5.f * PI / 8.f);
     q[0] = a0; q[1] = 3.85f; q[2] = U(1.f, 1.1f); q[3] = U(2.f, 2.1f); q[4] = U(0.8f, 2.3f); q[5] = U(-1.2f, -1.1f);
@@ -585,6 +587,13 @@ extern "C" int jaco_placing_hold(JacoHandle* h, const uint8_t* mask_dev, int nsu
   EnvIO hold; hold.mode = 3; hold.mask = mask_dev; hold.listed = h->reset_listed;
   return launch_step(h, nullptr, nsub, (hipStream_t)stream, nullptr, -1, hold);
 }
+#define JACO_PREREACH_MAX_SUBSTEPS 4000   // cap of the grasping reset's two `while True` loops (typically ~600-1500 substeps at 0.4 m/s)
+extern "C" int jaco_grasping_prereach(JacoHandle* h, const uint8_t* mask_dev, int max_substeps, float* obs_dev, void* stream) {
+  if (!h || !obs_dev || max_substeps <= 0) return JACO_EINVAL;
+  if (h->model_host.obj_body < 0 || h->model_host.nq < 23) { h->err = "jaco_grasping_prereach: the model has no object body"; return JACO_EINVAL; }
+  EnvIO pre; pre.mode = 6; pre.mask = mask_dev; pre.obs = obs_dev; pre.listed = h->reset_listed;
+  return launch_step(h, nullptr, max_substeps, (hipStream_t)stream, nullptr, -1, pre);
+}
 extern "C" int jaco_reset(JacoHandle* h, const uint8_t* mask_dev, float* obs_dev, void* stream) {
   if (!h || !obs_dev) return JACO_EINVAL;
   ENTER(h);
@@ -599,6 +608,11 @@ extern "C" int jaco_reset(JacoHandle* h, const uint8_t* mask_dev, float* obs_dev
   if (h->task == JACO_TASK_PLACING) {   // object into the hand, 150 held substeps while the fingers close (env_mujoco_util.py:106-117)
     int rc = jaco_placing_hold(h, mask_dev, JACO_PLACING_HOLD_SUBSTEPS, stream);
     if (rc) { h->reset_listed = false; return rc; }
+  }
+  if (h->task == JACO_TASK_GRASPING) {   // the pre-reach loops (env_mujoco_util.py:123-170); the observation comes from their last substep's mjData
+    int rc = jaco_grasping_prereach(h, mask_dev, JACO_PREREACH_MAX_SUBSTEPS, obs_dev, stream);
+    h->reset_listed = false;
+    return rc;
   }
   // sim.forward() + _get_observation for the reset envs (the others keep their observation row and controller cache)
   EnvIO io; io.mode = 2; io.obs = obs_dev; io.mask = mask_dev; io.listed = h->reset_listed;
@@ -722,6 +736,7 @@ extern "C" int jaco_set_option(JacoHandle* h, const char* name, double v) {
   if (!strcmp(name, "tier_return")) { h->tier_return = v != 0; return JACO_OK; }
   if (!strcmp(name, "heavy_workers")) { h->workers = v < 1 ? 1 : (int)v; return JACO_OK; }
   if (!strcmp(name, "handdown")) { h->handdown = v != 0; return JACO_OK; }
+  if (!strcmp(name, "min_nsub_sched")) { h->min_nsub_sched = v < 1 ? 1 : (int)v; return JACO_OK; }
   if (!strcmp(name, "hints")) { h->use_hints = v < 0 ? 0 : (v > 2 ? 2 : (int)v); return JACO_OK; }   // 0 off, 1 biggest tier of the last step, 2 tier of its last substep
   if (!strcmp(name, "obs_mode")) { if (v != 0 && v != 1) { h->err = "jaco_set_option: obs_mode must be 0 or 1"; return JACO_EINVAL; } h->obs_mode = (int)v; return JACO_OK; }
   else if (!strcmp(name, "iterations")) m.iterations = (int)v;

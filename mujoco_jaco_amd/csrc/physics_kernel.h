@@ -113,6 +113,7 @@ struct JacoStepArgs {
   int env_mode;              // 0 ctrl-level, 1 env step, 2 forward only (reset: fill cache + observation),
                              // 3 placing reset: nsub controlled substeps with the object pinned in the hand (env_mujoco_util.py:106-117)
                              // 4 take_action only (env_mujoco.py:158-159), 5 terminal_inspection only (env_mujoco.py:144-150): no physics
+                             // 6 grasping reset: the two pre-reach loops (env_mujoco_util.py:123-170), at most nsub substeps, then the observation
   const unsigned char* mask; // modes 2 and 3: envs to run (nullptr = all)
   float* marker;             // [nenv][2][12] poses (position, rotation) of the "hand" / "subgoal_reach" markers, or nullptr = XML rest pose
   int task_id, nact;
@@ -1164,13 +1165,16 @@ JDEV void hint_raise(const JacoStepArgs& A, int env, int tier, int lane) {
 // One substep loop for one env; returns the number of substeps NOT done (light tier bail-out) or 0.
 // TIER: 0 light, 1 medium, 2 heavy, 3 huge.  Tiers below 3 stop at a capacity overflow (*why = 1) and leave the env to the next
 // tier; tiers above 0 can give the env back to the tier below once it would fit again (handback; *why = 2).
-template <class C, int TIER>
+// FULL = false: the instantiation of the step kernel proper (jaco_physics_kernel), which is only ever launched in modes 0 (ctrl level)
+// and 1 (env step): the reset-time modes (forward pass, placing hold, grasping pre-reach, take_action / terminal_inspection on their own)
+// fold away at compile time and stay out of the hot kernel's code and register budget; their launches use jaco_physics_kernel_listed.
+template <class C, int TIER, bool FULL = true>
 JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int lane, bool handback = false, int* why = nullptr) {
   constexpr bool LIGHT = TIER == 0;
   bool bailed = false;
   const JacoModelDev* m = opaque_ptr(A.model);
   const int nq = m->nq, nv = m->nv, nu = m->nu, ns = m->nsensor;
-  if ((A.env_mode == 3 || A.env_mode == 2) && A.mask && !A.mask[env]) return 0;   // masked reset: the other envs are not touched
+  if (FULL && (A.env_mode == 3 || A.env_mode == 2 || A.env_mode == 6) && A.mask && !A.mask[env]) return 0;   // masked reset: the other envs are not touched
   if (lane < nq) { s.qpos[lane] = A.qpos[(size_t)env * nq + lane]; s.qpos_lo[lane] = A.qpos_lo ? A.qpos_lo[(size_t)env * nq + lane] : 0.f; }
   if (lane < nv) { s.qvel[lane] = A.qvel[(size_t)env * nv + lane]; s.qacc_ws[lane] = A.qacc_ws[(size_t)env * nv + lane]; s.qvel_lo[lane] = A.qvel_lo ? A.qvel_lo[(size_t)env * nv + lane] : 0.f; }
   if (lane < nu) s.ctrl[lane] = A.ctrl[(size_t)env * nu + lane];
@@ -1179,8 +1183,8 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
   float sens = 0.f;
   int iters = 0, left = 0, sub0 = 0, nls_last = 0, calm = 0;
   bool tier_used = false;   // this tier's extra capacity was really needed in at least one substep
-  const int emode = A.env_mode;
-  if (emode >= 4) nsub = 0;   // take_action / terminal_inspection on their own: no substep runs
+  const int emode = FULL ? A.env_mode : (A.env_mode != 0 ? 1 : 0);
+  if (emode == 4 || emode == 5) nsub = 0;   // take_action / terminal_inspection on their own: no substep runs
   // poses of the two task-layer markers: LDS copy for this launch (their geoms are re-posed every substep)
   if (lane < 24) s.mk[lane] = A.marker ? A.marker[(size_t)env * 24 + lane] : m->marker_rest[lane / 12][lane % 12];
   if (emode) {   // task row + the one-substep-stale quantities the controller reads (env_logic.h)
@@ -1279,6 +1283,35 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
     osc_target_quat(s, lane);
     wave_sync();
   }
+  if (emode == 6) {
+    // grasping reset (env_mujoco_util.py:123-170): EE target = [object goal, orientation looking along EE -> object] (float16 angles,
+    // yaw drawn), then loop 1: { stop_obj (free-body velocities zeroed, sim.forward), controller + sim.step } until the EE is within
+    // 0.2 m of the object goal (the target then becomes the EE's own position) or its orientation within pi/6 of the sampled reaching
+    // goal's; loop 2: { controller + sim.step, target back to the object goal } until the EE is within 0.15 m.  The reference's
+    // loops are unbounded; here `nsub` caps them (JFLAG_PREREACH_CAP).  JT_PHASE: 1 = loop 1, 2 = loop 2, 3 = done.
+    sub0 = wave_uniform_i((int)s.task[JT_SUB]);
+    if (s.task[JT_PHASE] == 0.f) {
+      stage_walk(m, s, lane, false);
+      wave_sync();
+      v3 pe; m3 Re;
+      ee_frame(m, s, &pe, &Re);
+      const unsigned cnt0 = __float_as_uint(s.task[JT_RNG]);
+      const float gamma = -0.1f + 0.2f * (A.noise ? A.noise[(size_t)env * 12] : rng_uniform(A.seed, (unsigned)env, cnt0));
+      float ori[3];
+      grasp_reach_ori(pe, ld3(s.task + JT_OBJGOAL), gamma, ori);
+      wave_sync();
+      if (lane == 0) {
+        float* t = s.task;
+        for (int k = 0; k < 3; k++) { t[JT_TARGET + k] = t[JT_OBJGOAL + k]; t[JT_TARGET + 3 + k] = ori[k]; }
+        t[JT_GRIP] = 0.6f; t[JT_GRIP_PREV] = 0.6f; t[JT_PHASE] = 1.f;
+        if (!A.noise) t[JT_RNG] = __uint_as_float(cnt0 + 1u);
+      }
+      wave_sync();
+    }
+    osc_target_quat(s, lane);
+    wave_sync();
+    if (s.task[JT_PHASE] >= 3.f) nsub = sub0;   // (already there: only the observation is left)
+  }
   const bool markers = A.marker != nullptr;
   JProfCtx pc;
   pc.row = nullptr;
@@ -1295,11 +1328,21 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
     // instructions each; the kernel's remaining spills (156 B) all sit inside the MPR routine.
     lane = wave_opaque_i(lane);
     bool held_pending = false;
-    if (emode == 3 && s.task[JT_PENDING] != 0.f) {   // resume of an interrupted held substep: its ctrl was saved
+    const int phase = emode == 6 ? wave_uniform_i((int)s.task[JT_PHASE]) : 0;
+    if ((emode == 3 || emode == 6) && s.task[JT_PENDING] != 0.f) {   // resume of an interrupted held substep: its ctrl was saved
       if (lane < nu) s.ctrl[lane] = s.task[JT_CTRL + lane];
       wave_sync();
       if (lane == 0) s.task[JT_PENDING] = 0.f;
       held_pending = true;
+    }
+    if (emode == 6 && phase == 2 && !held_pending) {   // _step_simulation() with what mjData holds from the previous sim.step (one substep stale)
+      stage_osc(m, s, lane, flags);
+      if (lane >= 6 && lane < nu) s.ctrl[lane] = 0.6f;
+      wave_sync();
+    }
+    if (emode == 6 && phase == 1 && !held_pending) {   // stop_obj (mujoco.py:239-246): free-body velocities zeroed before the forward pass
+      if (lane >= 9 && lane < nv) { s.qvel[lane] = 0.f; s.qvel_lo[lane] = 0.f; }
+      wave_sync();
     }
     if (emode == 1) {
       if (s.task[JT_PENDING] != 0.f) {   // resume of a substep interrupted by the light tier: its ctrl was saved
@@ -1332,7 +1375,7 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
     wave_sync();
     stage_mass_bias(m, s, lane, pf);
     wave_sync();
-    if (emode == 3 && !held_pending) {   // every held substep follows a sim.forward(): the controller sees *this* state's M, J, bias
+    if ((emode == 3 || (emode == 6 && phase == 1)) && !held_pending) {   // the substep follows a sim.forward(): the controller sees *this* state's M, J, bias
       stage_osc(m, s, lane, flags);
       if (lane >= 6 && lane < nu) s.ctrl[lane] = 0.6f;
       wave_sync();
@@ -1370,7 +1413,7 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
       left = nsub - sub;
       bailed = true;
       flags |= (cflags & 7u) << (JFLAG_BAIL_CAUSE_SHIFT + 3 * TIER);   // informational: which capacity of which tier sent the env on
-      if (emode == 1 || emode == 3) {
+      if (emode == 1 || emode == 3 || emode == 6) {
         if (lane < nu) s.task[JT_CTRL + lane] = s.ctrl[lane];
         if (lane == 0) { s.task[JT_PENDING] = 1.f; s.task[JT_SUB] = (float)sub; }
         wave_sync();
@@ -1457,13 +1500,36 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
       if (lane >= 9 && lane < nv) { s.qvel[lane] = 0.f; s.qvel_lo[lane] = 0.f; }
       wave_sync();
     }
+    if (emode == 6) {   // the loops' exit tests, on the poses of this substep's forward pass (what mjData holds after sim.step)
+      v3 pe; m3 Re;
+      ee_frame(m, s, &pe, &Re);
+      const v3 og = ld3(s.task + JT_OBJGOAL);
+      const float dist = norm(pe - og);
+      int nph = phase;
+      bool hold = false;
+      if (phase == 1) {
+        float eul[3];
+        mat_to_euler_rxyz(Re, eul);
+        if (dist < 0.2f) { nph = 2; hold = true; }
+        else if (grasp_ang_diff(eul, s.task + JT_REACHGOAL + 3) < 0.52359877559829887f) nph = 2;
+      } else if (dist < 0.15f) nph = 3;
+      wave_sync();
+      if (lane == 0) {
+        float* t = s.task;
+        if (phase == 2 || !hold) { t[JT_TARGET] = og.x; t[JT_TARGET + 1] = og.y; t[JT_TARGET + 2] = og.z; }
+        if (hold) { t[JT_TARGET] = pe.x; t[JT_TARGET + 1] = pe.y; t[JT_TARGET + 2] = pe.z; }
+        t[JT_PHASE] = (float)nph;
+      }
+      wave_sync();
+      if (nph == 3) { sub++; break; }   // (left stays 0: the observation follows below)
+    }
     JSTAMP(8);
     // heavy tier: the burst that overflowed the light capacities is over (two substeps in a row would have fitted): give
     // the env back to the light code for the rest of the step (the caller alternates the two tiers)
     if (!LIGHT && handback && calm >= 2 && sub + 1 < nsub && emode != 2) {
       left = nsub - (sub + 1);
       flags |= JFLAG_TIER_RETURN;
-      if (emode == 1 || emode == 3) { if (lane == 0) { s.task[JT_PENDING] = 0.f; s.task[JT_SUB] = (float)(sub + 1); } wave_sync(); }
+      if (emode == 1 || emode == 3 || emode == 6) { if (lane == 0) { s.task[JT_PENDING] = 0.f; s.task[JT_SUB] = (float)(sub + 1); } wave_sync(); }
       break;
     }
   }
@@ -1476,10 +1542,11 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
       if (lane < nv) { A.qvel[(size_t)env * nv + lane] = s.qvel[lane]; A.qacc_ws[(size_t)env * nv + lane] = s.qacc_ws[lane]; if (A.qvel_lo) A.qvel_lo[(size_t)env * nv + lane] = s.qvel_lo[lane]; }
     }
   }
-  if (left == 0 && lane < ns && A.sensordata && emode < 4) A.sensordata[(size_t)env * ns + lane] = sens;
+  if (left == 0 && lane < ns && A.sensordata && (emode < 4 || emode == 6)) A.sensordata[(size_t)env * ns + lane] = sens;
+  if (emode == 6 && left == 0 && s.task[JT_PHASE] < 3.f) flags |= JFLAG_PREREACH_CAP;
   if (emode == 5) sens = (lane < ns && A.sensordata) ? A.sensordata[(size_t)env * ns + lane] : 0.f;   // touch of the last forward pass
   if (emode) {
-    if ((left == 0 && emode != 3 && emode < 4) || (!LIGHT && left > 0 && !bailed && emode == 1)) {
+    if ((left == 0 && emode != 3 && (emode < 4 || emode == 6)) || (!LIGHT && left > 0 && !bailed && (emode == 1 || emode == 6))) {
       // what the controller reads one substep late, for the next launch -- or, on a heavy -> light hand-back in the middle
       // of a step, for the light code's next substep
       float* CW = A.cache + (size_t)env * JCACHE_N;
@@ -1510,9 +1577,12 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
       bool done = false;
       const float PI = 3.14159265358979323846f;
       if (emode == 1 || emode == 5) {
-        if (emode == 1) rew = A.task_id == 0 ? reward_picking(pe, eul, obj, touch) : (A.task_id == 2 ? reward_reaching(pe, eul, s.task + JT_REACHGOAL, ld3(m->base_pos)) : 0.f);
+        if (emode == 1) rew = A.task_id == JTASK_PICKING ? reward_picking(pe, eul, obj, touch)
+                            : (A.task_id == JTASK_REACHING ? reward_reaching(pe, eul, s.task + JT_REACHGOAL, ld3(m->base_pos))
+                            : (A.task_id == JTASK_GRASPING ? reward_picking(pe, eul, obj, touch, 0.05f) : 0.f));   // (placing, pickAndplace: 0 in the reference)
         float trow[4] = {0.f, s.task[JT_STEPS], s.task[JT_EPISODES], 0.f};
-        done = terminal_inspection(A.task_id, trow, s.qpos[2], pe, ld3(m->base_pos), obj, destgoal, touch, &bonus, &succ, &wb, eul, s.task + JT_REACHGOAL);
+        float picked = s.task[JT_PICKED];
+        done = terminal_inspection(A.task_id, trow, s.qpos[2], pe, ld3(m->base_pos), obj, destgoal, touch, &bonus, &succ, &wb, eul, s.task + JT_REACHGOAL, &picked);
         // quarantine (failure row): a state that went non-finite ends the episode with no reward and stays
         // frozen until it is reset -- what MuJoCo's own bad-state check does with mj_resetData, made visible to the learner
         const bool bad = wave_ballot((flags & JFLAG_NAN) != 0u || !(rew == rew)) != 0ull;
@@ -1520,7 +1590,7 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
         wave_sync();
         if (lane == 0) {
           s.task[JT_STEPS] = trow[JT_STEPS]; s.task[JT_EPISODES] = trow[JT_EPISODES]; s.task[JT_DONE] = done ? 1.f : 0.f;
-          s.task[JT_SUCC] = (float)succ; s.task[JT_WB] = wb; s.task[JT_SUB] = 0.f; s.task[JT_PENDING] = 0.f;
+          s.task[JT_SUCC] = (float)succ; s.task[JT_WB] = wb; s.task[JT_SUB] = 0.f; s.task[JT_PENDING] = 0.f; s.task[JT_PICKED] = picked;
           A.reward[env] = rew + bonus;
           A.done[env] = done ? 1 : 0;
         }
@@ -1542,7 +1612,7 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
         A.obs[(size_t)env * 26 + lane] = o;
       }
     }
-    if (left == 0 && emode == 3 && lane == 0) { s.task[JT_SUB] = 0.f; s.task[JT_PENDING] = 0.f; }
+    if (left == 0 && (emode == 3 || emode == 6) && lane == 0) { s.task[JT_SUB] = 0.f; s.task[JT_PENDING] = 0.f; }
     wave_sync();
     if (lane < JTASK_N) { if (bailed) st_wt(&A.task[(size_t)env * JTASK_N + lane], s.task[lane]); else A.task[(size_t)env * JTASK_N + lane] = s.task[lane]; }
   }
@@ -1570,6 +1640,7 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
 #ifndef JACO_LIGHT_WAVES
 #define JACO_LIGHT_WAVES 3   // waves per SIMD the light kernel is compiled for: 13.3 KB of LDS per env allow 12 envs per CU, 168 VGPRs each
 #endif
+template <bool FULL>
 JDEV void light_grid(const JacoStepArgs& A, JacoLDS<JacoLight>& s) {
   const int lane = lane_id();
   if (env_id() >= A.nenv) return;
@@ -1578,33 +1649,33 @@ JDEV void light_grid(const JacoStepArgs& A, JacoLDS<JacoLight>& s) {
   const int env = A.order ? A.order[slot] : slot;
   // (envs whose previous step ended in a bigger tier were queued there before the launch: not this grid's, and not counted in light_left)
   if (A.routed_mark && A.routed_mark[env] == A.launch_id) return;
-  const bool masked_out = (A.env_mode == 2 || A.env_mode == 3) && A.mask && !A.mask[env];
+  const bool masked_out = FULL && (A.env_mode == 2 || A.env_mode == 3 || A.env_mode == 6) && A.mask && !A.mask[env];
   int left = 0;
   if (!masked_out) {
-    if (A.hint && (A.env_mode == 2 || A.env_mode == 3) && lane == 0) st_wt_i(&A.hint[env], 0);   // a reset env starts from scratch (its forward pass may raise it again)
+    if (FULL && A.hint && (A.env_mode == 2 || A.env_mode == 3 || A.env_mode == 6) && lane == 0) st_wt_i(&A.hint[env], 0);   // a reset env starts from scratch (its forward pass may raise it again)
     const unsigned long long t_start = wave_clock();
-    left = run_env<JacoLight, 0>(A, s, env, A.nsub, lane);
+    left = run_env<JacoLight, 0, FULL>(A, s, env, A.nsub, lane);
     // (only real steps record their cost: the masked forward pass of a reset must not wipe the launch-order heuristic's input)
     if (lane == 0 && A.cost && A.env_mode <= 1) { unsigned c = (unsigned)((wave_clock() - t_start) >> 4); if (left > 0) st_wt_u(&A.cost[env], c); else A.cost[env] = c; }
     // hand-off: the env's state went to memory with write-through stores (run_env); once they are acknowledged the env
     // is appended to the medium tier's queue.  Its workgroups run concurrently (jaco_env.hip) and poll the queue.
     // (a reset's forward pass goes straight to the last tier: one more launch in the chain instead of three, each of which would
     // redo the narrowphase of a hand-inside-the-pedestal pose up to its own capacity)
-    if (left > 0) queue_push(A, A.env_mode == 2 ? 2 : 0, env, left, lane);
+    if (left > 0) queue_push(A, (FULL && A.env_mode == 2) ? 2 : 0, env, left, lane);
   }
   wave_sync();
   }
   if (lane == 0 && A.light_left) jaco_atomic_dec(A.light_left, false);
 }
-__global__ __launch_bounds__(64, JACO_LIGHT_WAVES) void jaco_physics_kernel(JacoStepArgs A) {
+__global__ __launch_bounds__(64, JACO_LIGHT_WAVES) void jaco_physics_kernel(JacoStepArgs A) {   // modes 0 and 1 only
   __shared__ JacoLDS<JacoLight> s;
-  light_grid(A, s);
+  light_grid<false>(A, s);
 }
-// the same code under its own name for reset-time launches (forward pass, placing hold; for a masked reset a small grid that walks
+// the full code under its own name for reset-time launches (forward pass, placing hold; for a masked reset a small grid that walks
 // the list of reset envs): the step kernel's launch statistics (rocprofv3 --stats, bench.py's kernel_ms) then hold step launches only
-__global__ __launch_bounds__(64, JACO_LIGHT_WAVES) void jaco_physics_kernel_listed(JacoStepArgs A) {
+__global__ __launch_bounds__(64, JACO_LIGHT_WAVES) void jaco_physics_kernel_listed(JacoStepArgs A) {   // every mode
   __shared__ JacoLDS<JacoLight> s;
-  light_grid(A, s);
+  light_grid<true>(A, s);
 }
 // One handed-over env on a bigger-tier workgroup: the big code (medium: TB = 1, heavy: TB = 2) runs while the overflow
 // lasts, the light code in between, until the env's step is complete.  Returns 0, or -- medium only -- the substeps left
@@ -1612,7 +1683,7 @@ __global__ __launch_bounds__(64, JACO_LIGHT_WAVES) void jaco_physics_kernel_list
 template <class BIG, int TB, class U>
 JDEV int run_env_tiers(const JacoStepArgs& A, U& u, int env, int lane) {
   const unsigned long long t_start = wave_clock();
-  const bool stepmode = A.env_mode == 1 || A.env_mode == 3;
+  const bool stepmode = A.env_mode == 1 || A.env_mode == 3 || A.env_mode == 6;
   int left = stepmode ? A.nsub : A.remaining[env], why = 0;
   for (;;) {
     left = run_env<BIG, TB>(A, u.big, env, stepmode ? A.nsub : left, lane, !A.no_tier_return, &why);
@@ -1638,7 +1709,7 @@ union JacoAllLDS { JacoLDS<JacoHeavy> heavy; JacoMediumLDS ml; };
 #define JACO_HANDDOWN_MIN 8
 #endif                      // substeps that must be left for a hand-down to pay (it costs a queue round trip and a fresh model staging)
 JDEV int heavy_env_run(const JacoStepArgs& A, JacoAllLDS& u, int env, int lane, bool allow_down = false) {
-  const bool stepmode = A.env_mode == 1 || A.env_mode == 3;
+  const bool stepmode = A.env_mode == 1 || A.env_mode == 3 || A.env_mode == 6;
   int left = stepmode ? A.nsub : A.remaining[env], why = 0;
   for (;;) {
     left = run_env<JacoHeavy, 2>(A, u.heavy, env, stepmode ? A.nsub : left, lane, !A.no_tier_return, &why);
@@ -1666,7 +1737,7 @@ JDEV void heavy_env(const JacoStepArgs& A, JacoAllLDS& u, int env, int lane) {
 // down through heavy / medium / light like everything else
 union JacoHugeLDS { JacoLDS<JacoHuge> huge; JacoAllLDS rest; };
 JDEV void huge_env(const JacoStepArgs& A, JacoHugeLDS& u, int env, int lane) {
-  const bool stepmode = A.env_mode == 1 || A.env_mode == 3;
+  const bool stepmode = A.env_mode == 1 || A.env_mode == 3 || A.env_mode == 6;
   const unsigned long long t_start = wave_clock();
   int left = stepmode ? A.nsub : A.remaining[env], why = 0;
   for (;;) {

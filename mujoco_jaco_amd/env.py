@@ -17,9 +17,10 @@ import torch
 from . import _lib
 from .physics import BatchedMujoco, JacoError
 
-# picking / placing run end to end in the reference; reaching's termination returns a 3-tuple there that env_mujoco.py:125 cannot
-# unpack (env_mujoco_util.py:504-520): built here with the missing success flag added
-TASK_IDS = {"picking": 0, "placing": 1, "reaching": 2}
+# picking / placing run end to end in the reference; the terminations of reaching / grasping / pickAndplace return 3-tuples there that
+# env_mujoco.py:125 cannot unpack (env_mujoco_util.py:504-536,585-600): built here with the missing success flag added.
+# Not built: carrying / releasing / pushing (terminate at once or need the object in hand with task-specific init poses, :181-189).
+TASK_IDS = {"picking": 0, "placing": 1, "reaching": 2, "grasping": 3, "pickAndplace": 4}
 
 
 class Box:
@@ -41,8 +42,8 @@ class JacoBatchedEnv:
     def __init__(self, num_envs=1, device=0, frame_skip=50, seed=0, **kwargs):
         self.task = kwargs.get("task", "picking")
         if self.task not in TASK_IDS:
-            # the reference's remaining task branches (grasping, carrying, pickAndplace, ...) return 3-tuples from
-            # _get_terminal_inspection (env_mujoco_util.py:521-536,585-600) that env_mujoco.py:125 cannot unpack
+            # carrying and pushing end every episode in their first step (`return True, 0, wb`, env_mujoco_util.py:549-550,583-584);
+            # releasing needs its own in-hand reset (:186-189)
             raise NotImplementedError("task %r: supported tasks are %s" % (self.task, sorted(TASK_IDS)))
         # observation / marker branch: the rule-based sub-goal (env_mujoco_util.py:240-254,607-609) is what main.py:44-45,183-184,
         # 223-224 always selects (the default here); rulebased_subgoal=False puts the reaching goal into obs[17:23] (:255-270).
@@ -64,7 +65,7 @@ class JacoBatchedEnv:
         # ---- RL setup (env_mujoco.py:15-93)
         self.current_steps = 0
         self.max_steps = 2500
-        self.task_max_steps = 700 if self.task in ("picking", "placing") else 500
+        self.task_max_steps = 700 if self.task in ("picking", "placing") else (500 if self.task in ("reaching", "grasping") else 1200)   # env_mujoco.py:18-23
         self.skip_frames = int(frame_skip)
         obs_max = np.hstack([[3], [1] * 25]).astype(np.float32)
         self.observation_space = Box(-obs_max, obs_max, dtype=np.float32)
@@ -125,6 +126,12 @@ class JacoBatchedEnv:
         """The held part of the placing reset on its own (env_mujoco_util.py:106-117); reset() runs it for task 'placing'."""
         m = self._mask(mask)
         self.sim._chk(self.L.jaco_placing_hold(self.h, self._p(m) if m is not None else None, int(nsub), self.sim._stream()))
+
+    def _grasping_prereach(self, mask=None, max_substeps=4000):
+        """The pre-reach loops of the grasping reset on their own (env_mujoco_util.py:123-170); reset() runs them for task 'grasping'."""
+        m = self._mask(mask)
+        self.sim._chk(self.L.jaco_grasping_prereach(self.h, self._p(m) if m is not None else None, int(max_substeps), self._p(self._obs), self.sim._stream()))
+        return self._out(self._obs)[0]
 
     def _mask(self, mask):
         if mask is None:

@@ -7,6 +7,7 @@ MuJoCo defaults that the reference relies on because its XML has no <option>
  are spelled out in DEFAULTS below.
 """
 import os
+import re
 from xml.etree import ElementTree
 
 import numpy as np
@@ -26,10 +27,32 @@ DEFAULTS = dict(
 )
 
 
+_NUM = re.compile(r"[-+]?(?:\d+\.?\d*|\.\d+)(?:[eE][-+]?\d+)?")
+
+
+def _numbers(s):
+    """Numeric attribute -> list of floats the way MuJoCo reads it: stream extraction (`istringstream >> double`), i.e. each number is the
+    longest valid prefix and the next one starts right behind it -- white space is not required between them.  The reference's own
+    files rely on that: jaco2_torque.xml:47 has size=".01 .02.035", which MuJoCo reads as (.01, .02, .035)."""
+    out, pos = [], 0
+    s = s.strip()
+    while pos < len(s):
+        while pos < len(s) and s[pos].isspace():
+            pos += 1
+        if pos >= len(s):
+            break
+        m = _NUM.match(s, pos)
+        if m is None:
+            raise ValueError("not a number at %r in attribute %r" % (s[pos:pos + 8], s))
+        out.append(float(m.group(0)))
+        pos = m.end()
+    return out
+
+
 def _floats(s, n=None, default=None):
     if s is None:
         return None if default is None else np.array(default, dtype=np.float64)
-    v = np.array([float(x) for x in s.split()], dtype=np.float64)
+    v = np.array(_numbers(s), dtype=np.float64)
     if n is not None and len(v) < n and default is not None:
         full = np.array(default, dtype=np.float64)
         full[: len(v)] = v

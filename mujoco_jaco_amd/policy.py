@@ -105,6 +105,18 @@ def read_policy_zip(path):
     z = zipfile.ZipFile(path)
     data = json.loads(z.read("data"))
     P = dict(np.load(io.BytesIO(z.read("parameters"))))
+    if not data.get("tails"):
+        # a plain (non-composite) SAC MlpPolicy zip, e.g. models_baseline/policies/reaching/policy.zip: one actor under model/pi.
+        # Its observation slice is not in the zip in a loadable form (policy_kwargs pickles a TensorFlow op); the reference wires
+        # this very policy as the `reaching` primitive with obs_relativity subtract ref [17..22] - tar [1..6] and actions [0..5]
+        # (main.py:97-103), which is also how it was trained on task `reaching` (goal pose minus EE pose, 6 inputs).
+        t = _tail_from_params(P, "model/pi")
+        nin, nout = t["hidden"][0][0].shape[0], t["out"][0].shape[1]
+        if nin != 6 or nout != 6:
+            raise ValueError("plain policy zip with %d inputs / %d actions: only the reaching layout (6 / 6) is known" % (nin, nout))
+        t.update(name="model/pi", obs_index=[1, 2, 3, 4, 5, 6, 17, 18, 19, 20, 21, 22], act_index=[0, 1, 2, 3, 4, 5],
+                 rel_ref=[17, 18, 19, 20, 21, 22], rel_tar=[1, 2, 3, 4, 5, 6], act_scale=1.0, is_weight=False)
+        return {"task": "reaching", "tails": [t]}
     prim = _Unpickler(io.BytesIO(base64.b64decode(data["primitives"][":serialized:"]))).load()
     tails = []
     for name in data["tails"]:

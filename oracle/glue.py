@@ -77,6 +77,42 @@ def reward_picking(ee_pos, ee_quat, obj_pos, touch):
     return r * 0.01
 
 
+def reward_grasping(ee_pos, ee_quat, obj_pos, touch):
+    """_get_reward, task 'grasping' (env_mujoco_util.py:352-391): the picking shape with its own coefficients
+    (touch 1 / 2 / 3: +0.75 / -0.75 / +2.5, scale 0.05)."""
+    roll, pitch, yaw = euler_from_quat(ee_quat)
+    ee_vec = get_rotation(roll, pitch, yaw, [0, 0, -1], False)
+    xyz = np.asarray(obj_pos, dtype=np.float64) - ee_pos
+    d = np.linalg.norm(xyz)
+    x, y, z = xyz / d
+    tp, ty = -np.arccos(z), -np.arccos(-x / np.sqrt(1 - z * z))
+    tv = get_rotation(0, tp, ty, [0, 0, 1], True)
+    tv[2] *= -1
+    ang = np.linalg.norm(ee_vec - tv)
+    r = 5 * np.exp(-d / 0.2) / 2 + 2 * np.exp(-ang / (np.pi / 6)) / 2 / (d * 15 + 1)
+    r += {1: 5 * 0.5 * 0.3, 2: -5 * 0.5 * 0.3, 3: 5 * 0.5}.get(int(touch), 0.0)
+    r += 100 * (obj_pos[2] - OBJECT_Z)
+    return r * 0.05
+
+
+def grasp_reach_ori(ee_pos, obj_goal, gamma):
+    """Orientation part of the pre-reach target of the grasping / carrying reset (env_mujoco_util.py:124-129): looks along EE -> object,
+    yaw = the drawn gamma; stored as float16 like the reference's np.array(..., dtype=np.float16)."""
+    x, y, z = np.asarray(obj_goal, np.float64) - np.asarray(ee_pos, np.float64)
+    alpha = -np.arcsin(y / np.sqrt(y ** 2 + z ** 2)) * np.sign(x)
+    beta = np.arccos(x / np.linalg.norm([x, y, z])) * np.sign(x)
+    return np.array([alpha, beta, gamma], dtype=np.float16).astype(np.float64)
+
+
+def grasp_prereach_conditions(ee_pos, ee_quat, obj_goal, reach_goal_ori):
+    """What the two `while True` loops of the grasping reset test after each substep (env_mujoco_util.py:138-167): distance EE -> object
+    goal, and |q_EE - q_goal| of the unit quaternions built from the Euler angles (goal = the sampled *reaching* goal's orientation)."""
+    dist = np.linalg.norm(np.asarray(ee_pos) - np.asarray(obj_goal))
+    grip = quat_from_euler(*euler_from_quat(ee_quat)); grip = grip / np.linalg.norm(grip)
+    tar = quat_from_euler(*reach_goal_ori); tar = tar / np.linalg.norm(tar)
+    return dist, np.linalg.norm(grip - tar)
+
+
 def canon_euler(e):
     """euler -> unit quaternion -> euler, as the reaching reward / termination do before differencing (env_mujoco_util.py:323-330)."""
     return euler_from_quat(quat_from_euler(*e))
@@ -113,13 +149,33 @@ def sample_reach_goal(u01, base_pos):
     return np.hstack([pos, np.array([alpha, beta, gamma], dtype=np.float16)])
 
 
-def terminal(task, q2, ee_pos, obj_pos, dest_goal, touch, num_episodes, base_pos, ee_quat=None, reach_goal=None):
-    """_get_terminal_inspection for the two live tasks (env_mujoco_util.py:492-502,537-548,567-582).
-    `num_episodes` is the counter value *before* the call (the function increments it first)."""
+def terminal(task, q2, ee_pos, obj_pos, dest_goal, touch, num_episodes, base_pos, ee_quat=None, reach_goal=None, picked=None):
+    """_get_terminal_inspection (env_mujoco_util.py:492-600) for picking / placing (4-tuples in the reference) and reaching / grasping /
+    pickAndplace (3-tuples there, which env_mujoco.py:125 cannot unpack: the success flag is the fix).
+    `num_episodes` is the counter value *before* the call (the function increments it first).  pickAndplace carries the `picked`
+    flag (self.picked): pass a one-element list, updated in place."""
     n = num_episodes + 1
     wb = np.linalg.norm(np.asarray(ee_pos) - base_pos)
     if np.pi - 0.1 < q2 < np.pi + 0.1:
         return True, -1.0, wb, 0
+    if task == "grasping":   # :521-536
+        if np.linalg.norm(np.asarray(ee_pos) - np.asarray(obj_pos)) > 0.2:
+            return True, -20.0, wb, 0
+        if obj_pos[2] > OBJECT_Z + 0.07 and touch in (1, 3):
+            return True, 200 - n * 0.1, wb, 1
+        if obj_pos[2] < 0.1:
+            return True, -20.0, wb, 0
+        return False, 0.0, wb, 0
+    if task == "pickAndplace":   # :585-600
+        dd = np.linalg.norm(np.asarray(dest_goal)[:2] - np.asarray(obj_pos)[:2])
+        if obj_pos[2] > OBJECT_Z + 0.07 and touch in (1, 3) and not picked[0]:
+            picked[0] = True
+            return False, 20.0, wb, 0
+        if dd < 0.04 and touch == 0 and obj_pos[2] < 0.35:
+            return True, 180.0, wb, 1
+        if obj_pos[2] < 0.1:
+            return True, -20.0, wb, 0
+        return False, 0.0, wb, 0
     if task == "reaching":   # :504-520 (a 3-tuple in the reference: success flag added)
         if np.linalg.norm(np.asarray(ee_pos) - reach_goal[:3]) < 0.025 and reach_ang_diff(ee_quat, reach_goal[3:6]) < np.pi / 6:
             return True, 200 - n * 0.1, wb, 1
@@ -142,7 +198,7 @@ def terminal(task, q2, ee_pos, obj_pos, dest_goal, touch, num_episodes, base_pos
 
 def env_terminal(task, current_steps, *args, **kw):
     """JacoMujocoEnv.terminal_inspection (env_mujoco.py:144-150): current_steps is the value *before* the call."""
-    task_max = 700 if task in ("picking", "placing") else 500
+    task_max = 700 if task in ("picking", "placing") else (1200 if task == "pickAndplace" else 500)   # env_mujoco.py:18-23
     if current_steps + 1 < task_max:
         return terminal(task, *args, **kw)
     return True, -10.0, 0.0, 0

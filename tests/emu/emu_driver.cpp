@@ -39,7 +39,8 @@ static int emu_launch(JacoStepArgs A, int* heavy_envs) {
   if ((int)g_hint.size() != A.nenv) g_hint.assign(A.nenv, 0);
   A.hint = g_use_hints ? g_hint.data() : nullptr; A.hint_mode = g_use_hints;
   emu_grid = A.nenv;
-  for (int e = 0; e < A.nenv; e++) emu_run_wave(e, [&]() { jaco_physics_kernel(A); });
+  // (as jaco_env.hip: the step kernel proper serves modes 0 / 1, every other mode the full-code twin)
+  for (int e = 0; e < A.nenv; e++) emu_run_wave(e, [&]() { if (A.env_mode >= 2) jaco_physics_kernel_listed(A); else jaco_physics_kernel(A); });
   emu_grid = 1;
   // (the resident workers of the GPU build leave as soon as the light grid is done: here that is always the case, so the
   // drains serve every queue; they are the same serve functions).  Same launch sequence as jaco_env.hip, grids of one workgroup.

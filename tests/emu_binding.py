@@ -101,6 +101,15 @@ class EmuJacoEnv(EmuEnv):
         finally:
             self.frame_skip = fs
 
+    def grasping_prereach(self, cap=4000, noise=None):
+        """mode 6: the pre-reach loops of the grasping reset (jaco_reset runs them after the draws); returns the observation row."""
+        fs, self.frame_skip = self.frame_skip, cap
+        try:
+            self._call(6, None, None if noise is None else np.ascontiguousarray(noise, np.float32))
+        finally:
+            self.frame_skip = fs
+        return self.obs.copy()
+
     def forward(self, noise=None):
         self._call(2, None, None if noise is None else np.ascontiguousarray(noise, np.float32))
         return self.obs.copy()

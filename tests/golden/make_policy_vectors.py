@@ -47,5 +47,11 @@ if __name__ == "__main__":
         f = os.path.join(REF, "logger_csv", "SR_%s_abalation_GA.csv" % task)
         v = success_log(f)
         sr[task] = {"file": "logger_csv/SR_%s_abalation_GA.csv" % task, "n": len(v), "mean_last_100": float(np.mean(v[-100:])), "max": float(np.max(v)), "final": float(v[-1])}
+    # the plain SAC reaching policy (no logged success rate exists for it in the reference tree)
+    P = policy.read_policy_zip(os.path.join(REF, "models_baseline", "policies", "reaching", "policy.zip"))
+    policy.save_npz(P, os.path.join(HERE, "policy_reaching.npz"))
+    Pp = policy.load_npz(os.path.join(HERE, "policy_picking.npz"))
+    print("reaching", [(t["name"], t["hidden"][0][0].shape) for t in P["tails"]],
+          "identical to the picking zip's frozen reaching primitive:", all(np.array_equal(a[0], b[0]) for a, b in zip(P["tails"][0]["hidden"], Pp["tails"][0]["hidden"])))
     json.dump(sr, open(os.path.join(HERE, "policy_success_rates.json"), "w"), indent=1)
     print(sr)

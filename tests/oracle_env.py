@@ -33,6 +33,8 @@ class OracleEnv:
         self.obj_goal, self.dest_goal = np.zeros(3), np.zeros(3)
         self.reach_goal = np.zeros(6)          # task 'reaching' / the rulebased_subgoal = False observation branch
         self.rulebased = True
+        self.picked = [False]                  # task 'pickAndplace' (self.picked)
+        self.target = None                     # task 'grasping': the EE target the reset's pre-reach leaves behind (self.target_pos)
 
     def set_state(self, qpos, qvel=None, qacc_ws=None):
         o = self.o
@@ -76,13 +78,51 @@ class OracleEnv:
             o.step(np.concatenate([u, [ramp[k]] * 3]))
         obs, touch, pe, qe, obj = self.observe(noise12[6:12])
         rew = glue.reward_picking(pe, qe, obj, touch) if self.task == "picking" else (
-            glue.reward_reaching(pe, qe, self.reach_goal, self.base) if self.task == "reaching" else 0.0)
+            glue.reward_reaching(pe, qe, self.reach_goal, self.base) if self.task == "reaching" else (
+                glue.reward_grasping(pe, qe, obj, touch) if self.task == "grasping" else 0.0))
         done, bonus, wb, succ = glue.env_terminal(self.task, self.steps, o.get("qpos")[2], pe, obj, self.dest_goal, touch, self.episodes, self.base,
-                                                  ee_quat=qe, reach_goal=self.reach_goal)
+                                                  ee_quat=qe, reach_goal=self.reach_goal, picked=self.picked)
         self.steps += 1
-        if self.steps < (700 if self.task in ("picking", "placing") else 500):
+        if self.steps < (700 if self.task in ("picking", "placing") else (1200 if self.task == "pickAndplace" else 500)):
             self.episodes += 1
         return obs, rew + bonus, done, succ
+
+    def _osc(self, target):
+        o = self.o
+        jp, jr = o.jac_body_com(self.ee)
+        J = np.vstack([jp[:, :6], jr[:, :6]])
+        M = o.get("qM").reshape(o.nv, o.nv)[:6, :6]
+        pe, qe = self._ee()
+        return glue.osc_generate(o.get("qvel")[:6], target, J, M, o.get("qfrc_bias")[:6], pe, qe)
+
+    def grasping_prereach(self, gamma, cap=4000):
+        """The pre-reach loops of the grasping reset (env_mujoco_util.py:123-170) from the current state (set_state has run sim.forward()):
+        returns the number of substeps taken.  Loop 1 calls stop_obj (free-body velocities zeroed + sim.forward(): the controller reads
+        the *current* state's M, J, bias) before every _step_simulation; loop 2 steps with what the previous sim.step left in mjData."""
+        o = self.o
+        pe, qe = self._ee()
+        ori = glue.grasp_reach_ori(pe, self.obj_goal, gamma)
+        target = np.concatenate([self.obj_goal, ori])
+        self.grip, n, g3 = 0.6, 0, [0.6] * 3
+        while n < cap:
+            v = o.get("qvel").copy(); v[9:] = 0
+            o.set("qvel", v); o.forward()
+            o.step(np.concatenate([self._osc(target), g3])); n += 1
+            pe, qe = self._ee()
+            dist, ang = glue.grasp_prereach_conditions(pe, qe, self.obj_goal, self.reach_goal[3:6])
+            if dist < 0.2:
+                target = np.concatenate([pe, ori])
+                break
+            if ang < np.pi / 6:
+                break
+        while n < cap:
+            o.step(np.concatenate([self._osc(target), g3])); n += 1
+            pe, qe = self._ee()
+            target = np.concatenate([self.obj_goal, ori])
+            if np.linalg.norm(pe - self.obj_goal) < 0.15:
+                break
+        self.target = target
+        return n
 
     def placing_hold(self, nsub=150):
         """The object part of the placing reset (env_mujoco_util.py:106-117): object into the grasp frame, `nsub` controlled

@@ -233,3 +233,106 @@ def test_action_taken_once_when_a_step_overflows_in_its_first_substep(names, mod
         assert abs(e.task[0, 0] - (0.7 + 0.1 * step)) < 1e-6 and abs(e.task[0, 16] - (0.6 + 0.1 * step)) < 1e-6   # gripper: one increment per step
         assert abs(obs[0, 7] - oo[7]) < 1e-6 and np.abs(e.qpos[0, 6:9] - oe.o.get("qpos")[6:9]).max() < 1e-4
         assert int(e.task[0, 18:19].view(np.uint32)[0]) == 12 * (step + 1) + 6   # draw counter: 6 (reset obs) + 12 per step
+
+
+# ---------------------------------------------------------------- tasks grasping / pickAndplace (round 3)
+def _quat_to_mat(q):
+    w, x, y, z = q
+    return np.array([[w * w + x * x - y * y - z * z, 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                     [2 * (x * y + w * z), w * w - x * x + y * y - z * z, 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), w * w - x * x - y * y + z * z]])
+
+
+def _inject_scene(e, model_arrays, ee, eeq, obj, q2, touch):
+    """Put a golden scene into what terminal_inspection reads: the cached frame of the body that carries the EE (so that the kernel's
+    EE frame = the given pose), the object position, joint 2, and a sensordata pattern of the given touch class."""
+    f = model_arrays["f_frame_EE"]
+    pl, Rl = f[1:4], _quat_to_mat(f[4:8])
+    Rb = _quat_to_mat(eeq / np.linalg.norm(eeq)) @ Rl.T
+    pb = ee - Rb @ pl
+    e.cache[0, 78:81] = pb; e.cache[0, 81:90] = Rb.reshape(-1); e.cache[0, 90:93] = obj
+    e.qpos[0, 2] = q2
+    s = np.zeros(20, np.float32)
+    if touch == 1: s[1] = 1.0                   # 0_touch: an inner pad alone
+    if touch == 2: s[0] = 1.0                   # EE_touch: outer
+    if touch == 3: s[2] = 1.0; s[6] = 1.0       # 1_touch (thumb) + 5_touch (index)
+    e.sensordata[0] = s
+
+
+def test_kernel_terminal_inspection_against_the_references_own_outputs(model_arrays):
+    """The in-kernel termination rules of tasks grasping and pickAndplace (csrc/env_logic.h), driven through the terminal_inspection
+    entry (mode 5), against tests/golden/glue_vectors_grasping.npz = outputs of the reference's own _get_terminal_inspection
+    (env_mujoco_util.py:521-536, 585-600): done flag exact, bonus to fp32 rounding, the `picked` flag carried in the task row."""
+    import os
+    GG = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "glue_vectors_grasping.npz"))
+    n = len(GG["g_reward"])
+    for task_id, key in ((3, "g_term_grasp"), (4, "g_term_pp")):
+        e = EmuJacoEnv(task_id=task_id, frame_skip=1)
+        for k in range(0, n, 2):
+            _inject_scene(e, model_arrays, GG["g_ee"][k], GG["g_eeq"][k], GG["g_obj"][k], GG["g_q2"][k], int(GG["g_touch"][k]))
+            e.task[0] = 0; e.task[0, 0] = 0.6; e.task[0, 16] = 0.6
+            e.task[0, 2] = GG["g_nsteps"][k]; e.task[0, 7:10] = GG["g_dest_goal"][k]; e.task[0, 31] = GG["g_picked_in"][k]
+            e._call(5)
+            rd, rb, rwb = GG[key][k]
+            assert bool(e.done[0]) == bool(rd), (task_id, k)
+            assert abs(e.reward[0] - rb) < 2e-4 and abs(e.task[0, 30] - rwb) < 1e-5, (task_id, k, e.reward[0], rb)
+            if task_id == 4:
+                assert e.task[0, 31] == GG["g_picked_out"][k] and e.task[0, 29] == float(rb == 180.0)
+            else:
+                assert e.task[0, 29] == float(bool(rd) and rb > 100)     # success flag (the 4th value the reference's tuple lacks)
+            assert e.task[0, 2] == GG["g_nsteps"][k] + 1 and e.task[0, 1] == 1
+
+
+def test_grasping_prereach_and_steps_match_oracle_env(names, model_arrays):
+    """Grasping reset (env_mujoco_util.py:123-170) from two arm poses of its init range (:181-185): the emulated kernel's pre-reach
+    (mode 6) must take the oracle env's path -- same loop exits, same EE target, observation and arm state -- and the env steps
+    that follow must agree in observation, reward (:352-391) and termination."""
+    for seed, expect_min in ((18, 50), (13, 1)):
+        rng = np.random.default_rng(100 + seed)
+        q = model_arrays["qpos0"].copy()
+        a0 = rng.uniform(3 * np.pi / 8, np.pi / 2) if seed % 2 else rng.uniform(np.pi / 2, 5 * np.pi / 8)
+        q[:6] = [a0, 3.85, rng.uniform(1, 1.1), rng.uniform(2, 2.1), rng.uniform(0.8, 2.3), rng.uniform(-1.2, -1.1)]
+        q[9:12] = [rng.uniform(-.1, .1), 0.65 + rng.uniform(-.08, .02), 0.1898]; q[16:18] = [0.42, 0.31]
+        f32 = lambda a: np.asarray(a, np.float64).astype(np.float32).astype(np.float64)
+        q[:6], q[9:11], q[16:18] = f32(q[:6]), f32(q[9:11]), f32(q[16:18])       # drawn coordinates fp32-representable; model constants exact
+        e = EmuJacoEnv(task_id=3, frame_skip=10)
+        oe = OracleEnv(names, task="grasping", frame_skip=10)
+        oe.obj_goal = f32(q[9:12]); oe.dest_goal = f32([q[16], q[17], 0.3468])
+        oe.reach_goal = np.array([0.35, -0.33, 0.4, 0.2, 1.0, 0.05])
+        oe.set_state(q)
+        e.qpos[0] = q; e.task[0, 4:7] = oe.obj_goal; e.task[0, 7:10] = oe.dest_goal; e.task[0, 32:38] = oe.reach_goal
+        nz = np.full((1, 12), 0.5, np.float32); nz[0, 0] = 0.8
+        n = oe.grasping_prereach(float(-0.1 + 0.2 * np.float32(0.8)))
+        obs = e.grasping_prereach(4000, nz)
+        assert n >= expect_min and e.task[0, 38] == 3 and not (e.flags[0] & 0x20000)            # both loops left, no cap
+        assert np.abs(e.task[0, 10:16] - oe.target).max() < 1e-6                                 # self.target_pos after the reset
+        oo = oe.observe(nz[0, 6:].astype(np.float64))[0]
+        assert np.abs(obs[0] - oo).max() < 2e-5 and np.abs(e.qpos[0, :9] - oe.o.get("qpos")[:9]).max() < 2e-5, (seed, n)
+        for step in range(2):
+            a = rng.uniform(-1, 1, 7).astype(np.float32); nz = rng.uniform(size=(1, 12)).astype(np.float32)
+            ob, rew, done = e.env_step(a, nz)
+            if step == 0:
+                oe.grip = 0.6
+            o2, orew, odone, _ = _oracle_step_with_target(oe, a, nz[0])
+            assert bool(done[0]) == odone and ob[0, 0] == o2[0]
+            assert np.abs(ob[0] - o2).max() < 1e-4 and abs(rew[0] - orew) < 1e-4, (seed, step)
+
+
+def _oracle_step_with_target(oe, a, nz):
+    return oe.step(a.astype(np.float64), nz.astype(np.float64))
+
+
+def test_kernel_terminal_inspection_picking_placing_against_the_references_own_outputs(model_arrays):
+    """Same for the two tasks the reference runs end to end (env_mujoco_util.py:537-548,567-582): tests/golden/glue_vectors.npz."""
+    import os
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "glue_vectors.npz"))
+    for task_id, key in ((0, "s_term_pick"), (1, "s_term_place")):
+        e = EmuJacoEnv(task_id=task_id, frame_skip=1)
+        for k in range(0, len(G["s_ee"]), 2):
+            _inject_scene(e, model_arrays, G["s_ee"][k], G["s_eeq"][k], G["s_obj"][k], G["s_q2"][k], int(G["s_touch"][k]))
+            e.task[0] = 0; e.task[0, 0] = 0.6; e.task[0, 16] = 0.6
+            e.task[0, 2] = G["s_nsteps"][k]; e.task[0, 7:10] = G["s_dest_goal"][k]
+            e._call(5)
+            rd, rb, rwb, rs = G[key][k]
+            assert bool(e.done[0]) == bool(rd) and e.task[0, 29] == rs, (task_id, k)
+            assert abs(e.reward[0] - rb) < 2e-4 and abs(e.task[0, 30] - rwb) < 1e-5

@@ -109,3 +109,47 @@ def test_reaching_goal_observation_branch():
         obs = glue.observation("reaching", touch, R["r_ee"][k], R["r_eeq"][k], R["r_grip"][k], R["r_obj"][k], R["r_dest_goal"][k], None, None,
                                reach_goal=R["r_goal"][k])
         assert np.allclose(obs, R["r_obs"][k], atol=2e-7)
+
+
+# ---------------------------------------------------------------- grasping / pickAndplace branches (round 3)
+@pytest.fixture(scope="module")
+def GG():
+    return np.load(os.path.join(ROOT, "tests", "golden", "glue_vectors_grasping.npz"))
+
+
+def test_grasping_reward_and_terminal_match_reference(GG):
+    base = np.array([0.0, 0.0, 0.157])
+    for k in range(len(GG["g_reward"])):
+        ee, q, obj, touch = GG["g_ee"][k], GG["g_eeq"][k], GG["g_obj"][k], int(GG["g_touch"][k])
+        assert abs(glue.reward_grasping(ee, q, obj, touch) - GG["g_reward"][k]) < 1e-12
+        d, b, wb, succ = glue.terminal("grasping", GG["g_q2"][k], ee, obj, GG["g_dest_goal"][k], touch, int(GG["g_nsteps"][k]), base)
+        rd, rb, rwb = GG["g_term_grasp"][k]
+        assert bool(rd) == d and abs(rb - b) < 1e-12 and abs(rwb - wb) < 1e-12
+        assert succ == int(d and b > 100)                                   # the 4th value the reference's 3-tuple lacks
+
+
+def test_pickandplace_terminal_with_picked_flag_matches_reference(GG):
+    base = np.array([0.0, 0.0, 0.157])
+    seen = set()
+    for k in range(len(GG["g_reward"])):
+        picked = [bool(GG["g_picked_in"][k])]
+        d, b, wb, succ = glue.terminal("pickAndplace", GG["g_q2"][k], GG["g_ee"][k], GG["g_obj"][k], GG["g_dest_goal"][k], int(GG["g_touch"][k]),
+                                       int(GG["g_nsteps"][k]), base, picked=picked)
+        rd, rb, rwb = GG["g_term_pp"][k]
+        assert bool(rd) == d and rb == b and abs(rwb - wb) < 1e-12 and picked[0] == bool(GG["g_picked_out"][k])
+        assert succ == int(b == 180.0)
+        seen.add(float(b))
+    assert seen == {-20.0, -1.0, 0.0, 20.0, 180.0}                          # every branch of :585-600 is exercised
+
+
+def test_grasping_prereach_quantities_match_reference(GG):
+    for k in range(len(GG["g_reward"])):
+        ori = glue.grasp_reach_ori(GG["g_ee"][k], GG["g_obj_goal"][k], GG["g_gamma"][k])
+        assert np.array_equal(ori, GG["g_reach_ori"][k])                    # float16 values: exact
+        dist, ang = glue.grasp_prereach_conditions(GG["g_ee"][k], GG["g_eeq"][k], GG["g_obj_goal"][k], GG["g_goal_ori"][k])
+        assert abs(dist - GG["g_dist"][k]) < 1e-12 and abs(ang - GG["g_angdiff"][k]) < 1e-9
+    assert list(GG["task_max_steps"]) == [500, 1200]
+    assert glue.env_terminal("grasping", 498, 1.3, np.ones(3), np.ones(3), np.ones(3), 0, 0, np.zeros(3))[1] != -10.0
+    assert glue.env_terminal("grasping", 499, 1.3, np.ones(3), np.ones(3), np.ones(3), 0, 0, np.zeros(3)) == (True, -10.0, 0.0, 0)
+    assert glue.env_terminal("pickAndplace", 1198, 1.3, np.ones(3), np.ones(3), np.ones(3), 0, 0, np.zeros(3), picked=[False])[1] != -10.0
+    assert glue.env_terminal("pickAndplace", 1199, 1.3, np.ones(3), np.ones(3), np.ones(3), 0, 0, np.zeros(3), picked=[False]) == (True, -10.0, 0.0, 0)

@@ -44,7 +44,8 @@ def test_env_step_parity_vs_oracle_env(model_arrays, names):
             rerrs.append(abs(rew[k] - orew))
     errs, rerrs = np.array(errs), np.array(rerrs)
     print("env-level obs error after up to %d steps x 50 substeps: median %.2e p90 %.2e max %.2e; reward error max %.2e" % (nstep, np.median(errs), np.percentile(errs, 90), errs.max(), rerrs.max()))
-    assert np.median(errs) < 2e-5 and errs.max() < 1e-3 and rerrs.max() < 1e-3
+    # MAX over 12 envs x 3 steps, bounds = 3x the values measured on MI355X (round 3: obs 5.6e-5, reward 2.8e-7, median 6.0e-8)
+    assert np.median(errs) < 2e-7 and errs.max() < 1.7e-4 and rerrs.max() < 1e-6
 
 
 def test_env_level_closed_loop_parity_256_envs_10_steps(tmp_path):
@@ -69,8 +70,9 @@ def test_env_level_closed_loop_parity_256_envs_10_steps(tmp_path):
     print("env level, %d envs x %d steps: qpos err median %.2e p99 %.2e max %.2e | obs err median %.2e max %.2e | reward err max %.2e | envs finished %d" % (
         B, nstep, np.median(eq[live]), np.percentile(eq[live], 99), eq[live].max(), np.median(eo[live]), eo[live].max(), er[live].max(), int(r["done"].any(0).sum())))
     assert (g["flags"] & 15).max() == 0
-    assert np.median(eq[live]) <= 1e-6 and np.percentile(eq[live], 99) <= 1e-4
-    assert eo[live].max() <= 1e-3 and er[live].max() <= 1e-3
+    # bounds = 3x measured (qpos median 1.3e-7, p99 1.0e-6, max 5.9e-5; obs max 1.5e-5; reward 1.3e-7)
+    assert np.median(eq[live]) <= 4e-7 and np.percentile(eq[live], 99) <= 3e-6 and eq[live].max() <= 2e-4
+    assert eo[live].max() <= 5e-5 and er[live].max() <= 5e-7
 
 
 def test_drop_in_surface_single_env():
@@ -169,7 +171,7 @@ def test_placing_reset_vs_oracle(model_arrays, names):
         xp = oe.o.get("xpos").reshape(-1, 3)[oe.ee_obj]; xm = oe.o.get("xmat").reshape(-1, 3, 3)[oe.ee_obj]
         assert np.abs(q[k, 9:12] - (xp - 0.04 * xm[:, 0])).max() < 3e-2                 # (pinned in space: the closing fingers push the hand a little)
     print("placing reset: obs err max %.2e" % max(errs))
-    assert max(errs) < 2e-5
+    assert max(errs) < 4e-7   # (measured 1.2e-7)
 
 
 def test_placing_hold_parity_150(model_arrays, names):
@@ -196,8 +198,8 @@ def test_placing_hold_parity_150(model_arrays, names):
         oe.placing_hold(150)
         oq = oe.o.get("qpos")
         print("placing hold env %d: arm/finger angle err %.2e, object position err %.2e" % (k, np.abs(q1[k, :9] - oq[:9]).max(), np.abs(q1[k, 9:12] - oq[9:12]).max()))
-        assert np.abs(q1[k, :9] - oq[:9]).max() < 1e-3, (k, np.abs(q1[k, :9] - oq[:9]).max())
-        assert np.abs(q1[k, 9:12] - oq[9:12]).max() < 1e-5
+        assert np.abs(q1[k, :9] - oq[:9]).max() < 2.5e-6, (k, np.abs(q1[k, :9] - oq[:9]).max())   # 150 controlled substeps; measured <= 6.9e-7
+        assert np.abs(q1[k, 9:12] - oq[9:12]).max() < 2.5e-7                                        # measured <= 7.3e-8
 
 
 def test_frame_skip4_with_termination_masking(model_arrays, names):
@@ -240,7 +242,7 @@ def test_frame_skip4_with_termination_masking(model_arrays, names):
             oo, orew, odone, _ = oes[k].step(a[k].astype(np.float64), nz[k].astype(np.float64))
             assert bool(done[k]) == odone, (s, k)
             fs4_errs.append(np.abs(obs[k] - oo).max())
-            assert np.abs(obs[k] - oo).max() < 2e-4 and obs[k, 0] == oo[0]
+            assert np.abs(obs[k] - oo).max() < 1.5e-6 and obs[k, 0] == oo[0]   # (measured max 4.2e-7 over 12 steps)
         if s == 1:
             assert done[::2].all() and not done[1::2].any() and (rew[::2] < -9).all()
             frozen_q = qn.copy()
@@ -491,3 +493,96 @@ def test_nan_state_is_quarantined():
     assert torch.isfinite(env.sim.get_state()[0]).all() and torch.isfinite(env.sim.get_state()[1]).all()
     obs, rew, done, infos = venv.step(a)
     assert not done[bad].any() and infos["quarantined"] == 0
+
+
+def test_grasping_reset_and_steps_vs_oracle(model_arrays, names):
+    """Task grasping end to end through the C ABI.  (A) jaco_reset (draws + the pre-reach loops of env_mujoco_util.py:123-170) leaves
+    every env with the EE within 0.15 m of its object goal.  (B) from an injected pre-reach state the loops, replayed on the fp64
+    oracle env, give the same EE target, observation and arm state; the env steps that follow agree in observation, reward
+    (:352-391) and termination (:521-536)."""
+    from mujoco_jaco_amd.env import JacoBatchedEnv
+    from oracle_env import OracleEnv
+    B = 16
+    env = JacoBatchedEnv(num_envs=B, task="grasping", seed=7)
+    assert env.task_max_steps == 500 and env.action_space.shape == (7,)
+    obs = env.reset().cpu().numpy()
+    t = env.task_state().cpu().numpy()
+    fl = env.sim.flags().cpu().numpy()
+    q = env.sim.get_state()[0].cpu().numpy()
+    assert (t[:, 38] == 3).all() and not (fl & (0x20000 | 15)).any()                          # every pre-reach finished: no cap, no error flag
+    assert (np.linalg.norm(obs[:, 1:4] - t[:, 4:7], axis=1) < 0.1505).all()                   # EE within 0.15 m of the object goal
+    assert np.abs(q[:, 1] - 3.85).max() < 0.6 and np.allclose(t[:, 10:13], t[:, 4:7])         # target_pos ends on the object goal
+    env.close()
+    # (B) injected state: arm in the init range of :181-185, object on the holder, zero velocity
+    rng = np.random.default_rng(5)
+    lo = np.array([3 * np.pi / 8, 3.85, 1.0, 2.0, 0.8, -1.2]); hi = np.array([5 * np.pi / 8, 3.85, 1.1, 2.1, 2.3, -1.1])
+    f32 = lambda a: np.asarray(a, np.float64).astype(np.float32).astype(np.float64)
+    q0 = np.tile(model_arrays["qpos0"], (B, 1)).astype(np.float64)                           # model constants exact, drawn coordinates fp32-representable
+    q0[:, :6] = f32(rng.uniform(lo, hi, (B, 6)))
+    q0[:, 9] = f32(rng.uniform(-0.1, 0.1, B)); q0[:, 10] = f32(0.65 + rng.uniform(-0.08, 0.02, B)); q0[:, 11] = f32(0.1898)
+    q0[:, 16] = f32(0.4 + rng.uniform(-0.05, 0.05, B)); q0[:, 17] = f32(0.3 + rng.uniform(-0.05, 0.05, B))
+    goal = f32(np.concatenate([rng.uniform(0.3, 0.42, (B, 2)) * rng.choice([-1, 1], (B, 2)), rng.uniform(0.3, 0.5, (B, 1)), rng.uniform(-1, 1, (B, 3))], 1))
+    env = JacoBatchedEnv(num_envs=B, task="grasping", seed=7)
+    dev = env.device
+    env.sim.set_state(torch.tensor(q0, dtype=torch.float32, device=dev), torch.zeros(B, 21, device=dev), torch.zeros(B, 21, device=dev))
+    ts = env.task_state(); ts[:] = 0; ts[:, 0] = 0.6; ts[:, 16] = 0.6
+    ts[:, 4:7] = torch.tensor(q0[:, 9:12], dtype=torch.float32); ts[:, 7:9] = torch.tensor(q0[:, 16:18], dtype=torch.float32); ts[:, 9] = 0.3468
+    ts[:, 32:38] = torch.tensor(goal, dtype=torch.float32)
+    env.set_task_state(ts)
+    nz = np.full((B, 12), 0.5, np.float32); nz[:, 0] = 0.3
+    env.set_noise(torch.tensor(nz))
+    obs2 = env._grasping_prereach().cpu().numpy()
+    t2 = env.task_state().cpu().numpy()
+    q2 = env.sim.get_state()[0].cpu().numpy()
+    oes, errs = [], []
+    for k in range(B):
+        oe = OracleEnv(names, task="grasping")
+        oe.obj_goal = q0[k, 9:12].copy(); oe.dest_goal = f32([q0[k, 16], q0[k, 17], 0.3468]); oe.reach_goal = goal[k].copy()
+        oe.set_state(q0[k])
+        n = oe.grasping_prereach(float(-0.1 + 0.2 * np.float32(0.3)))
+        assert t2[k, 38] == 3 and np.abs(t2[k, 10:16] - oe.target).max() < 1e-6, (k, n)
+        oo = oe.observe(nz[k, 6:].astype(np.float64))[0]
+        errs.append((np.abs(obs2[k] - oo).max(), np.abs(q2[k, :9] - oe.o.get("qpos")[:9]).max(), n))
+        oes.append(oe)
+    errs = np.array(errs)
+    print("grasping pre-reach, %d envs: substeps %d..%d, obs err max %.2e, arm angle err max %.2e" % (B, errs[:, 2].min(), errs[:, 2].max(), errs[:, 0].max(), errs[:, 1].max()))
+    assert errs[:, 0].max() < 3e-6 and errs[:, 1].max() < 7e-7   # 3x measured (9.8e-7 / 2.3e-7 over pre-reaches of 2 .. 427 substeps)
+    rng = np.random.default_rng(9)
+    serr, rerr = [], []
+    for s in range(3):
+        a = rng.uniform(-1, 1, (B, 7)).astype(np.float32); nzs = rng.uniform(size=(B, 12)).astype(np.float32)
+        env.set_noise(torch.tensor(nzs))
+        ob, rew, done, _ = env.step(torch.tensor(a))
+        ob, rew, done = ob.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()
+        for k in range(B):
+            if oes[k] is None:
+                continue
+            oo, orew, odone, _ = oes[k].step(a[k].astype(np.float64), nzs[k].astype(np.float64))
+            assert bool(done[k]) == odone and ob[k, 0] == oo[0], (s, k)
+            serr.append(np.abs(ob[k] - oo).max()); rerr.append(abs(rew[k] - orew))
+            if odone:
+                oes[k] = None
+    print("grasping steps: obs err max %.2e, reward err max %.2e" % (max(serr), max(rerr)))
+    assert max(serr) < 8e-7 and max(rerr) < 3e-7                 # 3x measured (2.7e-7 / 9.9e-8)
+
+
+def test_pickandplace_episode_flow(names):
+    """Task pickAndplace (termination env_mujoco_util.py:585-600; reward 0; 1 200-step episodes): reset like picking; the first step in
+    which the object is above the pick height with a grasp pays +20 once (`picked`), placing it on the pedestal ends the episode
+    with +180.  Driven through the C ABI with states injected into the HIP env; rules checked against oracle/glue.py."""
+    from mujoco_jaco_amd.env import JacoBatchedEnv
+    env = JacoBatchedEnv(num_envs=8, task="pickAndplace", seed=3)
+    assert env.task_max_steps == 1200 and env.action_space.shape == (7,)
+    obs = env.reset()
+    q = env.sim.get_state()[0].cpu().numpy()
+    lo = np.array([0.7, 3.8, 1.0, 1.8, 1.0, 0.8]); hi = np.array([2.5, 4.0, 1.7, 2.5, 2.5, 2.3])       # the picking init range (:177-180)
+    assert (q[:, :6] >= lo - 1e-6).all() and (q[:, :6] <= hi + 1e-6).all() and np.allclose(q[:, 11], 0.1898)
+    o, r, d, _ = env.step(torch.zeros(8, 7))
+    assert not d.any() and (r == 0).all()                                                                # reward 0 (:441-442), nothing picked yet
+    t = env.task_state()
+    assert (t[:, 31] == 0).all() and (t[:, 1] == 1).all()
+    # object lifted into the closed hand is hard to stage physically in one step: the rule itself is pinned in
+    # tests/test_env_emu.py::test_kernel_terminal_inspection_against_the_references_own_outputs; here: the time-out at 1 200 steps
+    t[:, 1] = 1198; env.set_task_state(t)
+    _, _, d, _ = env.step(torch.zeros(8, 7)); assert not d.any()
+    _, r, d, _ = env.step(torch.zeros(8, 7)); assert d.all() and (r == -10).all()

@@ -39,6 +39,19 @@ def _np_forward(P, obs, sign=1.0):
     return np.tanh(num / den), w
 
 
+def test_reaching_policy_fixture_is_the_picking_zips_frozen_primitive():
+    from mujoco_jaco_amd import policy
+    R = policy.load_npz(os.path.join(HERE, "golden", "policy_reaching.npz"))
+    P = policy.load_npz(os.path.join(HERE, "golden", "policy_picking.npz"))
+    assert len(R["tails"]) == 1 and R["tails"][0]["rel_ref"] == [17, 18, 19, 20, 21, 22] and R["tails"][0]["act_index"] == [0, 1, 2, 3, 4, 5]
+    for (Wa, ba), (Wb, bb) in zip(R["tails"][0]["hidden"], P["tails"][0]["hidden"]):      # main.py:97-103 loads it with freeze=True
+        assert np.array_equal(Wa, Wb) and np.array_equal(ba, bb)
+    pol = policy.HPCPolicy(R, nact=6)
+    obs = np.zeros((4, 26), np.float32); obs[:, 17:20] = [0.3, 0.3, 0.4]; obs[:, 1:4] = [0.2, 0.3, 0.4]
+    a, w = pol.predict(obs)
+    assert a.shape == (4, 6) and w.shape == (4, 1) and float(a[0, 0]) > 0.2          # goal 10 cm ahead in x: the policy moves +x
+
+
 @pytest.mark.parametrize("task", ["picking", "placing"])
 def test_policy_fixture_forward_matches_numpy(task):
     from mujoco_jaco_amd import policy
@@ -90,11 +103,13 @@ def test_policy_unpickler_refuses_everything_but_the_table_constructors():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("task,band", [("picking", (0.70, 1.0)), ("placing", (0.67, 1.0))])
-def test_shipped_policy_success_rate_on_hip_env(task, band):
+@pytest.mark.parametrize("task,mean_len,mean_ret", [("picking", 168.0, 177.0), ("placing", 129.0, 159.0)])
+def test_shipped_policy_success_rate_on_hip_env(task, mean_len, mean_ret):
     """2 048 deterministic episodes per task.  Reference (training-time rolling success, logger_csv): picking mean of the last
-    100 logged values 78.4 %, max 96 %; placing 81.9 %, max 96 %.  Band: from 8-15 points below the logged mean (the logged
-    runs still explore) up to 100 %.  Measured on MI355X: picking 95.0-95.4 %, placing 82.6 % (profiles/r02_policy_success.txt)."""
+    100 logged values 78.4 %, max 96 %; placing 81.9 %, max 96 %.  Two-sided band: from 15 points below the logged mean (the logged
+    runs still explore) to 2 points above the logged maximum -- a physics that is EASIER than MuJoCo (stickier friction, softer
+    fingers) fails the upper edge, a harder one the lower.  Episode length and return are pinned to the values measured on MI355X
+    in round 3 (picking 94.2 % / 167.8 steps / 176.8; placing 84.8 % / 128.8 steps / 159.3) so a drift of the physics shows there too."""
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
     from gpu_policy_eval import evaluate
@@ -102,8 +117,23 @@ def test_shipped_policy_success_rate_on_hip_env(task, band):
     res = evaluate(task, 2048, 1.0, verbose=False)
     print(task, res, "reference log:", ref)
     assert res["finished"] == 2048 and res["nan_flag"] == 0
-    assert band[0] <= res["success_rate"] <= band[1]
-    assert res["success_rate"] >= ref["mean_last_100"] / 100 - 0.15
+    assert ref["mean_last_100"] / 100 - 0.15 <= res["success_rate"] <= ref["max"] / 100 + 0.02
+    assert abs(res["mean_length"] - mean_len) <= 0.1 * mean_len and abs(res["mean_return"] - mean_ret) <= 0.1 * mean_ret
+
+
+@pytest.mark.gpu
+def test_shipped_reaching_policy_on_task_reaching():
+    """Third statistic: models_baseline/policies/reaching/policy.zip (a plain SAC MlpPolicy; identical weights to the frozen reaching
+    primitive inside the picking zip) on task `reaching`, 2 048 deterministic episodes.  The reference tree holds no logged success
+    rate for it, so this is a regression pin of the value measured on MI355X in round 3, not a reference pin."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
+    from gpu_policy_eval import evaluate
+    res = evaluate("reaching", 2048, 1.0, verbose=False)
+    print("reaching", res)
+    assert res["finished"] == 2048 and res["nan_flag"] == 0
+    # measured: 5.7 % success (the 2.5 cm / 30 degree goal of :516 is tight for a policy frozen as a primitive), mean episode 381 steps, mean return 42.6
+    assert 0.03 <= res["success_rate"] <= 0.09 and abs(res["mean_length"] - 381) <= 38 and abs(res["mean_return"] - 42.6) <= 6
 
 
 @pytest.mark.gpu

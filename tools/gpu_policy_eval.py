@@ -9,8 +9,11 @@ from mujoco_jaco_amd.policy import HPCPolicy
 
 
 def evaluate(task="picking", B=2048, sign=1.0, max_steps=700, seed=5, verbose=True, noise_free=False):
-    env = JacoBatchedEnv(num_envs=B, task=task, seed=seed)
-    pol = HPCPolicy.load(os.path.join(ROOT, "tests", "golden", "policy_%s.npz" % task), device=env.device, relativity_sign=sign)
+    # task reaching: the plain SAC policy of models_baseline/policies/reaching reads the reaching goal from obs[17:23] (the
+    # rulebased_subgoal = False observation branch, env_mujoco_util.py:255-270), 6-wide action, 500-step episodes
+    env = JacoBatchedEnv(num_envs=B, task=task, seed=seed, rulebased_subgoal=(task != "reaching"))
+    pol = HPCPolicy.load(os.path.join(ROOT, "tests", "golden", "policy_%s.npz" % task), device=env.device, relativity_sign=sign, nact=env.action_space.shape[0])
+    max_steps = min(max_steps, env.task_max_steps)
     if noise_free:
         env.set_noise(torch.full((B, 12), 0.5))
     obs = env.reset()
@@ -28,7 +31,7 @@ def evaluate(task="picking", B=2048, sign=1.0, max_steps=700, seed=5, verbose=Tr
         fin = active & done
         succ |= fin & (rew > 100)
         active &= ~done
-        wsum += w.mean(0); wn += 1
+        wsum = wsum[:w.shape[1]] + w.mean(0); wn += 1
         if verbose and (s % 100 == 99 or not bool(active.any())):
             print("step %3d: finished %d / %d, successes %d, mean primitive weights %s" % (s + 1, int((~active).sum()), B, int(succ.sum()), (wsum / wn).tolist()), flush=True)
         if not bool(active.any()):
