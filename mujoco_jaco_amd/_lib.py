@@ -59,22 +59,30 @@ SYMBOLS = {
     "jaco_stage_profile": (_ci, [_vp, ctypes.POINTER(ctypes.c_uint64), _ci]),
 }
 
-_lib = None
+_libs = {}
 
 
-def load():
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
+def load(variant=""):
+    """variant "": the default layout (11 fused bodies, 21 dofs in blocks 9 + 6 + 6); "_d12": the build for jaco2_torque.xml."""
+    if variant not in _libs:
+        path = LIB_PATH if not variant else os.path.join(_HERE, "libjaco_env%s.so" % variant)
+        if not os.path.exists(path):
             raise ImportError(
                 "mujoco_jaco_amd: %s is missing. Build the HIP extension first "
-                "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback." % LIB_PATH)
-        L = ctypes.CDLL(LIB_PATH)
+                "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback." % path)
+        L = ctypes.CDLL(path)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
             fn.restype, fn.argtypes = res, args
-        _lib = L
-    return _lib
+        _libs[variant] = L
+    return _libs[variant]
+
+
+def variant_for(blob_bytes):
+    """Which build of the library steps this model: the loader of each build rejects models outside its compiled layout."""
+    from .modelc import blob as blobmod
+    M = blobmod.loads(blob_bytes)
+    return "_d12" if (int(M["nv"][0]) == 12 and int(M["f_nbody"][0]) == 12) else ""
 
 
 def model_path(name):

@@ -460,12 +460,14 @@ JDEV void stage_osc_general(const JacoModelDev* m, L& s, int lane, unsigned& fla
   wave_sync();
 }
 
-// Direct form for the regular case.  J is square (6 task dimensions, 6 arm dofs), so wherever J M^-1 J^T is invertible
+// Direct form for the regular case (build option -DJACO_OSC_DIRECT; NOT the default: measured on MI355X it is 0.1-0.7 % slower end to end --
+// stage profile 6.5 k instead of 5.8 k cycles per substep: the pivot search adds dependent cross-lane round trips, and the kernel is
+// bound by those, not by the VALU work it saves -- profiles/r03_ab_osc.txt).  J is square (6 task dimensions, 6 arm dofs), so wherever J M^-1 J^T is invertible
 //     J^T (J M^-1 J^T)^-1 = J^T J^-T M J^-1 = M J^-1        and        det(J M^-1 J^T) = det(J)^2 / det(M):
 // one 6x6 solve J x = u_task (partial pivoting: J is not definite) and one pivot product of M replace the elimination on [M | J^T], the
 // 6x6x6 product and the second elimination of the general form -- and the solve is better conditioned (cond(J) instead of
 // cond(J)^2 cond(M)).  The branch rule stays abr_control's: |det(J M^-1 J^T)| < 1e-3 -> the general form with its pseudo-inverse.
-#ifndef JACO_OSC_GENERAL_ONLY
+#ifdef JACO_OSC_DIRECT
 template <class L>
 JDEV void stage_osc(const JacoModelDev* m, L& s, int lane, unsigned& flags) {
   float* Jm = s.J;            // [6][6] J[r][c], rows: 3 translational, 3 rotational; columns: arm dofs (same layout as the general form)

@@ -4,14 +4,31 @@
 // joint discovery (env_script/mujoco.py:60-88): dofs 0..5 arm, 6..8 fingers, then free bodies.
 #pragma once
 
+// Layout of the default build (jaco2_curtain_torque.xml and everything that fits inside it, e.g. the arm-only jaco2_reaching_torque.xml).
+// A second build of the same sources with -DJNB=12 -DJNV=12 -DJNQ=12 -DJB0=12 -DJB1=12 (libjaco_env_d12.so, __graft_entry__.build) serves
+// jaco2_torque.xml: 6 arm + 6 finger hinges (proximal + sprung distal, xml:109-133) in one kinematic tree, no free bodies.
+#ifndef JNB
 #define JNB 11        // moving (fused) bodies: 6 links, 3 fingers, object, destination pedestal
 #define JNV 21        // dofs
 #define JNQ 23        // generalized positions
+#endif
+#ifndef JB0
+#define JB0 9         // dof blocks of the mass matrix (one per kinematic tree): [0,JB0) arm + fingers, [JB0,JB1) object, [JB1,JNV) pedestal
+#define JB1 15
+#endif
 #define JNU 9         // actuators: 6 motors + 3 finger position servos (xml:341-349)
 #define JNSENS 20     // touch sensors (xml:352-374)
 #define JMAXGEOM 64   // collidable geoms
 #define JMAXPAIR 768  // geom pairs passing the static collision filter
+#ifndef JMAXINNER
 #define JMAXINNER 6   // bodies that have children (link1..link6)
+#endif
+#ifndef JMAXCHAIN
+#define JMAXCHAIN 7   // dofs that move one body: the six arm joints + its own finger joint (a free body's 6)
+#endif
+#ifndef JMAXDESC
+#define JMAXDESC 9    // bodies of one subtree: the arm's links and fingers
+#endif
 #define JMAXMPAIR 128 // structurally non-zero lower-triangle mass-matrix entries (84 for this model)
 #define JNMOCAP 16
 
@@ -65,6 +82,9 @@ struct JacoModelDev {
   // dofs
   int d_body[JNV], d_parent[JNV];
   float d_damping[JNV], d_invweight[JNV];
+  float d_stiffness[JNV], d_springref[JNV];   // joint springs (hinge dofs): qfrc_passive -= stiffness (qpos - springref); jaco2_torque.xml:109-133
+  int d_qadr[JNV];                            // qpos address of a hinge dof (-1: free-joint dof)
+  int has_springs;
   int has_damping;   // 0 none, 1 finger joints only (dofs 6..8: the shared-elimination Euler solve applies), 2 anywhere in block 0
 
   // actuators: force = position ? kp*(clamp(ctrl) - qpos) : ctrl, then clamped (xml:341-349)

@@ -1,8 +1,6 @@
 // Host-side: JACOMDL1 blob (fused view, f_* arrays) -> JacoModelDev + hull vertex table.
 // No HIP dependency so the same loader serves the product library and the CPU-side kernel checks.
 #include "model_blob.h"
-#define JB0 9
-#define JB1 15
 
 #include <cmath>
 #include <cstdint>
@@ -114,20 +112,29 @@ int jaco_model_from_blob(const void* buf, size_t size, JacoModelDev* m, std::vec
     m->d_parent[d] = dpar[d]; m->d_damping[d] = (float)ddamp[d]; m->d_invweight[d] = (float)diw[d];
     if (ddamp[d] > 0) m->has_damping = (d < 6 || m->has_damping == 2) ? 2 : 1;   // 1: only the finger joints (dofs >= 6), see ldl_block0_dual
     if (ddamp[d] > 0 && d >= JB0) FAIL("joint damping outside the arm/finger dof block is not supported by the kernels");
+    m->d_qadr[d] = -1;
+  }
+  {   // joint springs (optional arrays: blobs compiled before round 3 have none)
+    const double *fst = B.has("f_stiffness") ? B.f64("f_stiffness", nb) : nullptr, *fsr = B.has("f_springref") ? B.f64("f_springref", nb) : nullptr;
+    for (int b = 0; b < nb; b++) {
+      if (jt[b] != JJ_HINGE) continue;
+      m->d_qadr[da[b]] = qa[b];
+      if (fst && fsr && fst[b] != 0) { m->d_stiffness[da[b]] = (float)fst[b]; m->d_springref[da[b]] = (float)fsr[b]; m->has_springs = 1; }
+    }
   }
   for (int b = 0; b < nb; b++) {   // the kernels' block-diagonal solves assume this dof layout (one block per kinematic tree)
     int blk = da[b] < JB0 ? 0 : (da[b] < JB1 ? 1 : 2), root = b;
     while (par[root] >= 0) root = par[root];
     int rblk = da[root] < JB0 ? 0 : (da[root] < JB1 ? 1 : 2);
     int n = jt[b] == JJ_FREE ? 6 : 1;
-    if (blk != rblk || (da[b] + n > JB0 && da[b] < JB0) || (da[b] + n > JB1 && da[b] < JB1)) FAIL("dof layout does not match the kernels' blocks [0,9) [9,15) [15,21)");
+    if (blk != rblk || (da[b] + n > JB0 && da[b] < JB0) || (da[b] + n > JB1 && da[b] < JB1)) FAIL("dof layout does not match this build's dof blocks [0,JB0) [JB0,JB1) [JB1,JNV) (jaco/model_dev.h)");
   }
   for (int b = 0; b < nb; b++) {
     unsigned mask = par[b] >= 0 ? m->b_chainmask[par[b]] : 0u;
     int n = jt[b] == JJ_FREE ? 6 : 1;
     for (int k = 0; k < n; k++) mask |= 1u << (da[b] + k);
     m->b_chainmask[b] = mask;
-    if (__builtin_popcount(mask) > 7) FAIL("a body is moved by more than 7 dofs (JMAXCHAIN of physics_kernel.h)");
+    if (__builtin_popcount(mask) > JMAXCHAIN) FAIL("a body is moved by more dofs than JMAXCHAIN (jaco/model_dev.h)");
   }
   // ---- subtree tables for the composite-inertia / mass-matrix stages
   int ninner = 0;
@@ -136,7 +143,7 @@ int jaco_model_from_blob(const void* buf, size_t size, JacoModelDev* m, std::vec
     for (int x = 0; x < nb; x++)
       for (int y = x; y >= 0; y = par[y]) if (y == b) { desc |= 1u << x; break; }
     m->b_descmask[b] = desc;
-    if (__builtin_popcount(desc) > 9) FAIL("a subtree holds more than 9 bodies (JMAXDESC of physics_kernel.h)");
+    if (__builtin_popcount(desc) > JMAXDESC) FAIL("a subtree holds more bodies than JMAXDESC (jaco/model_dev.h)");
     if (desc != (1u << b)) {
       if (ninner >= JMAXINNER) FAIL("too many bodies with children for the kernels' subtree stage");
       m->inner_body[ninner++] = b;

@@ -44,8 +44,6 @@ typedef JacoCaps<512, 128, 512> JacoHuge;    // 8 rows per lane: a reset that pu
 #define JDBG_MAXCON 64
 #define JDBG_MAXEFC 256
 #define JLD (JNV)     // row stride of per-row dof vectors in LDS (21: odd, conflict-free for lane-per-row access)
-#define JB0 9         // dof blocks of the mass matrix: [0,JB0) arm + fingers, [JB0,JB1) object, [JB1,JNV) pedestal
-#define JB1 15
 
 #define JFLAG_CON_OVERFLOW 1u
 #define JFLAG_EFC_OVERFLOW 2u
@@ -219,7 +217,9 @@ struct JacoLDS {
     int q_dof[JNQ + 1];                         // dof that advances position coordinate q linearly (hinge angle, free-body translation), -1: quaternion component
   } mc;
 };
-static_assert(JB1 - JB0 == 6 && JNV - JB1 == 6, "dof blocks");
+static_assert(6 * JMAXINNER <= 64, "subtree force sums: one lane per (inner body, component)");
+static_assert((JB1 - JB0 == 6 || JB1 == JB0) && (JNV - JB1 == 6 || JNV == JB1) && JB0 >= 6 && JNV <= 21 && JNV - JB0 <= 15,
+              "dof blocks: one arm tree of at least the six arm joints, then zero, one or two free bodies");
 
 template <class L>
 JDEV void stage_model(const JacoModelDev* m, L& s, int lane) {
@@ -502,7 +502,6 @@ JDEV void st_frame(float* T, const m3& R, v3 p) {
 // sum of the 6-vectors T[d] over the dofs d of a chain mask.  A body is moved by at most JMAXCHAIN dofs (6 arm joints + its own
 // finger joint; a free body's 6): the loads of all terms are issued together (one LDS round trip) instead of one dependent
 // iteration per set bit.
-#define JMAXCHAIN 7
 JDEV sv chain_sum(const float* T, unsigned mask) {
   sv t[JMAXCHAIN];
   bool on[JMAXCHAIN];
@@ -676,7 +675,6 @@ JDEV void stage_walk(const JacoModelDev* m, L& s, int lane, bool markers, JProfC
 // the subtree (6 components; cacc is dead as an acceleration by now and doubles as the summed force).  Sources and
 // destinations are different arrays, so there is no ordering between lanes.
 // sum of T[stride * x] over the bodies x of a subtree mask (at most JMAXDESC: the arm's links and fingers), loads issued together
-#define JMAXDESC 9
 JDEV float subtree_sum(const float* T, int stride, unsigned mask) {
   float t[JMAXDESC];
   bool on[JMAXDESC];
@@ -694,11 +692,15 @@ JDEV float subtree_sum(const float* T, int stride, unsigned mask) {
 template <class L>
 JDEV void stage_accumulate(const JacoModelDev* m, L& s, int lane) {
   const int ni = m->ninner;
-  if (lane < 10 * ni) {
-    const int a = s.mc.inner_body[lane / 10], c = lane % 10;
-    s.crb[a][c] = subtree_sum(&s.cinert[0][0] + c, 10, s.mc.b_descmask[a]);
+#pragma unroll
+  for (int base = 0; base < 10 * JMAXINNER; base += 64) {   // (one pass for the default layout: 6 inner bodies x 10 components)
+    const int i = base + lane;
+    if (i < 10 * ni) {
+      const int a = s.mc.inner_body[i / 10], c = i % 10;
+      s.crb[a][c] = subtree_sum(&s.cinert[0][0] + c, 10, s.mc.b_descmask[a]);
+    }
   }
-  if (lane < 6 * ni) {
+  if (lane < 6 * ni) {   // (6 x JMAXINNER <= 64 in every layout)
     const int a = s.mc.inner_body[lane / 6], c = lane % 6;
     s.cacc[a][c] = subtree_sum(&s.cfrc[0][0] + c, 6, s.mc.b_descmask[a]);
   }
@@ -710,6 +712,7 @@ struct StagePrefetch {
   int codes[JMAXPAIR / 64];   // stage C, phase 1: this lane's pair of every 64-pair chunk
   int mp0, mp1;               // stage M: this lane's mass-matrix entries
   float damping;              // joint damping of dof `lane`
+  float stiffness, springref; int sqadr;   // joint spring of dof `lane` (models that have any)
   int limited; float lo, hi;  // joint limit of body `lane`
 };
 JDEV StagePrefetch stage_prefetch(const JacoModelDev* m, int lane) {
@@ -718,6 +721,8 @@ JDEV StagePrefetch stage_prefetch(const JacoModelDev* m, int lane) {
   for (int ch = 0; ch < JMAXPAIR / 64; ch++) P.codes[ch] = m->pair_code[ch * 64 + lane];   // (zero-padded to JMAXPAIR: straight-line loads)
   P.mp0 = m->mpair[lane]; P.mp1 = m->mpair[64 + lane];                                     // (zero-padded to JMAXMPAIR)
   P.damping = m->d_damping[lane < JNV ? lane : 0];
+  P.stiffness = 0.f; P.springref = 0.f; P.sqadr = 0;
+  if (m->has_springs) { P.stiffness = m->d_stiffness[lane < JNV ? lane : 0]; P.springref = m->d_springref[lane < JNV ? lane : 0]; P.sqadr = m->d_qadr[lane < JNV ? lane : 0]; }
   const int b = lane < JNB ? lane : 0;
   P.limited = m->b_limited[b]; P.lo = m->b_range[b][0]; P.hi = m->b_range[b][1];
   return P;
@@ -736,7 +741,9 @@ JDEV void stage_mass_bias(const JacoModelDev* m, L& s, int lane, const StagePref
     stsv(Fd + 6 * d, inert_mul(s.crb[b], S));
     float bias = dot(S, ldsv(s.cacc[b]));
     s.bias[d] = bias;
-    s.smooth[d] = -pf.damping * s.qvel[d] - bias;
+    float passive = -pf.damping * s.qvel[d];
+    if (m->has_springs && pf.sqadr >= 0) passive -= pf.stiffness * (s.qpos[pf.sqadr] - pf.springref);   // (wave-uniform test: one model per launch)
+    s.smooth[d] = passive - bias;
   }
   wave_sync();
 #pragma unroll

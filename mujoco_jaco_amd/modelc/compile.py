@@ -149,6 +149,7 @@ def fuse(M, names, pairs):
     F = {}
     fparent, fpos, fquat, faxis, fjpos, fq0, fmass, fcom, finert = [], [], [], [], [], [], [], [], []
     flim, frange, fdamp, ftype, fqadr, fdadr = [], [], [], [], [], []
+    fstiff, fsref = [], []
     for r in roots:
         members = [b for b in range(1, nbody) if weld[b] == r]
         mass = sum(M["body_mass"][b] for b in members)
@@ -187,6 +188,7 @@ def fuse(M, names, pairs):
         flim.append(M["jnt_limited"][j])
         frange.append(M["jnt_range"].reshape(-1, 2)[j])
         fdamp.append(M["dof_damping"][M["jnt_dofadr"][j]])
+        fstiff.append(M["jnt_stiffness"][j]); fsref.append(M["jnt_springref"][j])
         fmass.append(mass)
         fcom.append(com)
         finert.append([I[0, 0], I[1, 1], I[2, 2], I[0, 1], I[0, 2], I[1, 2]])
@@ -198,6 +200,7 @@ def fuse(M, names, pairs):
     F["f_pos"], F["f_quat"], F["f_axis"], F["f_jpos"] = f64(fpos), f64(fquat), f64(faxis), f64(fjpos)
     F["f_qpos0"], F["f_mass"], F["f_com"], F["f_inertia"] = f64(fq0), f64(fmass), f64(fcom), f64(finert)
     F["f_limited"], F["f_range"], F["f_damping"] = i32(flim), f64(frange), f64(fdamp)
+    F["f_stiffness"], F["f_springref"] = f64(fstiff), f64(fsref)
 
     # ---- geoms that can collide with anything (appear in the pair list), re-indexed
     used = sorted(set(pairs.reshape(-1).tolist()))
@@ -314,7 +317,8 @@ def compile_model(xml_name, timestep=0.001):
 
 def main():
     os.makedirs(OUT_DIR, exist_ok=True)
-    for xml_name in ("jaco2_curtain_torque", "jaco2_reaching_torque"):
+    # jaco2_torque: 6 arm + 6 finger hinges (sprung distal joints), no free bodies -- stepped by the d12 build of the library
+    for xml_name in ("jaco2_curtain_torque", "jaco2_reaching_torque", "jaco2_torque"):
         M, names = compile_model(xml_name)
         path = os.path.join(OUT_DIR, xml_name + ".jacomdl")
         blob.save(path, M)

@@ -75,10 +75,31 @@ class _Body:
     pass
 
 
+def _expand_includes(el, xml_dir, depth=0):
+    """<include file="..."/>: MuJoCo splices the children of the included file's root element in at that position (the dual-arm
+    model pulls its two arms in this way, jaco2_dual_torque.xml:48-49)."""
+    if depth > 8:
+        raise ValueError("include nesting too deep")
+    i = 0
+    while i < len(el):
+        ch = el[i]
+        if ch.tag == "include":
+            inc = ElementTree.parse(os.path.join(xml_dir, ch.get("file"))).getroot()
+            _expand_includes(inc, xml_dir, depth + 1)
+            el.remove(ch)
+            for k, sub in enumerate(list(inc)):
+                el.insert(i + k, sub)
+            i += len(inc)
+        else:
+            _expand_includes(ch, xml_dir, depth)
+            i += 1
+
+
 def parse(xml_path, timestep=None):
     """Parse one MJCF file into a dict of numpy arrays + name lists."""
     root = ElementTree.parse(xml_path).getroot()
     xml_dir = os.path.dirname(xml_path)
+    _expand_includes(root, xml_dir)
     comp = root.find("compiler")
     meshdir = comp.get("meshdir", "") if comp is not None else ""
     assert comp is None or comp.get("angle", "degree") == "radian"
@@ -180,6 +201,8 @@ def parse(xml_path, timestep=None):
                 j["limited"] = ch.get("limited", "false") == "true"
                 j["range"] = _floats(ch.get("range"), default=(0, 0))
                 j["damping"] = float(ch.get("damping", 0.0))
+                j["stiffness"] = float(ch.get("stiffness", 0.0))      # joint spring (jaco2_torque.xml:109-133: the distal finger joints)
+                j["springref"] = float(ch.get("springref", 0.0))
                 j["solref"] = _floats(ch.get("solreflimit"), 2, DEFAULTS["solref"])
                 j["solimp"] = _floats(ch.get("solimplimit"), 5, DEFAULTS["solimp"])
                 b.joints.append(len(joints))
@@ -318,6 +341,9 @@ def parse(xml_path, timestep=None):
         "qpos0": f64(qpos0),
         "dof_bodyid": i32(dof_bodyid), "dof_jntid": i32(dof_jntid), "dof_parentid": i32(dof_parentid),
         "dof_damping": f64(dof_damping),
+        # joint springs: qfrc_passive -= stiffness * (qpos - springref) on hinge joints (free joints carry none in these models)
+        "jnt_stiffness": f64([j["stiffness"] if j["type"] == JNT_HINGE else 0.0 for j in joints]),
+        "jnt_springref": f64([j["springref"] if j["type"] == JNT_HINGE else 0.0 for j in joints]),
         "geom_type": i32([g["type"] for g in geoms]), "geom_bodyid": i32([g["body"] for g in geoms]),
         "geom_dataid": i32([g["dataid"] for g in geoms]), "geom_contype": i32([g["contype"] for g in geoms]),
         "geom_conaffinity": i32([g["conaffinity"] for g in geoms]), "geom_condim": i32([g["condim"] for g in geoms]),

@@ -20,9 +20,9 @@ class BatchedMujoco:
     def __init__(self, num_envs, robot_file="jaco2_curtain_torque", device=0, frame_skip=50, task=0, seed=0):
         if not torch.cuda.is_available():
             raise JacoError("BatchedMujoco needs a HIP device (no CPU path exists)")
-        self.L = _lib.load()
         self.device = torch.device("cuda", device)
         self._blob = open(_lib.model_path(robot_file), "rb").read()
+        self.L = _lib.load(_lib.variant_for(self._blob))
         self._blob_buf = ctypes.create_string_buffer(self._blob, len(self._blob))
         cfg = _lib.JacoConfig(ctypes.cast(self._blob_buf, ctypes.c_void_p), len(self._blob), int(num_envs), int(device),
                               int(frame_skip), int(task), int(seed))

@@ -32,6 +32,7 @@ struct OrcModel {
   double *body_pos, *body_quat, *body_ipos, *body_inertia, *body_mass, *body_invweight0;
   int *jnt_type, *jnt_bodyid, *jnt_qposadr, *jnt_dofadr, *jnt_limited;
   double *jnt_pos, *jnt_axis, *jnt_range, *jnt_solref, *jnt_solimp, *qpos0;
+  double *jnt_stiffness, *jnt_springref;   /* optional (NULL in blobs compiled before round 3): joint springs of the sibling MJCFs */
   int *dof_bodyid, *dof_jntid, *dof_parentid;
   double *dof_damping, *dof_invweight0;
   int *geom_type, *geom_bodyid, *geom_dataid, *geom_contype, *geom_conaffinity, *geom_condim;
@@ -155,6 +156,7 @@ OrcModel* orc_load_model(const char* path) {
       {"jnt_qposadr", &m->jnt_qposadr, 1}, {"jnt_dofadr", &m->jnt_dofadr, 1}, {"jnt_limited", &m->jnt_limited, 1},
       {"jnt_pos", &m->jnt_pos, 0}, {"jnt_axis", &m->jnt_axis, 0}, {"jnt_range", &m->jnt_range, 0},
       {"jnt_solref", &m->jnt_solref, 0}, {"jnt_solimp", &m->jnt_solimp, 0}, {"qpos0", &m->qpos0, 0},
+      {"jnt_stiffness", &m->jnt_stiffness, 0}, {"jnt_springref", &m->jnt_springref, 0},
       {"dof_bodyid", &m->dof_bodyid, 1}, {"dof_jntid", &m->dof_jntid, 1}, {"dof_parentid", &m->dof_parentid, 1},
       {"dof_damping", &m->dof_damping, 0}, {"dof_invweight0", &m->dof_invweight0, 0},
       {"geom_type", &m->geom_type, 1}, {"geom_bodyid", &m->geom_bodyid, 1}, {"geom_dataid", &m->geom_dataid, 1},
@@ -518,6 +520,10 @@ void orc_jac_body_com(const OrcModel* m, const OrcData* d, int body, double* jac
 /* 6b. passive + actuation (motor clamp; position servo kp*(ctrl - q), ctrl- and force-clamped) */
 static void passive_actuation(const OrcModel* m, OrcData* d) {
   for (int i = 0; i < m->nv; i++) { d->qfrc_passive[i] = -m->dof_damping[i] * d->qvel[i]; d->qfrc_actuator[i] = 0; }
+  if (m->jnt_stiffness) /* joint springs [EXT mj_passive]: -stiffness (qpos - qpos_spring), hinge joints (jaco2_torque.xml:109-133) */
+    for (int j = 0; j < m->njnt; j++)
+      if (m->jnt_type[j] == J_HINGE && m->jnt_stiffness[j] != 0)
+        d->qfrc_passive[m->jnt_dofadr[j]] -= m->jnt_stiffness[j] * (d->qpos[m->jnt_qposadr[j]] - m->jnt_springref[j]);
   for (int a = 0; a < m->nu; a++) {
     int j = m->actuator_jntid[a];
     double c = d->ctrl[a];

@@ -16,31 +16,31 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 EMU_DIR = os.path.join(ROOT, "tests", "emu")
 ASSETS = os.path.join(ROOT, "mujoco_jaco_amd", "assets")
-_lib = None
+_libs = {}
 
 
-def lib():
-    global _lib
-    if _lib is None:
+def lib(layout=""):
+    """layout "": the default build (11 bodies / 21 dofs in blocks 9 + 6 + 6); "_d12": the build for jaco2_torque.xml (12 hinge dofs, one tree)."""
+    if layout not in _libs:
         subprocess.check_call(["make", "-s", "-C", EMU_DIR])
-        L = ctypes.CDLL(os.path.join(EMU_DIR, "libjaco_emu.so"))
+        L = ctypes.CDLL(os.path.join(EMU_DIR, "libjaco_emu%s.so" % layout))
         fp, ip, up = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint)
         L.emu_physics_step.argtypes = [ctypes.c_char_p, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int, fp, fp, fp, fp, fp, up, ip, fp, ctypes.c_int, ip]
         L.emu_env_call.argtypes = [ctypes.c_char_p, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_ulonglong,
                                    fp, fp, fp, fp, up, ip, fp, fp, fp, fp, fp, fp, ctypes.POINTER(ctypes.c_ubyte), fp, ip]
         L.emu_marker_rest.argtypes = [ctypes.c_char_p, ctypes.c_long, fp]
-        _lib = L
-    return _lib
+        _libs[layout] = L
+    return _libs[layout]
 
 
 class EmuEnv:
     """Batched env state (fp32, [nenv][n]) stepped by the emulated kernel."""
 
     def __init__(self, model="jaco2_curtain_torque", nenv=1):
-        self.L = lib()
         self.blob = open(os.path.join(ASSETS, model + ".jacomdl"), "rb").read()
         from mujoco_jaco_amd.modelc import blob as blobmod
         M = blobmod.loads(self.blob)
+        self.L = lib("" if (int(M["f_nbody"][0]) <= 11 and int(M["nv"][0]) != 12) else "_d12")
         self.M = M
         self.nq, self.nv, self.nu, self.ns = int(M["nq"][0]), int(M["nv"][0]), int(M["nu"][0]), int(M["nsensor"][0])
         self.nenv = nenv

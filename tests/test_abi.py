@@ -23,6 +23,9 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, n), "libjaco_env.so does not export %s" % n
     assert sorted(_lib.SYMBOLS) == names, "ctypes table and header disagree"
     _lib.load()
+    _lib.load("_d12")          # the build for the layout of jaco2_torque.xml exports the same ABI
+    assert _lib.variant_for(open(_lib.model_path("jaco2_torque"), "rb").read()) == "_d12"
+    assert _lib.variant_for(open(_lib.model_path("jaco2_curtain_torque"), "rb").read()) == "" and _lib.variant_for(open(_lib.model_path("jaco2_reaching_torque"), "rb").read()) == ""
 
 
 def test_header_cites_reference_call_sites():

@@ -256,3 +256,33 @@ def test_touch_sensors_in_grasp(model_arrays, names):
         nclass += int(touch_class(s[0]) == touch_class(so))
     print('touch: sensordata within 2 %% in %d of 30 frames, class equal in %d' % (nmatch, nclass))
     assert nmatch == 30 and nclass == 30   # measured 30 / 30 since round 2
+
+
+def test_jaco2_torque_sibling_model_on_the_d12_build():
+    """jaco2_torque.xml (12 hinge dofs in one tree, sprung + damped distal finger joints, xml:109-133) stepped by
+    libjaco_env_d12.so -- the same sources compiled for that layout -- against the fp64 oracle: 256 envs, 100 substeps of random motor
+    torques and finger commands, some fingers starting beyond their joint limits."""
+    from mujoco_jaco_amd import _lib
+    from mujoco_jaco_amd.modelc import blob
+    from oracle_binding import Oracle
+    M = blob.load(_lib.model_path("jaco2_torque"))
+    B, nsub = 256, 100
+    rng = np.random.default_rng(77)
+    q = np.tile(M["qpos0"], (B, 1))
+    q[:, :6] = rng.uniform([0.7, 3.8, 1.0, 1.8, 1.0, 0.8], [2.5, 4.0, 1.7, 2.5, 2.5, 2.3], (B, 6))
+    q[:, 6:12:2] = rng.uniform(0.0, 1.15, (B, 3)); q[:, 7:12:2] = rng.uniform(-0.45, 0.45, (B, 3))
+    q = q.astype(np.float32).astype(np.float64)
+    c = np.concatenate([rng.uniform(-1, 1, (B, 6)) * np.array([30, 30, 30, 15, 15, 15]) * 0.2, rng.uniform(0, 1.2, (B, 3))], 1).astype(np.float32).astype(np.float64)
+    env = _env(B, "jaco2_torque")
+    assert (env.nq, env.nv, env.nu) == (12, 12, 9)
+    env.set_state(_t(q, env.device), None, None)
+    env.send_forces(_t(c, env.device), nsub=nsub)
+    gq, gv, _ = [t.cpu().numpy().astype(np.float64) for t in env.get_state()]
+    o = Oracle("jaco2_torque")
+    qo, vo, wo = q.copy(), np.zeros((B, 12)), np.zeros((B, 12))
+    st = np.zeros((B, 4), np.int32)
+    o.step_batch(qo, vo, wo, np.ascontiguousarray(c), nsub=nsub, nthreads=16, stats=st)
+    eq, ev = np.abs(gq - qo).max(1), np.abs(gv - vo).max(1)
+    print("jaco2_torque, %d substeps: qpos err median %.2e max %.2e, qvel err max %.2e; oracle max rows %d, max contacts %d" % (nsub, np.median(eq), eq.max(), ev.max(), st[:, 1].max(), st[:, 0].max()))
+    assert (env.flags().cpu().numpy() & 15).max() == 0 and st[:, 1].max() >= 1
+    assert np.median(eq) < 1e-6 and eq.max() < 1e-4

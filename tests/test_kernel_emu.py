@@ -107,3 +107,28 @@ def test_huge_tier_keeps_every_row_of_a_hand_in_pedestal_reset(model_arrays):
         seen = max(seen, o.nefc)
         assert np.abs(e.qpos[0] - o.get("qpos")).max() < 1e-5
     assert seen > 256 and (e.flags[0] & 7) == 0
+
+
+def test_jaco2_torque_model_on_the_d12_build_matches_oracle():
+    """Sibling MJCF jaco2_torque.xml: 6 arm + 6 finger hinges in one tree, the distal finger joints sprung and damped
+    (xml:109-133), no free bodies.  The same kernel sources built for that layout (-DJNB=12 -DJNV=12 ..., jaco/model_dev.h) against
+    the fp64 oracle: free motion under motor torques with the fingers driven into their joint limits (limit rows)."""
+    from emu_binding import EmuEnv
+    from oracle_binding import Oracle
+    e = EmuEnv("jaco2_torque", 1)
+    o = Oracle("jaco2_torque")
+    assert (e.nq, e.nv, e.nu) == (12, 12, 9)
+    q = e.M["qpos0"].copy(); q[:6] = [1.2, 3.9, 1.3, 2.0, 1.5, 1.0]; q[6:12] = [1.15, -0.45, 0.8, 0.1, 1.0, 0.43]       # thumb proximal / distal and pinky distal start beyond their limits (1.1, -0.4, 0.4)
+    q = q.astype(np.float32).astype(np.float64)
+    c = np.array([3., -5., 2., 1., -1., 0.5, 0.0, 0.0, 0.0])
+    e.qpos[0] = q
+    o.set("qpos", q); o.set("qvel", np.zeros(12)); o.set("qacc_warmstart", np.zeros(12))
+    rows = 0
+    for k in range(6):
+        e.step(c, nsub=25)
+        o.step(c, n=25)
+        assert (e.stats[0, 0], e.stats[0, 1]) == (o.ncon, o.nefc) and not (e.flags[0] & 31)
+        rows = max(rows, o.nefc)
+        assert np.abs(e.qpos[0] - o.get("qpos")).max() < 2e-6 and np.abs(e.qvel[0] - o.get("qvel")).max() < 2e-4, k
+    assert rows >= 1                                                # the scenario really exercised limit rows
+    assert np.abs(o.get("qfrc_passive")[6:]).max() > 0.005           # ... and the springs / dampers are at work at the end
