@@ -61,6 +61,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-reset", action="store_true", help="finished envs stay frozen (BASELINE config 4: termination masking, no auto-reset)")
     ap.add_argument("--no-contact", action="store_true", help="contacts disabled (BASELINE config 2: arm-only model)")
     ap.add_argument("--config-legs", default="2,4", help="BASELINE configs also timed (briefly, each in a child process before the headline run); '' = none")
+    ap.add_argument("--set-option", action="append", default=[], help="name=value passed to jaco_set_option (e.g. compensated=0); repeatable")
     ap.add_argument("--dry-gather", action="store_true",
                     help="CPU rehearsal of the N > 1 plumbing (spawn, rendezvous, gather, max-over-ranks timing) on gloo: no GPU, no physics")
     return ap.parse_args(argv)
@@ -408,6 +409,10 @@ def main():
             if world > 1:
                 qpos, _, _ = env.state_views()
                 dist.all_gather_into_tensor(gathered, qpos)
+
+    for kv in args.set_option:
+        name, val = kv.split("=")
+        env.set_option(name, float(val))
 
     def timed(nsteps):
         if world > 1:

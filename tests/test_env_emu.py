@@ -336,3 +336,19 @@ def test_kernel_terminal_inspection_picking_placing_against_the_references_own_o
             rd, rb, rwb, rs = G[key][k]
             assert bool(e.done[0]) == bool(rd) and e.task[0, 29] == rs, (task_id, k)
             assert abs(e.reward[0] - rb) < 2e-4 and abs(e.task[0, 30] - rwb) < 1e-5
+
+
+def test_terminal_inspection_on_a_finished_env_is_frozen(names, model_arrays):
+    """jaco_terminal_inspection on its own (mode 5) freezes like jaco_step: a finished -- or NaN-quarantined -- env keeps done = 1,
+    bonus 0 and its counters (it used to count another step and recompute done, un-quarantining an env with NaN poses)."""
+    e, _ = _pair(names, model_arrays, 5, 1)
+    e.forward()
+    e.task[0, 1] = 699                                                   # one terminal_inspection away from the time-out
+    e._call(5)
+    assert e.done[0] == 1 and abs(e.reward[0] + 10.0) < 1e-6 and e.task[0, 3] == 1 and e.task[0, 1] == 700
+    steps, episodes = e.task[0, 1], e.task[0, 2]
+    e._call(5)                                                           # again: frozen
+    assert e.done[0] == 1 and e.reward[0] == 0 and e.task[0, 1] == steps and e.task[0, 2] == episodes and e.task[0, 3] == 1
+    e.cache[0, 78:93] = np.nan                                           # quarantined env: poses non-finite
+    e._call(5)
+    assert e.done[0] == 1 and e.reward[0] == 0 and e.task[0, 3] == 1

@@ -285,4 +285,4 @@ def test_jaco2_torque_sibling_model_on_the_d12_build():
     eq, ev = np.abs(gq - qo).max(1), np.abs(gv - vo).max(1)
     print("jaco2_torque, %d substeps: qpos err median %.2e max %.2e, qvel err max %.2e; oracle max rows %d, max contacts %d" % (nsub, np.median(eq), eq.max(), ev.max(), st[:, 1].max(), st[:, 0].max()))
     assert (env.flags().cpu().numpy() & 15).max() == 0 and st[:, 1].max() >= 1
-    assert np.median(eq) < 1e-6 and eq.max() < 1e-4
+    assert np.median(eq) < 4e-7 and eq.max() < 1.2e-5 and ev.max() < 2e-4   # 3x measured (1.2e-7 / 4.0e-6 / 5.8e-5; up to 11 limit rows, 1 contact)
