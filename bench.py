@@ -225,7 +225,11 @@ def cpu_baseline_and_drift(model, frame_skip, gpu_npz):
         done = mk
         ref[mk] = q.copy()
     dt = time.time() - t
+    # ... and one env on one core (plan item 2: single-thread and all-cores)
+    q1, v1, w1 = np.ascontiguousarray(q0[:1].copy()), np.zeros((1, o.nv)), np.zeros((1, o.nv))
+    t1 = time.time(); o.step_batch(q1, v1, w1, c[:1], nsub=2000, nthreads=1); dt1 = time.time() - t1
     base = {"value": nenv * done / dt / frame_skip, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "single_thread_env_steps_per_s": 2000 / dt1 / frame_skip,
             "sample": "%d envs x %d physics substeps of the same workload (picking reset distribution, constant random torques; the controller / observation glue is not timed), fp64 C oracle, OpenMP over %d threads, %.1f s; frame_skip %d"
                       % (nenv, done, cores, dt, frame_skip)}
     if gpu_npz is None or not os.path.exists(gpu_npz):

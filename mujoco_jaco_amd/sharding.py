@@ -58,11 +58,17 @@ class ObsGather:
             cur.wait_event(self._done)          # the previous gather has read the staging buffer (it finished a whole step ago)
         self.stage.copy_(local_obs)
         self._ready.record(cur)
-        with torch.cuda.stream(self.side):
-            self.side.wait_event(self._ready)
-            dist.all_gather_into_tensor(self.out, self.stage, group=self.group)
-            self._done = torch.cuda.Event()
-            self._done.record(self.side)
+        try:
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(self._ready)
+                dist.all_gather_into_tensor(self.out, self.stage, group=self.group)
+                self._done = torch.cuda.Event()
+                self._done.record(self.side)
+        except RuntimeError as e:   # a backend that cannot issue the collective from a side stream: same collective, caller's stream, said out loud
+            import sys
+            print("ObsGather: overlapped gather unavailable (%s); using the blocking form" % (str(e).splitlines()[0],), file=sys.stderr)
+            self._overlap, self._done = False, None
+            self(local_obs)
 
     def wait(self):
         if self._overlap and self._done is not None:

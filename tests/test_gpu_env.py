@@ -586,3 +586,48 @@ def test_pickandplace_episode_flow(names):
     t[:, 1] = 1198; env.set_task_state(t)
     _, _, d, _ = env.step(torch.zeros(8, 7)); assert not d.any()
     _, r, d, _ = env.step(torch.zeros(8, 7)); assert d.all() and (r == -10).all()
+
+
+def test_config1_single_env_1000_random_action_steps(model_arrays, names):
+    """BASELINE config 1 at its stated length: ONE env through the drop-in surface (the reference's unbatched types), 1 000 steps of
+    U(-1, 1)^7 actions from numpy.random.default_rng(0), task picking, frame_skip 50, with the caller pattern of
+    main.py:254-260 (reset when done).  The first 40 steps (2 000 substeps) are replayed on the fp64 oracle env from the same reset
+    state with the same injected noise; the rest checks the episode bookkeeping and that nothing goes non-finite or gets flagged."""
+    from mujoco_jaco_amd.env import JacoBatchedEnv
+    from oracle_env import OracleEnv
+    env = JacoBatchedEnv(task="picking", robot_file="jaco2_curtain_torque", n_robots=1, seed=11)
+    rng = np.random.default_rng(0)
+    nz0 = np.full((1, 12), 0.5, np.float32)
+    env.set_noise(torch.tensor(nz0))
+    obs = env.reset()
+    q0 = env.sim.get_state()[0].cpu().numpy()[0].astype(np.float64)
+    t0 = env.task_state().cpu().numpy()[0]
+    oe = OracleEnv(names)
+    oe.obj_goal, oe.dest_goal = t0[4:7].astype(np.float64), t0[7:10].astype(np.float64)
+    # (the reset state as the env holds it: fp32 draws; the model's own constants -- finger angles 1.1, pedestal height -- exact for the oracle)
+    qo = model_arrays["qpos0"].copy(); qo[:6] = q0[:6]; qo[9:12] = q0[9:12]; qo[16:18] = q0[16:18]
+    oe.set_state(qo)
+    assert np.abs(obs - oe.observe(nz0[0, 6:].astype(np.float64))[0]).max() < 2e-6
+    errs, episodes, steps_in_episode, returns = [], 0, 0, 0.0
+    replay = True
+    for s in range(1000):
+        a = rng.uniform(-1, 1, 7).astype(np.float32)
+        nz = rng.uniform(size=(1, 12)).astype(np.float32)
+        env.set_noise(torch.tensor(nz))
+        obs, reward, done, info = env.step(a)
+        assert isinstance(reward, float) and isinstance(done, bool) and info == {0: 0} and obs.shape == (26,) and np.isfinite(obs).all()
+        steps_in_episode += 1; returns += reward
+        if replay and s < 40:
+            oo, orew, odone, _ = oe.step(a.astype(np.float64), nz[0].astype(np.float64))
+            assert done == odone and obs[0] == oo[0]
+            errs.append(np.abs(obs - oo).max())
+            assert abs(reward - orew) < 1e-4
+        if done:
+            replay = False
+            assert steps_in_episode <= 700
+            episodes += 1; steps_in_episode = 0
+            env.set_noise(torch.tensor(nz0))
+            obs = env.reset()
+    fl = int(env.sim.flags().cpu().numpy()[0])
+    print("config 1: 1 000 steps, %d episodes finished, first %d steps vs the oracle env: obs err median %.2e max %.2e; flags 0x%x" % (episodes, len(errs), np.median(errs), max(errs), fl))
+    assert fl & 15 == 0 and len(errs) >= 20 and max(errs) < 2e-6   # (measured 6.6e-7 over 40 steps = 2 000 substeps)

@@ -201,3 +201,30 @@ def test_static_pair_pruning_is_exact(model_arrays, tmp_path):
             assert a.ncon == b.ncon and np.array_equal(a.get("contact")[:], b.get("contact")[:])
     finally:
         os.remove(path)
+
+
+def test_config1_oracle_env_1000_random_action_steps(names, model_arrays):
+    """BASELINE config 1 on the CPU side: the reference's mujoco_py step is not runnable here, so the plumbing case runs on the
+    fp64 restatement: ONE env, 1 000 steps of U(-1, 1)^7 actions from numpy.random.default_rng(0), task picking, frame_skip 50
+    (50 000 physics substeps with the controller in the loop)."""
+    from mujoco_jaco_amd import workload
+    from oracle_env import OracleEnv
+    rng = np.random.default_rng(0)
+    q0 = workload.reset_states(model_arrays["qpos0"], 1, seed=123)[0]
+    oe = OracleEnv(names)
+    oe.obj_goal = q0[9:12].copy(); oe.dest_goal = np.array([q0[16], q0[17], 0.3468])
+    oe.set_state(q0)
+    episodes, rets, ret = 0, [], 0.0
+    for s in range(1000):
+        a = rng.uniform(-1, 1, 7)
+        obs, rew, done, succ = oe.step(a, rng.uniform(size=12))
+        ret += rew
+        assert np.isfinite(obs).all() and np.isfinite(rew) and obs.shape == (26,) and obs.dtype == np.float32
+        if done:
+            episodes += 1; rets.append(ret); ret = 0.0
+            oe = OracleEnv(names)
+            oe.obj_goal = q0[9:12].copy(); oe.dest_goal = np.array([q0[16], q0[17], 0.3468])
+            oe.set_state(q0)
+    q = oe.o.get("qpos")
+    assert np.isfinite(q).all() and abs(np.linalg.norm(q[12:16]) - 1) < 1e-9 and abs(np.linalg.norm(q[19:23]) - 1) < 1e-9
+    assert episodes >= 1          # random actions on the arm end an episode now and then (singular guard, dropped object, time-out)
