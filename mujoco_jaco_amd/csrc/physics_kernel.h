@@ -1502,6 +1502,35 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
     wave_sync();
     stage_integrate_pos(m, s, lane);
     wave_sync();
+    // Sensitivity probes (diagnostic builds only, tools/build_variant.sh; profiles/r03_ab_probe.txt): what paces the kernel?
+    // +640 independent fma per substep (+10 % VALU) cost +3.7 %; 12 extra dependent LDS round trips per substep cost +0.6 %.
+#ifdef JACO_PROBE_VALU
+    {
+      float pa[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) pa[k] = s.qvel[(lane + k) & 15];
+      for (int i = 0; i < JACO_PROBE_VALU / 8; i++) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) pa[k] = fmaf(pa[k], 1.0000001f, 1e-30f);
+      }
+      float pr = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; k++) pr += pa[k];
+      if (pr == 123.456f) s.smooth[40] = pr;   // (never true: keeps the chains alive)
+    }
+#endif
+#ifdef JACO_PROBE_LDS
+    {
+      float pv = s.qvel[lane & 15];
+      for (int i = 0; i < JACO_PROBE_LDS; i++) {
+        s.smooth[48 + (lane & 15)] = pv;
+        wave_sync();
+        pv = s.smooth[48 + ((lane + 1) & 15)] + 1e-30f;
+        wave_sync();
+      }
+      if (pv == 123.456f) s.smooth[40] = pv;
+    }
+#endif
     if (emode == 3) {   // set_obj_xyz (mujoco.py:217-227): object back to the pinned pose, all free-body velocities zeroed
       if (lane >= 9 && lane < 16) { s.qpos[lane] = pinv; s.qpos_lo[lane] = 0.f; }
       if (lane >= 9 && lane < nv) { s.qvel[lane] = 0.f; s.qvel_lo[lane] = 0.f; }
