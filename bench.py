@@ -11,8 +11,9 @@ Workload: 65 536 environments per GPU, full Jac
 contacts, the reference's `picking` reset distribution, inputs resident in HBM.
 Default `--level env`: one "step" = one JacoMujocoEnv.step (env_mujoco.py:116-139) for every env of the batch: a fresh
 random action U(-1,1)^7 x --action-scale -> _take_action, `--frame-skip` (default 50 = the reference, env_mujoco.py:24)
-substeps of operational-space control + physics, observation, reward, termination (jaco_step), then a masked jaco_reset
-of the envs that finished -- inside the timed region, no host synchronisation.  The batch is first rolled `--preroll`
+substeps of operational-space control + physics, observation, reward, termination (jaco_step), and the reset of the envs that
+finished -- inside the timed region, no host synchronisation: by default inside jaco_step itself (option auto_reset: the wave that
+finished an episode does sim.reset(), the draws and sim.forward()), with --explicit-reset as a masked jaco_reset launch chain.  The batch is first rolled `--preroll`
 untimed steps (with the same masked resets, episode ages staggered over [0, 700)) so the timed window sees a rollout in
 progress, not the 25 steps after a global reset.  `--level ctrl` times the ctrl-level entry jaco_physics_step (random motor
 torques, `--frame-skip` substeps per step, default 1) used for oracle parity.
@@ -59,6 +60,7 @@ def parse_args(argv=None):
     ap.add_argument("--drift-gpu-leg", default=None, help=argparse.SUPPRESS)   # internal: child process that steps the HIP path on the drift workload
     ap.add_argument("--env-drift-gpu-leg", default=None, help=argparse.SUPPRESS)   # internal: child process, HIP leg of the env-level closed-loop drift
     ap.add_argument("--no-reset", action="store_true", help="finished envs stay frozen (BASELINE config 4: termination masking, no auto-reset)")
+    ap.add_argument("--explicit-reset", action="store_true", help="reset finished envs with a masked jaco_reset launch chain after every step instead of inside jaco_step (option auto_reset)")
     ap.add_argument("--no-contact", action="store_true", help="contacts disabled (BASELINE config 2: arm-only model)")
     ap.add_argument("--config-legs", default="2,4", help="BASELINE configs also timed (briefly, each in a child process before the headline run); '' = none")
     ap.add_argument("--set-option", action="append", default=[], help="name=value passed to jaco_set_option (e.g. compensated=0); repeatable")
@@ -365,7 +367,8 @@ def main():
     if args.level == "env":
         from mujoco_jaco_amd.env import JacoBatchedEnv
         from mujoco_jaco_amd.sharding import ObsGather, env_seed
-        genv = JacoBatchedEnv(num_envs=B, device=local_rank, frame_skip=fs, seed=env_seed(1000, rank), task=args.task, robot_file=args.model)
+        genv = JacoBatchedEnv(num_envs=B, device=local_rank, frame_skip=fs, seed=env_seed(1000, rank), task=args.task, robot_file=args.model,
+                              auto_reset=not (args.explicit_reset or args.no_reset))
         env = genv.sim
         if args.hints is not None:
             env.set_option("hints", args.hints)
@@ -394,8 +397,9 @@ def main():
                 a = (torch.rand(B, nact, device=dev, generator=gen) * 2 - 1) * scale[0]
             o, r, d, _ = genv.step(a)
             done_count.add_(d.sum())
-            if not args.no_reset:
+            if not args.no_reset and not genv.auto_reset:
                 o = genv.reset(d)  # masked jaco_reset of the finished envs: no host sync; their obs rows become the new episode's first
+            # (default: option auto_reset -- the same reset, done inside jaco_step by the wave that finished the episode)
             cur_obs[0] = o
             if world > 1:          # one collective per rollout step: concatenate the observation rows of all shards (issued on a
                 gather.start(o)    # side stream: it overlaps the next step's launch set; the timed region ends on a full device sync)
@@ -495,6 +499,7 @@ def main():
                        "collective": ({"backend": dist.get_backend(), "world_size": dist.get_world_size(), "rank0_device": torch.cuda.get_device_name(local_rank),
                                        "devices_visible": torch.cuda.device_count(), "overlapped_on_side_stream": args.level == "env"} if world > 1 else None),
                        "mean_contacts": float(stats[0]), "mean_rows": float(stats[1]), "mean_newton_iters": float(stats[2]),
+                       "reset": ("none (finished envs frozen)" if args.no_reset else ("inside jaco_step (auto_reset)" if (args.level == "env" and genv.auto_reset) else "masked jaco_reset launch chain after every step")),
                        "error_flags_or": flags & 31, "info_flags_or": flags & ~31, "launches_per_step": launches_per_step,
                        "config2_env_steps_per_s": (cfg_legs.get("config2") or {}).get("env_steps_per_s"), "config4_env_steps_per_s": (cfg_legs.get("config4") or {}).get("env_steps_per_s"),
                        "config_legs": cfg_legs,

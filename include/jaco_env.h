@@ -155,6 +155,10 @@ int jaco_set_frame_skip(JacoHandle* h, int frame_skip);
 
 /* Solver / collision options, MuJoCo <option> names: "iterations", "tolerance", "ls_iterations",
  * "disable_contact" (contact flag), "mpr_iterations", "mpr_tolerance", "mpr_output"; "compensated" (1 default, see jaco_set_state).
+ * "auto_reset" (0 default): jaco_step resets an env whose step ended its episode inside the same call -- sim.reset(), the draws of _reset
+ * (the code and RNG stream of jaco_reset), sim.forward() -- in the wavefront that finished it: reward_dev / done_dev carry the terminal
+ * step's values, the env's obs_dev row and task row are the new episode's first.  Bit-identical to jaco_step followed by
+ * jaco_reset(done mask); honoured for the tasks whose reset is draws + forward pass (picking, reaching, pickAndplace).
  * Setting a model option (everything in this first group except "disable_contact") SYNCHRONISES the device before the model
  * constants are re-uploaded: it is the one entry point besides the *_debug / *_time_ms hooks that does.
  * Execution options ("schedule", "concurrent_heavy", "heavy_workers", "handdown": bit-identical results; "hints" / "tier_return" pick which

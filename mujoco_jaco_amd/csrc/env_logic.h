@@ -25,6 +25,7 @@
 #define JT_WB 30         // last |EE - base| (get_wb)
 #define JT_PICKED 31     // task pickAndplace: self.picked (env_mujoco_util.py:587-590)
 #define JT_REACHGOAL 32  // [6] reaching goal: position + Euler rxyz (drawn at reset, env_mujoco_util.py:199-207)
+#define JT_FWD 39        // auto-reset: 1 while the reset env's forward pass (sim.forward() + observation) is still to be done (survives a tier hand-off)
 #define JT_PHASE 38      // task grasping, reset only: 0 pre-reach not started, 1 in its first loop (:138-159), 2 in its second (:160-170), 3 done
 #define JTASK_N 40
 static_assert(JTASK_N == JTASK_FLOATS, "task row size");
@@ -284,6 +285,48 @@ JDEV float grasp_ang_diff(const float* eul_ee, const float* eul_goal) {
   float s = 0.f;
   for (int k = 0; k < 4; k++) { const float d = a[k] * na - b[k] * nb; s += d * d; }
   return sqrtf(s);
+}
+
+// ---------------------------------------------------------------- a12: the draws of _reset (env_mujoco_util.py:92-121,176-219)
+// One env's randomised initial state: arm angles (_create_init_angle), the reaching / object / destination goals (__sample_goal), object on
+// the holder and pedestal at its goal (set_obj_xyz with the zero quaternion, set_dest_xyz), task row cleared (draw counter kept).
+// `q` (nq, already holding qpos0) and `t` (the task row) may live in global memory (jaco_reset_kernel: one thread per env) or in LDS (the
+// in-kernel auto-reset of a finished env: one lane).  Same code, same counter-based RNG stream: both paths produce the same bits.
+JDEV void reset_draws(int task_id, unsigned long long seed, unsigned env, int has_free, const float* base, float* q, float* t) {
+  unsigned c = __float_as_uint(t[JT_RNG]);
+#define JRU(lo, hi) ((lo) + ((hi) - (lo)) * rng_uniform(seed, env, c++))
+  const float PI = 3.14159265358979323846f;
+  if (task_id == JTASK_PLACING || task_id == JTASK_GRASPING) {   // 'carrying', 'grasping', 'placing' (:181-185)
+    const float pick = JRU(0.f, 1.f);
+    const float a0 = pick < 0.5f ? JRU(3.f * PI / 8.f, PI / 2.f) : JRU(PI / 2.f, 5.f * PI / 8.f);
+    q[0] = a0; q[1] = 3.85f; q[2] = JRU(1.f, 1.1f); q[3] = JRU(2.f, 2.1f); q[4] = JRU(0.8f, 2.3f); q[5] = JRU(-1.2f, -1.1f);
+  } else {                                                       // 'reaching', 'picking', 'pickAndplace' (:177-180)
+    q[0] = JRU(0.7f, 2.5f); q[1] = JRU(3.8f, 4.f); q[2] = JRU(1.f, 1.7f); q[3] = JRU(1.8f, 2.5f); q[4] = JRU(1.f, 2.5f); q[5] = JRU(0.8f, 2.3f);
+  }
+  for (int k = 0; k < JTASK_N; k++) if (k != JT_RNG) t[k] = 0.f;
+  t[JT_GRIP] = 0.6f; t[JT_GRIP_PREV] = 0.6f;
+  {   // reaching goal (__sample_goal, :199-207; drawn for every task, read by task 'reaching' and by the reaching-goal observation)
+    float g[3];
+    for (int k = 0; k < 2; k++) { const float mag = JRU(0.3f, 0.42f); const float sgn = JRU(0.f, 1.f); g[k] = sgn < 0.5f ? -mag : mag; }
+    g[2] = JRU(0.3f, 0.5f);
+    float x = g[0] - base[0], y = g[1] - base[1], z = g[2] - base[2];
+    const float n = sqrtf(x * x + y * y + z * z);
+    x /= n; y /= n; z /= n;
+    const float sx = x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f);
+    const float alpha = -asinf(y / sqrtf(y * y + z * z)) * sx, beta = acosf(x) * sx, gamma = JRU(-0.1f, 0.1f);   // (|xyz| = 1)
+    t[JT_REACHGOAL] = g[0]; t[JT_REACHGOAL + 1] = g[1]; t[JT_REACHGOAL + 2] = g[2];
+    // np.array([alpha, beta, gamma], dtype=np.float16) (:206): the orientation is stored with 11 bits of mantissa
+    t[JT_REACHGOAL + 3] = f16_round(alpha); t[JT_REACHGOAL + 4] = f16_round(beta); t[JT_REACHGOAL + 5] = f16_round(gamma);
+  }
+  if (has_free) {   // __sample_goal (:215-219), set_dest_xyz (mujoco.py:229-237), set_obj_xyz with the zero quaternion (:119-121)
+    const float ox = JRU(-0.1f, 0.1f), oy = 0.65f + JRU(-0.08f, 0.02f), dx = 0.4f + JRU(-0.05f, 0.05f), dy = 0.3f + JRU(-0.05f, 0.05f);
+    q[9] = ox; q[10] = oy; q[11] = 0.1898f; q[12] = 1.f; q[13] = 0.f; q[14] = 0.f; q[15] = 0.f;
+    q[16] = dx; q[17] = dy;
+    t[JT_OBJGOAL] = ox; t[JT_OBJGOAL + 1] = oy; t[JT_OBJGOAL + 2] = 0.1898f;
+    t[JT_DESTGOAL] = dx; t[JT_DESTGOAL + 1] = dy; t[JT_DESTGOAL + 2] = 0.3468f;
+  }
+#undef JRU
+  t[JT_RNG] = __uint_as_float(c);
 }
 
 // ---------------------------------------------------------------- a4/a5: operational-space controller on the wave

@@ -52,6 +52,7 @@ struct JacoHandle {
   int* order = nullptr;       // launch order of the env-level light kernel: expensive envs first
   unsigned* order_ctl = nullptr;   // histogram / cursors / cost sum / bucket reference of the ordering passes
   int schedule = 1;           // option "schedule": 0 = launch envs in index order
+  int auto_reset = 0;         // option "auto_reset"
   int min_nsub_sched = 2;     // option "min_nsub_sched": shortest step (substeps) that gets the cost-ordered launch and the resident tier workers
   const float* noise = nullptr;
   const float* subgoal = nullptr;   // obs_mode 1: the policy's sub-goal offsets for the "subgoal_reach" marker
@@ -435,6 +436,10 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
   A.env_mode = io.mode; A.task_id = h->task; A.nact = h->task == JACO_TASK_REACHING ? 6 : 7; A.seed = h->seed;
   A.task = h->task_rows; A.cache = h->cache; A.action = io.action; A.noise = h->noise; A.obs_mode = h->obs_mode; A.subgoal = h->subgoal; A.obs = io.obs; A.reward = io.reward; A.done = io.done; A.mask = io.mask; A.marker = h->marker;
   A.cost = h->cost;
+  // auto-reset folds draws + sim.forward() + observation into the step wave: the tasks whose reset is nothing more (placing holds the
+  // object for 150 substeps, grasping pre-reaches: those keep the explicit jaco_reset)
+  A.auto_reset = h->auto_reset && io.mode == 1 && (h->task == JACO_TASK_PICKING || h->task == JACO_TASK_REACHING || h->task == JACO_TASK_PICKANDPLACE);
+  A.qpos0 = h->qpos0_dev;
   const bool reorder = io.mode == 1 && h->schedule && nsub >= h->min_nsub_sched && h->num_envs >= 4096;
   std::pair<hipEvent_t, hipEvent_t>*ev = nullptr, *kev = nullptr;
   if (h->timing && io.mode <= 1) {   // (the masked forward passes of resets are not the kernel being measured)
@@ -537,43 +542,11 @@ __global__ void jaco_reset_kernel(JacoResetArgs R) {
   if (e >= R.nenv || (R.mask && !R.mask[e])) return;
   if (R.mask) R.list[atomicAdd(R.list_count, 1u)] = e;
   float* t = R.task + (size_t)e * JTASK_N;
-  unsigned c = __float_as_uint(t[JT_RNG]);
-  auto U = [&](float lo, float hi) { float u = rng_uniform(R.seed, (unsigned)e, c++); return lo + (hi - lo) * u; };
   float* q = R.qpos + (size_t)e * R.nq;
   for (int k = 0; k < R.nq; k++) { q[k] = R.qpos0[k]; R.qpos_lo[(size_t)e * R.nq + k] = 0.f; }
   for (int k = 0; k < R.nv; k++) { R.qvel[(size_t)e * R.nv + k] = 0.f; R.qacc_ws[(size_t)e * R.nv + k] = 0.f; R.qvel_lo[(size_t)e * R.nv + k] = 0.f; }
   for (int k = 0; k < 24; k++) R.marker[(size_t)e * 24 + k] = R.marker_rest[k];   // sim.reset(): markers back to their XML pose
-  // _create_init_angle (env_mujoco_util.py:176-185); fingers stay at qpos0 (mujoco.py:342-343)
-  if (R.task_id == JACO_TASK_PLACING || R.task_id == JACO_TASK_GRASPING) {   // 'carrying', 'grasping', 'placing' (:181-185)
-    const float PI = 3.14159265358979323846f;
-    float a0 = U(0.f, 1.f) < 0.5f ? U(3.f * PI / 8.f, PI / 2.f) : U(PI / 2.f, 5.f * PI / 8.f);
-    q[0] = a0; q[1] = 3.85f; q[2] = U(1.f, 1.1f); q[3] = U(2.f, 2.1f); q[4] = U(0.8f, 2.3f); q[5] = U(-1.2f, -1.1f);
-  } else {
-    q[0] = U(0.7f, 2.5f); q[1] = U(3.8f, 4.f); q[2] = U(1.f, 1.7f); q[3] = U(1.8f, 2.5f); q[4] = U(1.f, 2.5f); q[5] = U(0.8f, 2.3f);
-  }
-  for (int k = 0; k < JTASK_N; k++) if (k != JT_RNG) t[k] = 0.f;
-  t[JT_GRIP] = 0.6f; t[JT_GRIP_PREV] = 0.6f;
-  {   // reaching goal (__sample_goal, :199-207; drawn for every task, read by task 'reaching' and by the reaching-goal observation)
-    float g[3];
-    for (int k = 0; k < 2; k++) { float m = U(0.3f, 0.42f); g[k] = U(0.f, 1.f) < 0.5f ? -m : m; }
-    g[2] = U(0.3f, 0.5f);
-    float x = g[0] - R.base[0], y = g[1] - R.base[1], z = g[2] - R.base[2];
-    const float n = sqrtf(x * x + y * y + z * z);
-    x /= n; y /= n; z /= n;
-    const float sx = x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f);
-    const float alpha = -asinf(y / sqrtf(y * y + z * z)) * sx, beta = acosf(x) * sx, gamma = U(-0.1f, 0.1f);   // (|xyz| = 1)
-    t[JT_REACHGOAL] = g[0]; t[JT_REACHGOAL + 1] = g[1]; t[JT_REACHGOAL + 2] = g[2];
-    // np.array([alpha, beta, gamma], dtype=np.float16) (:206): the orientation is stored with 11 bits of mantissa
-    t[JT_REACHGOAL + 3] = __half2float(__float2half_rn(alpha)); t[JT_REACHGOAL + 4] = __half2float(__float2half_rn(beta)); t[JT_REACHGOAL + 5] = __half2float(__float2half_rn(gamma));
-  }
-  if (R.has_free) {   // __sample_goal (:215-219), set_dest_xyz (mujoco.py:229-237), set_obj_xyz with the zero quaternion (:119-121)
-    float ox = U(-0.1f, 0.1f), oy = 0.65f + U(-0.08f, 0.02f), dx = 0.4f + U(-0.05f, 0.05f), dy = 0.3f + U(-0.05f, 0.05f);
-    q[9] = ox; q[10] = oy; q[11] = 0.1898f; q[12] = 1.f; q[13] = 0.f; q[14] = 0.f; q[15] = 0.f;
-    q[16] = dx; q[17] = dy;
-    t[JT_OBJGOAL] = ox; t[JT_OBJGOAL + 1] = oy; t[JT_OBJGOAL + 2] = 0.1898f;
-    t[JT_DESTGOAL] = dx; t[JT_DESTGOAL + 1] = dy; t[JT_DESTGOAL + 2] = 0.3468f;
-  }
-  t[JT_RNG] = __uint_as_float(c);
+  reset_draws(R.task_id, R.seed, (unsigned)e, R.has_free, R.base, q, t);          // (env_logic.h: shared with the in-kernel auto-reset)
 }
 
 extern "C" int jaco_forward(JacoHandle* h, float* obs_dev, void* stream) {
@@ -736,6 +709,7 @@ extern "C" int jaco_set_option(JacoHandle* h, const char* name, double v) {
   if (!strcmp(name, "tier_return")) { h->tier_return = v != 0; return JACO_OK; }
   if (!strcmp(name, "heavy_workers")) { h->workers = v < 1 ? 1 : (int)v; return JACO_OK; }
   if (!strcmp(name, "handdown")) { h->handdown = v != 0; return JACO_OK; }
+  if (!strcmp(name, "auto_reset")) { h->auto_reset = v != 0; return JACO_OK; }
   if (!strcmp(name, "min_nsub_sched")) { h->min_nsub_sched = v < 1 ? 1 : (int)v; return JACO_OK; }
   if (!strcmp(name, "hints")) { h->use_hints = v < 0 ? 0 : (v > 2 ? 2 : (int)v); return JACO_OK; }   // 0 off, 1 biggest tier of the last step, 2 tier of its last substep
   if (!strcmp(name, "obs_mode")) { if (v != 0 && v != 1) { h->err = "jaco_set_option: obs_mode must be 0 or 1"; return JACO_EINVAL; } h->obs_mode = (int)v; return JACO_OK; }

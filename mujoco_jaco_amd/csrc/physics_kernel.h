@@ -121,6 +121,9 @@ struct JacoStepArgs {
   const float* action;       // [nenv][nact]
   const float* noise;        // optional [nenv][12] sub-goal noise draws (6 for the marker, 6 for the observation), else RNG
   int obs_mode;              // 0: rule-based sub-goal in obs[17:23] (what main.py selects), 1: the reaching goal (rulebased_subgoal = False, env_mujoco_util.py:255-270)
+  int auto_reset;            // mode 1, option "auto_reset": an env whose step ends its episode is reset (draws of _reset + sim.forward() + first
+                             // observation) by the wave that finished it, instead of by a separate masked jaco_reset launch chain
+  const float* qpos0;        // [nq] reset pose (auto_reset)
   const float* subgoal;      // obs_mode 1, optional [nenv][6]: the policy's sub-goal offset; "subgoal_reach" marker = it + the previous target (:609)
   float* obs;                // [nenv][26]
   float* reward;             // [nenv]
@@ -1209,7 +1212,14 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
       return 0;
     }
   }
-  if (emode == 1 || emode == 4) {
+  bool fwd = false;   // auto-reset: this pass is the reset env's sim.forward() + observation (one substep's derived quantities, no integration)
+  if (emode == 1 && s.task[JT_FWD] != 0.f) {   // ... resumed in a bigger tier after the forward pass overflowed the tier below
+    fwd = true; nsub = 1;
+    if (lane < nu) s.ctrl[lane] = 0.f;
+    if (lane == 0) { s.task[JT_SUB] = 0.f; s.task[JT_PENDING] = 0.f; }
+    wave_sync();
+  }
+  if ((emode == 1 && !fwd) || emode == 4) {
     sub0 = wave_uniform_i((int)s.task[JT_SUB]);
     // (a step that overflowed this tier in its very first substep comes back with JT_SUB = 0 and the interrupted substep pending:
     // its action has been taken already -- taking it again would add the gripper increment twice and shift the draw counter)
@@ -1327,6 +1337,7 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
   pc.row = A.prof ? A.prof + (size_t)env * JPROF_N : nullptr;
   pc.tprev = __builtin_amdgcn_s_memtime();
 #endif
+again:
   for (int sub = sub0; sub < nsub; sub++) {
     m = opaque_ptr(A.model);
     // Same for the lane id: everything a lane addresses (LDS offsets, "lane < n" masks, model table slots) derives from it, and the
@@ -1351,7 +1362,7 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
       if (lane >= 9 && lane < nv) { s.qvel[lane] = 0.f; s.qvel_lo[lane] = 0.f; }
       wave_sync();
     }
-    if (emode == 1) {
+    if (emode == 1 && !fwd) {
       if (s.task[JT_PENDING] != 0.f) {   // resume of a substep interrupted by the light tier: its ctrl was saved
         if (lane < nu) s.ctrl[lane] = s.task[JT_CTRL + lane];
         wave_sync();
@@ -1488,7 +1499,7 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
       if (lane < m->nsensor) D[JDBG_SENS + lane] = sens;
     }
     wave_sync();
-    if (emode == 2) break;   // sim.forward(): derived quantities only, no integration
+    if (emode == 2 || fwd) break;   // sim.forward(): derived quantities only, no integration
     if (lane < nv) {
       float v;
       if (m->compensated) {   // qvel += h qacc on the compensated pair
@@ -1569,6 +1580,7 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
       break;
     }
   }
+  bool reset_now = false;
   if (emode != 2) {
     if (bailed) {   // handed over to another workgroup (possibly on another XCD): write-through stores
       if (lane < nq) { st_wt(&A.qpos[(size_t)env * nq + lane], s.qpos[lane]); if (A.qpos_lo) st_wt(&A.qpos_lo[(size_t)env * nq + lane], s.qpos_lo[lane]); }
@@ -1612,7 +1624,7 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
       int succ = 0;
       bool done = false;
       const float PI = 3.14159265358979323846f;
-      if (emode == 1 || emode == 5) {
+      if ((emode == 1 && !fwd) || emode == 5) {
         if (emode == 1) rew = A.task_id == JTASK_PICKING ? reward_picking(pe, eul, obj, touch)
                             : (A.task_id == JTASK_REACHING ? reward_reaching(pe, eul, s.task + JT_REACHGOAL, ld3(m->base_pos))
                             : (A.task_id == JTASK_GRASPING ? reward_picking(pe, eul, obj, touch, 0.05f) : 0.f));   // (placing, pickAndplace: 0 in the reference)
@@ -1630,7 +1642,9 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
           A.reward[env] = rew + bonus;
           A.done[env] = done ? 1 : 0;
         }
+        reset_now = emode == 1 && A.auto_reset != 0 && wave_ballot(done) != 0ull;
       }
+      if (fwd && lane == 0) { s.task[JT_FWD] = 0.f; s.task[JT_SUB] = 0.f; s.task[JT_PENDING] = 0.f; }
       if (lane == 0 && emode != 5 && A.obs_mode == 0) s.task[JT_RNG] = __uint_as_float(cnt + 6u);
       if (lane < 26 && emode != 5) {
         float o;
@@ -1651,6 +1665,30 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
     if (left == 0 && (emode == 3 || emode == 6) && lane == 0) { s.task[JT_SUB] = 0.f; s.task[JT_PENDING] = 0.f; }
     wave_sync();
     if (lane < JTASK_N) { if (bailed) st_wt(&A.task[(size_t)env * JTASK_N + lane], s.task[lane]); else A.task[(size_t)env * JTASK_N + lane] = s.task[lane]; }
+  }
+  if (reset_now) {
+    // auto-reset (option "auto_reset"; tasks whose reset is draws + sim.forward(): picking, reaching, pickAndplace): the episode has
+    // ended and its reward / done flag are out; the same wave now does what jaco_reset(mask) would do in a launch chain of its own
+    // (0.6 ms of mostly idle GPU per step, profiles/r03_trace_policy.txt): sim.reset(), the draws (env_logic.h reset_draws: the code and
+    // RNG stream of jaco_reset_kernel), then one more pass through the substep body as sim.forward() and the new episode's observation.
+    wave_sync();
+    if (lane < nq) { s.qpos[lane] = A.qpos0[lane]; s.qpos_lo[lane] = 0.f; }
+    if (lane < nv) { s.qvel[lane] = 0.f; s.qvel_lo[lane] = 0.f; s.qacc_ws[lane] = 0.f; }
+    if (lane < nu) s.ctrl[lane] = 0.f;
+    if (lane < 24) {
+      const float r = m->marker_rest[lane / 12][lane % 12];
+      s.mk[lane] = r;
+      if (A.marker) st_wt(&A.marker[(size_t)env * 24 + lane], r);   // (write-through: a bigger tier may pick the forward pass up)
+    }
+    wave_sync();
+    if (lane == 0) {
+      reset_draws(A.task_id, A.seed, (unsigned)env, nq >= 23, m->base_pos, s.qpos, s.task);
+      s.task[JT_FWD] = 1.f;
+      if (A.hint) st_wt_i(&A.hint[env], 0);   // a reset env starts from scratch, as under jaco_reset (a bigger tier that finishes the forward pass sets it again)
+    }
+    wave_sync();
+    fwd = true; sub0 = 0; nsub = 1; left = 0; calm = 0;
+    goto again;
   }
   unsigned long long anyf = wave_ballot(flags != 0);
   if (anyf) {

@@ -61,6 +61,14 @@ class JacoBatchedEnv:
         self.L, self.h, self.device = self.sim.L, self.sim.h, self.sim.device
         if not self.rulebased_subgoal:
             self.sim.set_option("obs_mode", 1)
+        # auto_reset=True (batched rollouts): an env whose step ends its episode is reset inside that very jaco_step call -- sim.reset(),
+        # the draws of _reset, sim.forward() -- by the wavefront that finished it; step() then returns the terminal step's reward and
+        # done flag together with the FIRST observation of the new episode (and the task row, success flag included, is the new
+        # episode's: read success as `reward > 100 and done`, main.py:262).  Tasks whose reset is more than draws + forward pass
+        # (placing: 150-substep hold; grasping: pre-reach loops) keep the explicit reset(mask).
+        self.auto_reset = bool(kwargs.get("auto_reset", False)) and self.task in ("picking", "reaching", "pickAndplace")
+        if self.auto_reset:
+            self.sim.set_option("auto_reset", 1)
         self._subgoal = None
         # ---- RL setup (env_mujoco.py:15-93)
         self.current_steps = 0

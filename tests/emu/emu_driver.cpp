@@ -62,6 +62,17 @@ static int emu_launch(JacoStepArgs A, int* heavy_envs) {
   return 0;
 }
 // env-level call: mode 1 = step (nsub = frame_skip), mode 2 = forward only
+static int g_auto_reset = 0;
+static std::vector<float> g_qpos0;
+extern "C" void emu_set_auto_reset(int on, const float* qpos0, int nq) { g_auto_reset = on; g_qpos0.assign(qpos0, qpos0 + nq); }
+// what jaco_reset_kernel does for one env (jaco_env.hip): sim.reset() + the draws; the forward pass is a mode-2 emu_env_call
+extern "C" void emu_reset_env(int task_id, unsigned long long seed, int env, int nq, int nv, const float* qpos0, const float* base, float* qpos, float* qvel,
+                              float* qacc_ws, float* task, float* marker, const float* marker_rest) {
+  for (int k = 0; k < nq; k++) qpos[(size_t)env * nq + k] = qpos0[k];
+  for (int k = 0; k < nv; k++) { qvel[(size_t)env * nv + k] = 0.f; qacc_ws[(size_t)env * nv + k] = 0.f; }
+  for (int k = 0; k < 24; k++) marker[(size_t)env * 24 + k] = marker_rest[k];
+  reset_draws(task_id, seed, (unsigned)env, nq >= 23, base, qpos + (size_t)env * nq, task + (size_t)env * JTASK_N);
+}
 extern "C" int emu_env_call(const void* blob, long blob_size, int nenv, int mode, int frame_skip, int task_id, int nact, unsigned long long seed,
                             float* qpos, float* qvel, float* qacc_ws, float* sensordata, unsigned* flags, int* stats, float* task, float* cache,
                             const float* action, const float* noise, float* obs, float* reward, unsigned char* done, float* marker, int* heavy_envs) {
@@ -72,6 +83,7 @@ extern "C" int emu_env_call(const void* blob, long blob_size, int nenv, int mode
   A.model = &g_model; A.hull = g_hull.data(); A.qpos = qpos; A.qvel = qvel; A.qacc_ws = qacc_ws; A.ctrl = qvel; A.sensordata = sensordata;
   A.flags = flags; A.stats = stats; A.nenv = nenv; A.nsub = mode == 2 ? 1 : frame_skip; A.env_mode = mode; A.task_id = task_id; A.nact = nact;
   A.seed = seed; A.task = task; A.cache = cache; A.action = action; A.noise = noise; A.obs = obs; A.reward = reward; A.done = done; A.marker = marker; A.dbg_env = -1;
+  A.auto_reset = g_auto_reset && mode == 1 && (task_id == 0 || task_id == 2 || task_id == 4); A.qpos0 = g_qpos0.empty() ? nullptr : g_qpos0.data();
   return emu_launch(A, heavy_envs);
 }
 // rest pose of the two task-layer markers (what jaco_reset_state writes): 24 floats

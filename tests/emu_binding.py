@@ -29,6 +29,8 @@ def lib(layout=""):
         L.emu_env_call.argtypes = [ctypes.c_char_p, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_ulonglong,
                                    fp, fp, fp, fp, up, ip, fp, fp, fp, fp, fp, fp, ctypes.POINTER(ctypes.c_ubyte), fp, ip]
         L.emu_marker_rest.argtypes = [ctypes.c_char_p, ctypes.c_long, fp]
+        L.emu_set_auto_reset.argtypes = [ctypes.c_int, fp, ctypes.c_int]
+        L.emu_reset_env.argtypes = [ctypes.c_int, ctypes.c_ulonglong, ctypes.c_int, ctypes.c_int, ctypes.c_int, fp, fp, fp, fp, fp, fp, fp, fp]
         _libs[layout] = L
     return _libs[layout]
 
@@ -109,6 +111,22 @@ class EmuJacoEnv(EmuEnv):
         finally:
             self.frame_skip = fs
         return self.obs.copy()
+
+    def set_auto_reset(self, on):
+        """option "auto_reset": a finished env is reset (draws + sim.forward() + first observation) by the wave that finished it."""
+        q0 = np.ascontiguousarray(self.M["qpos0"], np.float32)
+        self.L.emu_set_auto_reset(int(on), q0.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), self.nq)
+
+    def reset_env(self, env, noise=None):
+        """jaco_reset(mask = {env}): the reset kernel's work for one env, then the forward pass + observation (mode 2; here for all envs,
+        which is harmless for the others: a forward pass does not change state)."""
+        fp = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+        q0 = np.ascontiguousarray(self.M["qpos0"], np.float32)
+        base = np.ascontiguousarray(self.M["f_pos"].reshape(-1, 3)[0], np.float32)
+        rest = np.zeros(24, np.float32)
+        assert self.L.emu_marker_rest(self.blob, len(self.blob), fp(rest)) == 0
+        self.L.emu_reset_env(self.task_id, self.seed, env, self.nq, self.nv, fp(q0), fp(base), fp(self.qpos), fp(self.qvel), fp(self.qacc_ws), fp(self.task),
+                             fp(self.marker), fp(rest))
 
     def forward(self, noise=None):
         self._call(2, None, None if noise is None else np.ascontiguousarray(noise, np.float32))

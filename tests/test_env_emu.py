@@ -1,6 +1,7 @@
 """CPU tier: env-level step of the emulated HIP kernels (OSC + substeps + obs/reward/done) against the fp64 oracle
 env (tests/oracle_env.py = physics oracle + oracle/glue.py, the latter pinned by the reference's golden vectors)."""
 import numpy as np
+import pytest
 
 from emu_binding import EmuJacoEnv
 from mujoco_jaco_amd import workload
@@ -352,3 +353,60 @@ def test_terminal_inspection_on_a_finished_env_is_frozen(names, model_arrays):
     e.cache[0, 78:93] = np.nan                                           # quarantined env: poses non-finite
     e._call(5)
     assert e.done[0] == 1 and e.reward[0] == 0 and e.task[0, 3] == 1
+
+
+def test_auto_reset_equals_the_explicit_reset_chain(names, model_arrays):
+    """Option "auto_reset": the wave that finishes an episode does sim.reset(), the draws of _reset and sim.forward() + the first
+    observation itself.  Bit-for-bit what the explicit chain (reset kernel's work, then a mode-2 forward pass) leaves behind: state,
+    task row (goals, draw counter, counters), controller cache, markers and the observation row; reward / done are the terminal step's."""
+    def make():
+        e, _ = _pair(names, model_arrays, 7, 2)
+        e.seed = 1234
+        e.forward(np.full((1, 12), 0.5, np.float32))
+        e.task[0, 1] = 698                                       # two steps before the 700-step time-out
+        return e
+    a = np.array([0.3, -0.2, 0.1, 0.2, -0.1, 0.3, 0.5], np.float32)
+    nz = np.full((1, 12), 0.25, np.float32)
+    ea, eb = make(), make()
+    ea.set_auto_reset(1)
+    oa, ra, da = ea.env_step(a, nz); ob, rb, db = eb.env_step(a, nz)
+    assert da[0] == 0 and np.array_equal(oa, ob) and np.array_equal(ea.qpos, eb.qpos)                 # no episode end: nothing differs
+    oa, ra, da = ea.env_step(a, nz)                              # time-out: auto path resets in the same call
+    ea.set_auto_reset(0)
+    ob, rb, db = eb.env_step(a, nz)                              # explicit path: terminal step ...
+    assert da[0] == 1 and db[0] == 1 and ra[0] == rb[0] and abs(ra[0] + 10.0) < 0.2
+    eb.reset_env(0)                                              # ... then jaco_reset(mask): reset kernel's work + forward pass
+    ob = eb.forward(nz)
+    assert np.array_equal(oa, ob), np.abs(oa - ob).max()
+    for x, y in ((ea.qpos, eb.qpos), (ea.qvel, eb.qvel), (ea.qacc_ws, eb.qacc_ws), (ea.task, eb.task), (ea.cache, eb.cache), (ea.marker, eb.marker)):
+        assert np.array_equal(x, y)
+    assert ea.task[0, 1] == 0 and ea.task[0, 3] == 0 and ea.task[0, 39] == 0 and ea.task[0, 0] == np.float32(0.6)   # fresh episode, forward pass done
+    assert abs(oa[0, 10] - 0.1898) < 1e-6 and abs(oa[0, 7] + 1.0) < 1e-6                                  # object on the holder, gripper command 0.6
+    # the new episode runs on: both sides step identically
+    o2a, _, d2a = ea.env_step(a, nz); o2b, _, d2b = eb.env_step(a, nz)
+    assert d2a[0] == 0 and np.array_equal(o2a, o2b) and np.array_equal(ea.qpos, eb.qpos)
+
+
+@pytest.mark.parametrize("seed", [26, 31])
+def test_auto_reset_forward_pass_survives_a_tier_hand_off(names, model_arrays, seed):
+    """Resets whose drawn pose puts the hand into the holder / pedestal (48 contacts / 216 rows for seed 26, 65 / 290 for seed 31, with the draw counter at 18 as it stands after one forward pass and one step): the
+    forward pass of the auto-reset overflows the light tier and is finished by a bigger one (JT_FWD travels in the task row).  Same
+    bits as the explicit reset chain, whose forward pass is handed on the same way."""
+    def make():
+        e, _ = _pair(names, model_arrays, 7, 2)
+        e.seed = seed
+        e.forward(np.full((1, 12), 0.5, np.float32))
+        e.task[0, 1] = 699
+        return e
+    a = np.zeros(7, np.float32); nz = np.full((1, 12), 0.25, np.float32)
+    ea, eb = make(), make()
+    ea.set_auto_reset(1)
+    oa, ra, da = ea.env_step(a, nz)
+    ea.set_auto_reset(0)
+    ob, rb, db = eb.env_step(a, nz)
+    assert da[0] == 1 and db[0] == 1 and ra[0] == rb[0]
+    eb.reset_env(0); eb.flags[:] = 0
+    ob = eb.forward(nz)
+    assert eb.flags[0] & 32 and ea.flags[0] & 32                                       # both forward passes left the light tier
+    assert np.array_equal(oa, ob) and np.array_equal(ea.qpos, eb.qpos) and np.array_equal(ea.task, eb.task) and np.array_equal(ea.cache, eb.cache)
+    assert ea.task[0, 39] == 0 and ea.task[0, 19] == 0 and ea.task[0, 17] == 0          # forward pass done, nothing pending

@@ -631,3 +631,34 @@ def test_config1_single_env_1000_random_action_steps(model_arrays, names):
     fl = int(env.sim.flags().cpu().numpy()[0])
     print("config 1: 1 000 steps, %d episodes finished, first %d steps vs the oracle env: obs err median %.2e max %.2e; flags 0x%x" % (episodes, len(errs), np.median(errs), max(errs), fl))
     assert fl & 15 == 0 and len(errs) >= 20 and max(errs) < 2e-6   # (measured 6.6e-7 over 40 steps = 2 000 substeps)
+
+
+def test_auto_reset_equals_step_plus_masked_reset_8192_envs():
+    """Option auto_reset at batch scale: 8 192 envs, episodes ending all over the batch (step counters spread just below the 700-step
+    time-out), 6 steps: jaco_step with the reset folded into the step wave against jaco_step + jaco_reset(done): rewards, done flags,
+    observations, states and task rows bit-identical in every step -- including the resets whose forward pass leaves the light tier."""
+    from mujoco_jaco_amd.env import JacoBatchedEnv
+    B = 8192
+    outs = []
+    for auto in (True, False):
+        env = JacoBatchedEnv(num_envs=B, task="picking", seed=31, auto_reset=auto, frame_skip=10)
+        assert env.auto_reset == auto
+        env.reset()
+        gen = torch.Generator(device=env.device); gen.manual_seed(3)
+        t = env.task_state(); t[:, 1] = torch.randint(693, 699, (B,), device=env.device, generator=gen).float(); env.set_task_state(t)
+        rec = []
+        for s in range(6):
+            a = torch.rand(B, 7, device=env.device, generator=gen) * 2 - 1
+            o, r, d, _ = env.step(a)
+            r, d = r.clone(), d.clone()
+            if not auto:
+                o = env.reset(d)
+            rec.append((o.clone(), r, d, env.sim.get_state()[0].clone(), env.task_state().clone()))
+        outs.append((rec, env.sim.flags().clone()))
+        env.close()
+    ndone, heavy_resets = 0, 0
+    for s, (x, y) in enumerate(zip(outs[0][0], outs[1][0])):
+        ndone += int(x[2].sum())
+        for k in range(5):
+            assert torch.equal(x[k], y[k]), (s, k, (x[k].float() - y[k].float()).abs().max())
+    assert ndone >= B // 2 and ((outs[0][1] & 15) == 0).all()
