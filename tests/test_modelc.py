@@ -32,3 +32,47 @@ def test_sibling_mjcfs_parse():
         sizes[name] = (int(M["nq"][0]), int(M["nv"][0]), int(M["nu"][0]), int(M["njnt"][0]))
     assert sizes["jaco2_curtain_torque"] == (23, 21, 9, 11) and sizes["jaco2_reaching_torque"] == (9, 9, 9, 9)
     assert sizes["jaco2_torque"] == (12, 12, 9, 12) and sizes["jaco2_curtain_torque_old"][3] == 13
+
+
+def test_compiled_model_against_the_surveys_model_table():
+    """An independent pin of the MJCF reader: SURVEY.md section 8a's model table was read off jaco2_curtain_torque.xml by the surveyor
+    (line numbers cited there), not produced by this compiler.  The compiled blob must hold those numbers: an MJCF-convention error in
+    modelc would otherwise be common to the kernel and the oracle (both read the blob)."""
+    from mujoco_jaco_amd.modelc import blob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    M = blob.load(os.path.join(root, "mujoco_jaco_amd", "assets", "jaco2_curtain_torque.jacomdl"))
+    names = {}
+    for line in open(os.path.join(root, "mujoco_jaco_amd", "assets", "jaco2_curtain_torque.names.txt")):
+        k, v = line.strip().split(": ", 1)
+        names[k] = v.split()
+    B = {n: i for i, n in enumerate(names["body"])}
+    J = {n: i for i, n in enumerate(names["joint"]) if n != "-"}
+    pos, mass, ipos = M["body_pos"].reshape(-1, 3), M["body_mass"], M["body_ipos"].reshape(-1, 3)
+    # frame positions and inertial rows (xml:109-140)
+    for body, p in (("link1", (0, 0, 0.157)), ("link2", (0, 0.0016, 0.1186)), ("link3", (0, 0, 0.410)), ("link4", (0, -0.0115, 0.2072)),
+                    ("link5", (0, 0.037, 0.0641)), ("link6", (0, 0.037, 0.0641)), ("EE", (0, 0, 0.12)), ("object_body", (1, 1.2, 1)), ("object_dest", (0.6, 0.3, 0.09))):
+        assert np.allclose(pos[B[body]], p, atol=1e-12), body
+    for body, m in (("link1", 0.754), ("link2", 1.01), ("link3", 0.559), ("link4", 0.417), ("link5", 0.417), ("link6", 0.727)):
+        assert abs(mass[B[body]] - m) < 1e-12, body
+    assert np.allclose(ipos[B["link1"]], (-4.2e-5, -1.285e-3, 0.112784)) and np.allclose(ipos[B["link2"]], (1.4e-5, 0.009353, 0.329006))
+    # joints: axes (normalised at compile; joint4 is `0 -1.9 -1.1` in the XML), reference angles, ranges, damping (xml:113-144,172,208,244)
+    ax, rng, q0 = M["jnt_axis"].reshape(-1, 3), M["jnt_range"].reshape(-1, 2), M["qpos0"]
+    assert np.allclose(ax[J["joint0"]], (0, 0, -1)) and np.allclose(ax[J["joint1"]], (0, -1, 0)) and np.allclose(ax[J["joint2"]], (0, 1, 0))
+    assert np.allclose(ax[J["joint4"]], np.array([0, -1.9, -1.1]) / np.linalg.norm([1.9, 1.1])) and np.allclose(ax[J["joint_thumb"]], (1, 0, 0)) and np.allclose(ax[J["joint_index"]], (-1, 0, 0))
+    qa = M["jnt_qposadr"]
+    assert q0[qa[J["joint1"]]] == 3.14 and q0[qa[J["joint2"]]] == 3.14 and q0[qa[J["joint_thumb"]]] == 1.1
+    assert np.allclose(rng[J["joint1"]], (0.872665, 5.41052)) and np.allclose(rng[J["joint2"]], (0.331613, 5.95157)) and np.allclose(rng[J["joint_thumb"]], (0, 1.51))
+    da = M["jnt_dofadr"]
+    assert all(M["dof_damping"][da[J[j]]] == 0.15 for j in ("joint_thumb", "joint_index", "joint_pinky")) and M["dof_damping"][:6].max() == 0
+    # free bodies from their geoms (no <inertial>): box .027 x .027 x .03 at density 100 -> 0.017496 kg; pedestal .1 x .1 x .16 at 1e5 -> 1280 kg
+    assert abs(mass[B["object_body"]] - 8 * 0.027 * 0.027 * 0.03 * 100) < 1e-12 and abs(mass[B["object_dest"]] - 8 * 0.1 * 0.1 * 0.16 * 1e5) < 1e-6
+    # actuators (xml:341-349): 6 motors with force ranges 30 / 15, 3 position servos kp 20, ctrlrange [0, 1.51], force +-0.3
+    fr = M["actuator_forcerange"].reshape(-1, 2)
+    assert np.allclose(fr[:6, 1], (30, 30, 30, 15, 15, 15)) and np.allclose(fr[6:, 1], 0.3) and np.allclose(M["actuator_kp"][6:], 20)
+    assert list(M["actuator_position"]) == [0] * 6 + [1] * 3 and np.allclose(M["actuator_ctrlrange"].reshape(-1, 2)[6:], (0, 1.51))
+    # contact parameters of the object and the hand mesh (xml:141,292): friction .95 .3 .1, solref .001 1; condim 6, solref .01
+    G = {n: i for i, n in enumerate(names["geom"]) if n != "-"}
+    gobj = int(np.where(M["geom_bodyid"] == B["object_body"])[0][0])
+    assert np.allclose(M["geom_friction"].reshape(-1, 3)[gobj], (0.95, 0.3, 0.1)) and np.allclose(M["geom_solref"].reshape(-1, 2)[gobj], (0.001, 1))
+    assert M["geom_condim"][G["link6"]] == 6 and np.allclose(M["geom_solref"].reshape(-1, 2)[G["link6"]], (0.01, 1))
+    assert float(M["opt_timestep"][0]) == 0.001 and np.allclose(M["opt_gravity"], (0, 0, -9.81))
