@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 TAG=$1; LEVEL=${2:-env}; shift; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG
 rm -rf $OUT && mkdir -p $OUT
-CMD="python3 $GRAFT_REPO_ROOT/bench.py --level $LEVEL --steps 4 --warmup 2 --preroll 20 --no-cpu-baseline --extra-scales= --policy-leg= $@"
+CMD="python3 $GRAFT_REPO_ROOT/bench.py --level $LEVEL --steps 4 --warmup 2 --preroll 20 --no-cpu-baseline --extra-scales= --policy-leg= --config-legs= $@"
 i=0
 for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" \
            "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
