@@ -566,15 +566,59 @@ JDEV void stage_collision(const JacoStepArgs& A, const JacoModelDev* m, L& s, in
 }
 
 // ---------------------------------------------------------------- stage R (contacts): pyramidal rows
+// Side rows (light tier, models with a pedestal block).  The 64-row light tier overflows by a handful of rows exactly in the regimes
+// real rollouts live in: object on holder (16 rows) + pedestal on floor (16) + the EE's axis sticks lying on the "hand" marker's
+// sticks (9 contacts = 36) = 68.  The pedestal's rows touch nothing but the pedestal's own six dofs (dof block [JB1, JNV)), and as
+// long as no other row reaches into that block its sub-problem is exactly separable from the rest of the Newton problem.  So when
+// the rows do not fit, the contacts whose dof support is the pedestal block alone go to a side buffer of up to JSIDE_ROWS rows x 6
+// columns, solved by a small Newton solve of its own (newton_side, physics_kernel.h), and the main buffer keeps the other <= 64.
+// The side buffer costs no LDS: it overlays cdof[6..] + cvel, which are dead between this stage and the next substep's tree walk
+// (the controller reads cdof[0..5] only).  Virtual row index of side row j: JSIDE_BASE + j.
+#define JSIDE_ROWS 16
+#define JSIDE_BASE 64
+#define JSIDE_J 0        // [JSIDE_ROWS][6] Jacobian columns JB1 .. JNV-1
+#define JSIDE_AREF 96    // [JSIDE_ROWS] aref, later the residual staging of the side solve
+#define JSIDE_D 112      // [JSIDE_ROWS]
+#define JSIDE_F 128      // [JSIDE_ROWS] row weights during the side solve, row forces after it
+template <class L>
+struct SideRows {
+  static constexpr bool on = L::Caps::MAXEFC == 64 && JNV - JB1 == 6 && (JNV - 6) * 6 + JNB * 6 >= JSIDE_F + JSIDE_ROWS;
+};
+template <class L>
+JDEV float* side_buf(L& s) { return &s.cdof[6][0]; }
+// row velocity J_row . qvel of pyramid edge e of contact c, from the two bodies' spatial velocities: the contact-frame components of the
+// relative point velocity (k < 3) or relative angular velocity (k >= 3), combined as the pyramid edge  v_0 +- mu_k v_k
+template <class L>
+JDEV float contact_row_vel(const L& s, int c, int e, float mu) {
+  const int pd = s.c_dim[c];
+  const int kf = pd == 1 ? 0 : 1 + (e >> 1);
+  const int obs = s.c_ob[c], b1 = ((obs >> 8) & 0xFF) - 1, b2 = ((obs >> 24) & 0xFF) - 1;
+  sv v1, v2;
+  v1.a = v1.b = v2.a = v2.b = mk3(0.f, 0.f, 0.f);
+  if (b1 >= 0) v1 = ldsv(s.cvel[b1]);
+  if (b2 >= 0) v2 = ldsv(s.cvel[b2]);
+  v3 cp = ld3(s.c_pos[c]);
+  v3 dw = v2.a - v1.a, dv = (v2.b - v1.b) + cross(dw, cp);
+  const float* fr = s.c_frame[c];
+  float vel = dot(ld3(fr), dv);
+  if (pd > 1) {
+    const int ax = kf < 3 ? kf : kf - 3;
+    const float comp = dot(ld3(fr + 3 * ax), kf < 3 ? dv : dw);
+    vel += ((e & 1) ? -1.f : 1.f) * mu * comp;
+  }
+  return vel;
+}
 template <class L>
 JDEV void stage_contact_rows(const JacoModelDev* m, L& s, int lane, unsigned& flags) {
   constexpr int MAXEFC = L::Caps::MAXEFC;
+  constexpr bool SIDE = SideRows<L>::on;
   const int nv = m->nv, ncon = wave_uniform_i(s.ncon), nlim = wave_uniform_i(s.nlimit);
   // per-contact parameters handed to the row lanes through LDS: a contact's chain masks are dead once its own lane has read
   // them (each lane only ever overwrites its own contact's slots), c_fn is not yet in use
   float* pa0 = reinterpret_cast<float*>(s.c_m1);
   float* pbc = reinterpret_cast<float*>(s.c_m2);
-  int rowbase = nlim, kept_total = 0;
+  float* sd = side_buf(s);
+  int rowbase = nlim, kept_total = 0, nside = 0, side_cand = 0;
   // Jacobian rows: lane = (contact slot 0..2, dof); the slot's contact data is fetched from its owner lane
   const int cl = lane / JNV, k = lane - cl * JNV;
   const bool dofok = cl < 3 && k < nv;
@@ -601,21 +645,65 @@ JDEV void stage_contact_rows(const JacoModelDev* m, L& s, int lane, unsigned& fl
       if (dim > 1) R = fmaxf(JMINVAL, 2.f * mu0 * mu0 * R);
       dinv = 1.f / R;
     }
-    const int end = rowbase + wave_scan_incl(nrow, lane);
+    // which contacts could live in the side buffer: dof support = the pedestal block alone, at most 4 rows; usable when they number at most
+    // JSIDE_ROWS rows and no other contact reaches into that block (every tier counts them: "would the light tier cope?" needs the number)
+    const unsigned mm = cm1 | cm2;
+    bool sidec = false;
+    if (JNV - JB1 == 6 && cb == 0) {
+      const bool only2 = lane < nhere && mm != 0u && (mm & ((1u << JB1) - 1u)) == 0u && nrow <= 4;
+      const bool reach2 = lane < nhere && !only2 && (mm >> JB1) != 0u;
+      const unsigned long long o2 = wave_ballot(only2);
+      if (o2 != 0ull && wave_ballot(reach2) == 0ull && ncon <= 64) {
+        int srows = 0;   // (a handful of contacts: serial over the set bits, wave-uniform)
+        for (unsigned long long b = o2; b; b &= b - 1ull) srows += wave_bcast_i(nrow, ffs64(b));
+        if (srows <= JSIDE_ROWS) { side_cand = srows; sidec = only2; }
+      }
+    }
+    int end = rowbase + wave_scan_incl(nrow, lane);
+    bool split = false;
+    int r0s = 0;
+    if (SIDE && side_cand > 0 && wave_bcast_i(end, nhere - 1) > MAXEFC && wave_bcast_i(end, nhere - 1) - side_cand <= MAXEFC) {
+      // the rows do not fit the main buffer, and they do without the pedestal's: split
+      split = true;
+      end = rowbase + wave_scan_incl(sidec ? 0 : nrow, lane);
+      r0s = JSIDE_BASE + wave_scan_incl(sidec ? nrow : 0, lane) - nrow;
+      nside = side_cand;
+    }
+    sidec = sidec && split;
     const unsigned long long fm = wave_ballot(lane < nhere && end <= MAXEFC);
     const int kept = popc64(fm);   // row offsets are monotone, so the contacts that fit form a prefix
     int total = wave_bcast_i(end, kept > 0 ? kept - 1 : 0);
     total = kept > 0 ? total : rowbase;
-    const int r0 = end - nrow;
+    const int r0 = sidec ? r0s : end - nrow;
     if (lane < kept) {
       s.c_efc[ci] = r0;
-      unsigned mm = cm1 | cm2;
       int blk = ((mm & ((1u << JB0) - 1u)) ? 1 : 0) | (((mm >> JB0) & ((1u << (JB1 - JB0)) - 1u)) ? 2 : 0) | ((mm >> JB1) ? 4 : 0);
-      for (int e = 0; e < nrow; e++) {
+      if (!sidec) for (int e = 0; e < nrow; e++) {
         s.e_con[r0 + e] = ci | (e << 8) | (blk << 16);
         s.e_f[r0 + e] = e < 4 ? mu0 : (e < 6 ? mu1 : mu2);   // friction of the row's pyramid edge (e_f is free until the solver runs)
       }
       pa0[ci] = a0; pbc[ci] = bcoef; s.c_fn[ci] = dinv;
+    }
+    wave_sync();   // e_con, the per-contact parameters and the row maps are visible
+    // per-row parameters of this chunk's main rows, lane = row (before the Jacobian rows: in split mode those overwrite cvel)
+    for (int rr = rowbase + lane; rr < total; rr += 64) {
+      const int ce = s.e_con[rr], c = ce & 255, e = (ce >> 8) & 255;
+      const float vel = contact_row_vel(s, c, e, s.e_f[rr]);
+      s.e_aref[rr] = pa0[c] - pbc[c] * vel;
+      s.e_D[rr] = s.c_fn[c];
+    }
+    // ... and of the side rows, by their contact's own lane, into registers (the side buffer overlays cvel, which is still being read)
+    float aside[4] = {0.f, 0.f, 0.f, 0.f};
+    if (SIDE && sidec && lane < kept) {
+#pragma unroll
+      for (int e = 0; e < 4; e++) if (e < nrow) aside[e] = a0 - bcoef * contact_row_vel(s, ci, e, mu0);
+    }
+    if (SIDE && split) {
+      wave_sync();   // every read of cvel / cdof[6..] of this stage is done: the side buffer may be written
+      if (sidec && lane < kept) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) if (e < nrow) { sd[JSIDE_AREF + r0 - JSIDE_BASE + e] = aside[e]; sd[JSIDE_D + r0 - JSIDE_BASE + e] = dinv; }
+      }
     }
     for (int c0 = 0; c0 < kept; c0 += 3) {
       int c = c0 + (cl < 3 ? cl : 0);
@@ -623,7 +711,8 @@ JDEV void stage_contact_rows(const JacoModelDev* m, L& s, int lane, unsigned& fl
       int cdim = wave_shfl_i(dim, src), cr0 = wave_shfl_i(r0, src);
       float f0 = wave_shfl(mu0, src), f1 = wave_shfl(mu1, src), f2 = wave_shfl(mu2, src);
       unsigned a1 = (unsigned)wave_shfl_i((int)cm1, src), a2 = (unsigned)wave_shfl_i((int)cm2, src);
-      if (dofok && c < kept) {
+      const bool cside = SIDE && cr0 >= JSIDE_BASE;   // (side rows hold the pedestal block's six columns only: their other entries are zero by construction)
+      if (dofok && c < kept && (!cside || k >= JB1)) {
         float coef = (float)((int)((a2 >> k) & 1u) - (int)((a1 >> k) & 1u));
         v3 pos = ld3(s.c_pos[cb + c]);
         v3 jp = (S.b + cross(S.a, pos)) * coef, jr = S.a * coef;
@@ -631,15 +720,16 @@ JDEV void stage_contact_rows(const JacoModelDev* m, L& s, int lane, unsigned& fl
         float Jc[6];
 #pragma unroll
         for (int a = 0; a < 3; a++) { Jc[a] = dot(ld3(fr + 3 * a), jp); Jc[3 + a] = dot(ld3(fr + 3 * a), jr); }
-        float* Jw = s.J + cr0 * JLD + k;
+        const int ld = cside ? 6 : JLD;
+        float* Jw = cside ? sd + JSIDE_J + (cr0 - JSIDE_BASE) * 6 + (k - JB1) : s.J + cr0 * JLD + k;
         if (cdim == 1) Jw[0] = Jc[0];
         else {
-          Jw[0] = Jc[0] + f0 * Jc[1]; Jw[JLD] = Jc[0] - f0 * Jc[1];
-          Jw[2 * JLD] = Jc[0] + f0 * Jc[2]; Jw[3 * JLD] = Jc[0] - f0 * Jc[2];
+          Jw[0] = Jc[0] + f0 * Jc[1]; Jw[ld] = Jc[0] - f0 * Jc[1];
+          Jw[2 * ld] = Jc[0] + f0 * Jc[2]; Jw[3 * ld] = Jc[0] - f0 * Jc[2];
           if (cdim > 3) {
-            Jw[4 * JLD] = Jc[0] + f1 * Jc[3]; Jw[5 * JLD] = Jc[0] - f1 * Jc[3];
-            Jw[6 * JLD] = Jc[0] + f2 * Jc[4]; Jw[7 * JLD] = Jc[0] - f2 * Jc[4];
-            Jw[8 * JLD] = Jc[0] + f2 * Jc[5]; Jw[9 * JLD] = Jc[0] - f2 * Jc[5];
+            Jw[4 * ld] = Jc[0] + f1 * Jc[3]; Jw[5 * ld] = Jc[0] - f1 * Jc[3];
+            Jw[6 * ld] = Jc[0] + f2 * Jc[4]; Jw[7 * ld] = Jc[0] - f2 * Jc[4];
+            Jw[8 * ld] = Jc[0] + f2 * Jc[5]; Jw[9 * ld] = Jc[0] - f2 * Jc[5];
           }
         }
       }
@@ -648,35 +738,8 @@ JDEV void stage_contact_rows(const JacoModelDev* m, L& s, int lane, unsigned& fl
     if (kept < nhere) { flags |= JFLAG_EFC_OVERFLOW; break; }   // the row buffer is full: this contact and all later ones are dropped
   }
   const int total = rowbase;
-  wave_sync();  // every lane has read the incoming row / contact counts; J rows, e_con and the per-contact parameters are visible
-  if (lane == 0) { s.nefc = total; s.ncon = kept_total; }
-  // per-row parameters, lane = row
-  for (int rr = nlim + lane; rr < total; rr += 64) {
-    int ce = s.e_con[rr], c = ce & 255, e = (ce >> 8) & 255;
-    int pd = s.c_dim[c];
-    int kf = pd == 1 ? 0 : 1 + (e >> 1);
-    // row velocity J_row . qvel, taken from the two bodies' spatial velocities: the contact-frame components of the relative
-    // point velocity (k < 3) or relative angular velocity (k >= 3), combined as the pyramid edge  v_0 +- mu_k v_k
-    float vel;
-    {
-      int obs = s.c_ob[c], b1 = ((obs >> 8) & 0xFF) - 1, b2 = ((obs >> 24) & 0xFF) - 1;
-      sv v1, v2;
-      v1.a = v1.b = v2.a = v2.b = mk3(0.f, 0.f, 0.f);
-      if (b1 >= 0) v1 = ldsv(s.cvel[b1]);
-      if (b2 >= 0) v2 = ldsv(s.cvel[b2]);
-      v3 cp = ld3(s.c_pos[c]);
-      v3 dw = v2.a - v1.a, dv = (v2.b - v1.b) + cross(dw, cp);
-      const float* fr = s.c_frame[c];
-      vel = dot(ld3(fr), dv);
-      if (pd > 1) {
-        int ax = kf < 3 ? kf : kf - 3;
-        float comp = dot(ld3(fr + 3 * ax), kf < 3 ? dv : dw);
-        vel += ((e & 1) ? -1.f : 1.f) * s.e_f[rr] * comp;
-      }
-    }
-    s.e_aref[rr] = pa0[c] - pbc[c] * vel;
-    s.e_D[rr] = s.c_fn[c];
-  }
+  wave_sync();  // every lane has read the incoming row / contact counts; J rows and row parameters are visible
+  if (lane == 0) { s.nefc = total; s.ncon = kept_total; s.nside = nside; s.nside_cand = side_cand; }
 }
 
 // ---------------------------------------------------------------- stage T: touch sensors (env_mujoco_util.py:470-475 reads them)
@@ -736,7 +799,8 @@ JDEV void stage_touch(const JacoModelDev* m, L& s, int lane, float* sens) {
     int cd = s.c_dim[ci];
     int nrow = cd == 1 ? 1 : 2 * (cd - 1), r0 = s.c_efc[ci];
     float fn = 0.f;
-    for (int e = 0; e < nrow; e++) fn += s.e_f[r0 + e];
+    if (SideRows<L>::on && r0 >= JSIDE_BASE) { const float* sd = side_buf(s); for (int e = 0; e < nrow; e++) fn += sd[JSIDE_F + r0 - JSIDE_BASE + e]; }
+    else for (int e = 0; e < nrow; e++) fn += s.e_f[r0 + e];
     s.c_fn[ci] = fn;
   }
   wave_sync();

@@ -134,6 +134,10 @@ JDEV void wave_sleep() { __builtin_amdgcn_s_sleep(127); }   // ~8k cycles
 // compensated state update (physics_kernel.h, comp_add) need the rounded product itself as an operand.
 JDEV float fmul_rn(float a, float b) { return __fmul_rn(a, b); }
 
+// (the host emulator fills a workgroup's LDS with garbage here -- real LDS is not zeroed between workgroups -- so that a read of a
+// never-written word shows up in the CPU tests; no code on the device)
+#define JEMU_POISON(x)
+
 // Pin three already-loaded values in VGPRs here: keeps the optimiser from sinking their loads into a (divergent) branch.
 JDEV void keep_loaded(float& a, float& b, float& c) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c)); }
 

@@ -207,6 +207,7 @@ struct JacoLDS {
   };
   float e_x[C::MAXEFC > 64 ? C::MAXEFC : 1];    // heavy tier only: residuals staged for the MFMA pass (light reuses `smooth`)
   int ncon, nefc, ncand, nlimit, nsphere;      // (ncand: narrowphase candidates after the OBB cull; nsphere: bounding-sphere survivors before it)
+  int nside, nside_cand;                       // rows in the side buffer (light tier, split mode; collision.h) / rows that could go there (every tier)
   float task[JTASK_FLOATS];                    // (= JTASK_N of env_logic.h)
   float osc_qd[4];                              // target orientation quaternion of the current env step (constant over its substeps)
   // per-launch copy of the small, hot model tables (per-lane gathers from LDS instead of dependent global loads)
@@ -1154,6 +1155,91 @@ JDEV void stage_integrate_pos(const JacoModelDev* m, L& s, int lane) {
 #include "collision.h"
 #include "env_logic.h"
 
+// ---------------------------------------------------------------- stage S, side solve (light tier, split mode: collision.h "Side rows")
+// The pedestal block's sub-problem on its own: six dofs (lanes JB1 .. JNV-1), up to JSIDE_ROWS rows (lane = row), same primal Newton with
+// exact line search as stage_newton; the Hessian is built by a loop over the rows (a handful of rank-1 updates of a 6 x 6 matrix: not
+// worth a matrix-core pass).  Overwrites the block's entries of the main solve's output (there they are the unconstrained solution).
+template <class L>
+JDEV void newton_side(const JacoModelDev* m, L& s, const float (&mrow)[JNV], float smooth, int lane, NewtonOut& out) {
+  float* sd = side_buf(s);
+  int ns = wave_uniform_i(s.nside);
+  ns = ns < 0 ? 0 : (ns > JSIDE_ROWS ? JSIDE_ROWS : ns);
+  const int nv = m->nv;
+  const bool mine = lane >= JB1 && lane < JNV, vr = lane < ns;
+  const int kk = mine ? lane - JB1 : 0, rr = vr ? lane : 0;
+  float js[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) js[k] = vr ? sd[JSIDE_J + rr * 6 + k] : 0.f;
+  const float D = vr ? sd[JSIDE_D + rr] : 0.f, ar = vr ? sd[JSIDE_AREF + rr] : 0.f;
+  const float scale = 1.f / (m->meaninertia * (float)(nv > 1 ? nv : 1)), tol = m->tolerance;
+  wave_sync();   // (aref / D are in registers: their slots become the staging area of the loop)
+  float a = mine ? s.qacc_ws[lane] : 0.f;
+  float Ma = 0.f, x = 0.f;
+#pragma unroll
+  for (int j = 0; j < 6; j++) { const float aj = wave_bcast(a, JB1 + j); Ma += mrow[JB1 + j] * aj; x += js[j] * aj; }
+  Ma = mine ? Ma - smooth : 0.f;
+  x = vr ? x - ar : 0.f;
+  float jtf = 0.f;
+  int it = 0;
+  for (; it < m->iterations; it++) {
+    if (vr) { sd[JSIDE_F + lane] = x < 0.f ? D : 0.f; sd[JSIDE_AREF + lane] = x < 0.f ? -D * x : 0.f; }
+    wave_sync();
+    float h[JNV];
+#pragma unroll
+    for (int j = 0; j < JNV; j++) h[j] = (j >= JB1 && mine) ? mrow[j] : 0.f;
+    jtf = 0.f;
+    for (int r = 0; r < ns; r++) {
+      const float* Jr = sd + JSIDE_J + r * 6;
+      const float jk = Jr[kk], t = sd[JSIDE_F + r] * jk;
+      jtf += jk * sd[JSIDE_AREF + r];
+#pragma unroll
+      for (int j = 0; j < 6; j++) h[JB1 + j] += t * Jr[j];
+    }
+    wave_sync();
+    const float grad = mine ? Ma - jtf : 0.f;
+    const float gn = sqrtf(wave_sum(grad * grad));
+    if (gn * scale < tol) break;
+    const float p = ldl_block<JB1, JNV>(h, -grad, lane);
+    float Mp = 0.f, jp = 0.f;
+#pragma unroll
+    for (int j = 0; j < 6; j++) { const float pj = wave_bcast(p, JB1 + j); Mp += mrow[JB1 + j] * pj; jp += js[j] * pj; }
+    Mp = mine ? Mp : 0.f;
+    jp = vr ? jp : 0.f;
+    const float pMp = wave_sum(p * Mp), pMa = wave_sum(p * Ma);
+    float al = 0.f, lo = 0.f, hi = 3.0e38f, d10 = 0.f, dlo = 0.f, dhi = 0.f;
+    for (int ls = 0; ls < m->ls_iterations; ls++) {   // exact line search, as in stage_newton
+      const float xa = x + al * jp;
+      const float s1 = xa < 0.f ? D * xa * jp : 0.f, s2 = xa < 0.f ? D * jp * jp : 0.f;
+      const float d1 = pMa + al * pMp + wave_sum(s1), d2 = pMp + wave_sum(s2);
+      if (ls == 0) d10 = fabsf(d1);
+      if (ls > 0 && fabsf(d1) <= 1e-6f * d10) break;
+      if (d1 < 0.f) { lo = al; dlo = -d1; } else { hi = al; dhi = d1; }
+      if (hi < 1.0e38f && fmaxf(dlo, dhi) * (hi - lo) * scale < 1e-3f * tol) break;
+      float nx = al - d1 / d2;
+      if (!(nx > lo && nx < hi)) nx = hi < 1.0e38f ? 0.5f * (lo + hi) : 2.f * al + 1.f;
+      if (nx == al) break;
+      al = nx;
+    }
+    const float dx = al * jp, xn = x + dx;
+    const bool was = x < 0.f, is = xn < 0.f;
+    const float dc = (was && is) ? 0.5f * D * dx * (2.f * x + dx) : (is ? 0.5f * D * xn * xn : (was ? -0.5f * D * x * x : 0.f));
+    x = xn;
+    const float improvement = -(al * pMa + 0.5f * al * al * pMp + wave_sum(dc));
+    a += al * p; Ma += al * Mp;
+    if (improvement * scale < tol) { it++; break; }
+  }
+  // row forces (touch stage) and J^T f of the block
+  const float f = x < 0.f ? -D * x : 0.f;
+  wave_sync();
+  if (vr) sd[JSIDE_F + lane] = f;
+  wave_sync();
+  float qf = 0.f;
+  for (int r = 0; r < ns; r++) qf += sd[JSIDE_J + r * 6 + kk] * sd[JSIDE_F + r];
+  out.qacc = mine ? a : out.qacc;
+  out.qfrc_con = mine ? qf : out.qfrc_con;
+  if (it > (out.iters & 255)) out.iters = (out.iters & ~255) | (it & 255);
+}
+
 // Append `env` to tier queue `t` from inside a running launch.  Everything the consumer will read (state rows, task row,
 // remaining, ...) must already have gone out with write-through stores; the entry is published after they are acknowledged.
 JDEV void queue_push(const JacoStepArgs& A, int t, int env, int left, int lane) {
@@ -1189,6 +1275,7 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
   if (lane < nv) { s.qvel[lane] = A.qvel[(size_t)env * nv + lane]; s.qacc_ws[lane] = A.qacc_ws[(size_t)env * nv + lane]; s.qvel_lo[lane] = A.qvel_lo ? A.qvel_lo[(size_t)env * nv + lane] : 0.f; }
   if (lane < nu) s.ctrl[lane] = A.ctrl[(size_t)env * nu + lane];
   stage_model(m, s, lane);
+  if (lane == 0) { s.ncon = 0; s.nefc = 0; s.ncand = 0; s.nlimit = 0; s.nsphere = 0; s.nside = 0; s.nside_cand = 0; }   // (LDS is not zeroed between workgroups)
   unsigned flags = LIGHT ? 0u : JFLAG_HEAVY_TIER;
   float sens = 0.f;
   int iters = 0, left = 0, sub0 = 0, nls_last = 0, calm = 0;
@@ -1415,14 +1502,16 @@ again:
       JSTAMP(5);
     } else {
       stage_limit_rows(m, s, lane, pf);
-      if (lane == 0) { s.ncon = 0; s.ncand = 0; s.nsphere = 0; }
+      if (lane == 0) { s.ncon = 0; s.ncand = 0; s.nsphere = 0; s.nside = 0; s.nside_cand = 0; }
       wave_sync();
     }
     if (!LIGHT) {   // would the tier below have coped with this substep?  (huge -> heavy, heavy -> medium, medium -> light)
       constexpr int LCON = TIER == 3 ? JacoHeavy::MAXCON : (TIER == 2 ? JacoMedium::MAXCON : JacoLight::MAXCON);
       constexpr int LEFC = TIER == 3 ? JacoHeavy::MAXEFC : (TIER == 2 ? JacoMedium::MAXEFC : JacoLight::MAXEFC);
       constexpr int LCAND = TIER == 3 ? JacoHeavy::MAXCAND : (TIER == 2 ? JacoMedium::MAXCAND : JacoLight::MAXCAND);
-      const bool fits = s.ncon <= LCON && s.nefc <= LEFC && s.nsphere <= LCAND;   // (head room below the capacity was tried: no gain)
+      // (the light tier also copes when the rows fit without the pedestal's, which it solves on the side: collision.h "Side rows")
+      const bool rows_fit = s.nefc <= LEFC || (TIER == 1 && SideRows<JacoLDS<JacoLight>>::on && s.nside_cand > 0 && s.nefc - s.nside_cand <= LEFC);
+      const bool fits = s.ncon <= LCON && rows_fit && s.nsphere <= LCAND;   // (head room below the capacity was tried: no gain)
       calm = fits ? calm + 1 : 0;
       if (!fits && !tier_used) { tier_used = true; if (A.hint_mode != 2) hint_raise(A, env, TIER, lane); }
     }
@@ -1450,6 +1539,7 @@ again:
     wave_sync();
     const float hdamp = (m->has_damping && lane < nv) ? m->timestep * pf.damping : 0.f;
     NewtonOut nw = stage_newton(m, s, mrow, smooth, hdamp, lane, pc);
+    if (SideRows<JacoLDS<C>>::on) { if (wave_uniform_i(s.nside) > 0) newton_side(m, s, mrow, smooth, lane, nw); }
     JSTAMP(6);
     iters = nw.iters & 255;
     int nls_dbg = nw.iters >> 8;
@@ -1485,7 +1575,7 @@ again:
         D[JDBG_BIAS + lane] = s.bias[lane]; D[JDBG_SMOOTH + lane] = smooth; D[JDBG_QACC_SMOOTH + lane] = qas;
         D[JDBG_QACC + lane] = nw.qacc; D[JDBG_QFRC_CON + lane] = nw.qfrc_con;
       }
-      if (lane == 0) { D[JDBG_NCON] = (float)s.ncon; D[JDBG_NCON + 1] = (float)s.nefc; D[JDBG_NCON + 2] = (float)iters; D[JDBG_NCON + 3] = (float)s.ncand; }
+      if (lane == 0) { D[JDBG_NCON] = (float)s.ncon; D[JDBG_NCON + 1] = (float)(s.nefc + s.nside); D[JDBG_NCON + 2] = (float)iters; D[JDBG_NCON + 3] = (float)s.ncand; }
       for (int c = lane; c < s.ncon && c < JDBG_MAXCON; c += 64) {
         float* o = D + JDBG_CONTACT + 8 * c;
         o[0] = s.c_dist[c]; o[1] = s.c_pos[c][0]; o[2] = s.c_pos[c][1]; o[3] = s.c_pos[c][2];
@@ -1698,12 +1788,13 @@ again:
   }
   if (!LIGHT && left == 0 && nsub > 0 && lane == 0 && A.hint && A.hint_mode == 2) {   // the tier the state the next step starts from needs
     const int nc = s.ncon, ne = s.nefc, ns = s.nsphere;
-    A.hint[env] = (nc <= JacoLight::MAXCON && ne <= JacoLight::MAXEFC && ns <= JacoLight::MAXCAND) ? 0
+    const bool light_rows = ne <= JacoLight::MAXEFC || (SideRows<JacoLDS<JacoLight>>::on && s.nside_cand > 0 && ne - s.nside_cand <= JacoLight::MAXEFC);
+    A.hint[env] = (nc <= JacoLight::MAXCON && light_rows && ns <= JacoLight::MAXCAND) ? 0
                 : ((nc <= JacoMedium::MAXCON && ne <= JacoMedium::MAXEFC && ns <= JacoMedium::MAXCAND) ? 1
                 : ((nc <= JacoHeavy::MAXCON && ne <= JacoHeavy::MAXEFC && ns <= JacoHeavy::MAXCAND) ? 2 : 3));
   }
   if (left == 0 && lane == 0 && A.stats) {
-    A.stats[4 * env] = s.ncon; A.stats[4 * env + 1] = s.nefc; A.stats[4 * env + 2] = iters; A.stats[4 * env + 3] = s.ncand | (nls_last << 16);
+    A.stats[4 * env] = s.ncon; A.stats[4 * env + 1] = s.nefc + s.nside; A.stats[4 * env + 2] = iters; A.stats[4 * env + 3] = s.ncand | (nls_last << 16);
   }
   wave_sync();
   if (why) *why = left <= 0 ? 0 : (bailed ? 1 : 2);
@@ -1743,12 +1834,14 @@ JDEV void light_grid(const JacoStepArgs& A, JacoLDS<JacoLight>& s) {
 }
 __global__ __launch_bounds__(64, JACO_LIGHT_WAVES) void jaco_physics_kernel(JacoStepArgs A) {   // modes 0 and 1 only
   __shared__ JacoLDS<JacoLight> s;
+  JEMU_POISON(s);
   light_grid<false>(A, s);
 }
 // the full code under its own name for reset-time launches (forward pass, placing hold; for a masked reset a small grid that walks
 // the list of reset envs): the step kernel's launch statistics (rocprofv3 --stats, bench.py's kernel_ms) then hold step launches only
 __global__ __launch_bounds__(64, JACO_LIGHT_WAVES) void jaco_physics_kernel_listed(JacoStepArgs A) {   // every mode
   __shared__ JacoLDS<JacoLight> s;
+  JEMU_POISON(s);
   light_grid<true>(A, s);
 }
 // One handed-over env on a bigger-tier workgroup: the big code (medium: TB = 1, heavy: TB = 2) runs while the overflow
@@ -1907,28 +2000,34 @@ JDEV void tier_drain(const JacoStepArgs& A, LDS& u, int lane) {
 __global__ __launch_bounds__(64, 2) void jaco_physics_kernel_medium(JacoStepArgs A) {
   __builtin_amdgcn_s_setprio(1);
   __shared__ JacoMediumLDS u;
+  JEMU_POISON(u);
   tier_workers<0>(A, u, lane_id());
 }
 __global__ __launch_bounds__(64, 2) void jaco_physics_kernel_medium_drain(JacoStepArgs A) {
   __shared__ JacoMediumLDS u;
+  JEMU_POISON(u);
   tier_drain<0>(A, u, lane_id());
 }
 __global__ __launch_bounds__(64, JACO_HEAVY_WAVES) void jaco_physics_kernel_heavy_workers(JacoStepArgs A) {
   __builtin_amdgcn_s_setprio(2);
   __shared__ JacoAllLDS u;
+  JEMU_POISON(u);
   tier_workers<1>(A, u, lane_id());
 }
 __global__ __launch_bounds__(64, JACO_HEAVY_WAVES) void jaco_physics_kernel_heavy_drain(JacoStepArgs A) {
   __shared__ JacoAllLDS u;
+  JEMU_POISON(u);
   tier_drain<1>(A, u, lane_id());
 }
 __global__ __launch_bounds__(64) void jaco_physics_kernel_huge_workers(JacoStepArgs A) {
   __builtin_amdgcn_s_setprio(3);
   __shared__ JacoHugeLDS u;
+  JEMU_POISON(u);
   tier_workers<2>(A, u, lane_id());
 }
 __global__ __launch_bounds__(64) void jaco_physics_kernel_huge_drain(JacoStepArgs A) {
   __builtin_amdgcn_s_setprio(3);
   __shared__ JacoHugeLDS u;
+  JEMU_POISON(u);
   tier_drain<2>(A, u, lane_id());
 }

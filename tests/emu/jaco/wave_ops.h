@@ -33,6 +33,8 @@ JDEV void wave_sleep() {}
 JDEV unsigned long long wave_clock() { return 0ull; }
 JDEV int wave_uniform_i(int v) { return wave_bcast_i(v, 0); }
 JDEV void keep_loaded(float&, float&, float&) {}
+// real LDS is not zeroed between workgroups: fill it with garbage (0x7f7f7f7f: 3.4e38 as a float, 2 139 062 143 as an int) before the kernel body runs
+#define JEMU_POISON(x) do { if (emu_cur_lane == 0) memset((void*)&(x), 0x7f, sizeof(x)); emu_collective(); } while (0)
 JDEV float fmul_rn(float a, float b) { volatile float p = a * b; return p; }
 JDEV int wave_opaque_i(int v) { return v; }
 JDEV float wave_shfl(float v, int src) { int p = emu_post_f(v); emu_collective(); return emu_x[p][src & 63].f; }

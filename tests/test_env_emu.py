@@ -410,3 +410,30 @@ def test_auto_reset_forward_pass_survives_a_tier_hand_off(names, model_arrays, s
     assert eb.flags[0] & 32 and ea.flags[0] & 32                                       # both forward passes left the light tier
     assert np.array_equal(oa, ob) and np.array_equal(ea.qpos, eb.qpos) and np.array_equal(ea.task, eb.task) and np.array_equal(ea.cache, eb.cache)
     assert ea.task[0, 39] == 0 and ea.task[0, 19] == 0 and ea.task[0, 17] == 0          # forward pass done, nothing pending
+
+
+def test_side_rows_keep_a_68_row_env_in_the_light_tier(names, model_arrays):
+    """Light tier, split mode (csrc/collision.h "Side rows"): object on holder (16 rows) + pedestal on floor (16) + the EE's axis sticks on
+    the "hand" marker's sticks bring a step to 68-72 rows -- more than the 64-row main buffer.  The pedestal's rows go to the side buffer
+    and are solved by the side Newton solve; the env stays in the light tier (no tier flag) and matches the oracle env like any other."""
+    seen = 0
+    for seed in (4, 6):
+        fs = 10
+        e = EmuJacoEnv(frame_skip=fs); oe = OracleEnv(names, frame_skip=fs)
+        q = workload.reset_states(model_arrays["qpos0"], 1, seed=seed, f32_draws=True)[0]
+        oe.obj_goal = q[9:12].copy(); oe.dest_goal = np.array([q[16], q[17], 0.3468]).astype(np.float32).astype(np.float64)
+        oe.set_state(q)
+        e.qpos[0] = q; e.task[0, 4:7] = oe.obj_goal; e.task[0, 7:10] = oe.dest_goal
+        rng = np.random.default_rng(seed)
+        nz = rng.uniform(size=(1, 12)).astype(np.float32)
+        e.forward(nz); oe.observe(nz[0, 6:].astype(np.float64))
+        for step in range(4):
+            a = (rng.uniform(-1, 1, 7) * 0.05).astype(np.float32); nz = rng.uniform(size=(1, 12)).astype(np.float32)
+            e.flags[:] = 0
+            obs, rew, done = e.env_step(a, nz)
+            oo, orew, odone, _ = oe.step(a.astype(np.float64), nz[0].astype(np.float64))
+            assert (e.stats[0, 0], e.stats[0, 1]) == (oe.o.ncon, oe.o.nefc)                 # contacts / rows (main + side) as the oracle counts them
+            assert np.abs(obs[0] - oo).max() < 2e-6 and np.abs(e.qpos[0] - oe.o.get("qpos")).max() < 2e-6 and abs(rew[0] - orew) < 1e-5
+            if 64 < e.stats[0, 1] <= 80 and not (e.flags[0] & 32):
+                seen += 1                                                                    # more rows than the main buffer holds, and no bigger tier was used
+    assert seen >= 2

@@ -8,7 +8,8 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 task = sys.argv[3] if len(sys.argv) > 3 else "picking"
 scale = float(sys.argv[4]) if len(sys.argv) > 4 else 1.0   # actions are U(-1, 1) times this
-env = JacoBatchedEnv(num_envs=B, task=task, seed=7)
+auto = "--auto-reset" in sys.argv                            # reset inside jaco_step (option auto_reset) instead of a masked jaco_reset per step
+env = JacoBatchedEnv(num_envs=B, task=task, seed=7, auto_reset=auto)
 env.reset()
 gen = torch.Generator(device=env.device); gen.manual_seed(1)
 ndone = nsucc = 0
@@ -20,7 +21,8 @@ for s in range(n):
     bad += int((~torch.isfinite(obs).all(1)).sum()) + int((~torch.isfinite(rew)).sum())
     if done.any():
         ndone += int(done.sum()); nsucc += int(env.success_flags()[done].sum()) if hasattr(env, "success_flags") else 0
-        env.reset(done)
+        if not env.auto_reset:
+            env.reset(done)
     if s % 50 == 49:
         fl = env.sim.flags()
         print("step %4d  %.1f ms/step  episodes ended %d  non-finite %d  flags: nan %d con-ovf %d efc-ovf %d cand-ovf %d maxiter %d" % (
