@@ -123,124 +123,174 @@ JDEV void collide_plane_convex(const JacoStepArgs& A, const JacoModelDev* m, L& 
 }
 
 // ---------------------------------------------------------------- box-box
+// Up to four pairs per pass, one 16-lane row each (the EE's axis sticks on the hand marker's sticks alone are nine pairs, and they come
+// in a row in pair order): row lane a < 15 tests one separating axis (a < 6: face axes, else edge axis A[i] x B[j]); the clipping
+// candidates of a face contact are produced in two rounds, lanes 0..3 incident vertices + lanes 4..7 reference corners, then all 16
+// lanes one edge crossing each.  Contacts come out row by row, within a row in candidate order (vertices, corners, crossings).
+// Row r handles candidate cbase + r of the list; lane c of the A-arrays holds candidate c's pair index, code and contact bookkeeping.
 template <class L>
-JDEV void collide_box_box(const JacoModelDev* m, L& s, int g1, int g2, int pair, int lane, int& ncon, unsigned& flags) {
+JDEV void collide_box_box4(const JacoModelDev* m, L& s, int cbase, int nrows, int pkA, int codeA, unsigned m1A, unsigned m2A, int obA, int dimA,
+                           int lane, int& ncon, unsigned& flags) {
+  constexpr int MAXCON = L::Caps::MAXCON;
+  const int g = lane >> 4, a = lane & 15, rb = lane & 48;
+  const bool slot = g < nrows;
+  const int src = cbase + (slot ? g : 0);
+  const int code = wave_shfl_i(codeA, src), pair = wave_shfl_i(pkA, src);
+  const unsigned pm1 = (unsigned)wave_shfl_i((int)m1A, src), pm2 = (unsigned)wave_shfl_i((int)m2A, src);
+  const int pob = wave_shfl_i(obA, src), pdim = wave_shfl_i(dimA, src);
+  const int g1 = code & 255, g2 = (code >> 8) & 255;
   GeomPose P1 = geom_pose(s, g1), P2 = geom_pose(s, g2);
   float s1[3] = {m->g_size[g1][0], m->g_size[g1][1], m->g_size[g1][2]}, s2[3] = {m->g_size[g2][0], m->g_size[g2][1], m->g_size[g2][2]};
   v3 Aa[3] = {col(P1.R, 0), col(P1.R, 1), col(P1.R, 2)}, Ba[3] = {col(P2.R, 0), col(P2.R, 1), col(P2.R, 2)};
   v3 pp = P2.p - P1.p;
-  // lane a < 6: face axis; 6 <= a < 15: edge axis A[i] x B[j]
-  int a = lane < 15 ? lane : 0;
-  int ei = a >= 6 ? (a - 6) / 3 : (a < 3 ? a : 0), ej = a >= 6 ? (a - 6) % 3 : (a >= 3 ? a - 3 : 0);
+  const int ai = a < 15 ? a : 0;
+  int ei = ai >= 6 ? (ai - 6) / 3 : (ai < 3 ? ai : 0), ej = ai >= 6 ? (ai - 6) % 3 : (ai >= 3 ? ai - 3 : 0);
   // (selects instead of runtime-indexed arrays: those would live in scratch memory)
   v3 Ai = ei == 0 ? Aa[0] : (ei == 1 ? Aa[1] : Aa[2]), Bj = ej == 0 ? Ba[0] : (ej == 1 ? Ba[1] : Ba[2]);
-  v3 ax = a < 3 ? Ai : (a < 6 ? Bj : cross(Ai, Bj));
+  v3 ax = ai < 3 ? Ai : (ai < 6 ? Bj : cross(Ai, Bj));
   float len = norm(ax);
-  bool degenerate = a >= 6 && len < 1e-6f;
+  bool degenerate = ai >= 6 && len < 1e-6f;
   ax = ax * (1.f / fmaxf(len, 1e-30f));
   float ra = s1[0] * fabsf(dot(ax, Aa[0])) + s1[1] * fabsf(dot(ax, Aa[1])) + s1[2] * fabsf(dot(ax, Aa[2]));
-  float rb = s2[0] * fabsf(dot(ax, Ba[0])) + s2[1] * fabsf(dot(ax, Ba[1])) + s2[2] * fabsf(dot(ax, Ba[2]));
-  float dp = dot(pp, ax), pen = ra + rb - fabsf(dp);
-  bool mine = lane < 15 && !degenerate;
-  if (wave_ballot(mine && pen < 0.f)) return;  // separated
+  float rb_ = s2[0] * fabsf(dot(ax, Ba[0])) + s2[1] * fabsf(dot(ax, Ba[1])) + s2[2] * fabsf(dot(ax, Ba[2]));
+  float dp = dot(pp, ax), pen = ra + rb_ - fabsf(dp);
+  bool mine = slot && a < 15 && !degenerate;
+  const unsigned long long sepm = wave_ballot(mine && pen < 0.f);
+  const bool alive = slot && ((sepm >> rb) & 0xffffull) == 0ull;   // no separating axis in my row
+  if (wave_ballot(alive) == 0ull) return;
   float fbest, ebest;
-  int fcode = wave_argmax(lane < 6 ? -pen : -3.0e38f, lane, &fbest);
-  int ecode = wave_argmax((lane >= 6 && mine) ? -pen : -3.0e38f, lane, &ebest);
+  int fcode = row_argmax(a < 6 ? -pen : -3.0e38f, a, &fbest);
+  int ecode = row_argmax((a >= 6 && mine) ? -pen : -3.0e38f, a, &ebest);
   fbest = -fbest; ebest = -ebest;
-  bool edge = ebest < 1.0e38f && ebest * 1.05f < fbest;
-  if (edge) {
-    int i = (ecode - 6) / 3, j = (ecode - 6) % 3;
-    float sgn = wave_bcast(dp, ecode) < 0.f ? -1.f : 1.f;
-    v3 n = mk3(wave_bcast(ax.x, ecode), wave_bcast(ax.y, ecode), wave_bcast(ax.z, ecode)) * sgn;
+  const bool edge = ebest < 1.0e38f && ebest * 1.05f < fbest;
+  // up to two contacts per lane: (h1, d1, x1) from the first candidate round (or the row's edge contact, on its lane 0), (h2, d2, x2) from the second
+  bool h1 = false, h2 = false;
+  float d1 = 0.f, d2 = 0.f;
+  v3 x1 = mk3(0, 0, 0), x2 = mk3(0, 0, 0), nrm = mk3(0, 0, 1.f);
+  if (wave_ballot(alive && edge)) {
+    const int ec = edge ? ecode : 6;
+    const int i = (ec - 6) / 3, j = (ec - 6) % 3;
+    float sgn = wave_shfl(dp, rb + ec) < 0.f ? -1.f : 1.f;
+    v3 n = mk3(wave_shfl(ax.x, rb + ec), wave_shfl(ax.y, rb + ec), wave_shfl(ax.z, rb + ec)) * sgn;
     v3 ea = P1.p, eb = P2.p;
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-      if (k != i) ea = ea + Aa[k] * (dot(n, Aa[k]) > 0.f ? s1[k] : -s1[k]);
-      if (k != j) eb = eb + Ba[k] * (dot(n, Ba[k]) > 0.f ? -s2[k] : s2[k]);
+      const v3 ea2 = ea + Aa[k] * (dot(n, Aa[k]) > 0.f ? s1[k] : -s1[k]), eb2 = eb + Ba[k] * (dot(n, Ba[k]) > 0.f ? -s2[k] : s2[k]);
+      if (k != i) ea = ea2;
+      if (k != j) eb = eb2;
     }
     v3 ua = i == 0 ? Aa[0] : (i == 1 ? Aa[1] : Aa[2]), ub = j == 0 ? Ba[0] : (j == 1 ? Ba[1] : Ba[2]);
     v3 r = eb - ea;
     float uv = dot(ua, ub), du = dot(r, ua), dv = dot(r, ub), den = 1.f - uv * uv;
     float sa = den > 1e-12f ? (du - uv * dv) / den : 0.f, tb = den > 1e-12f ? (uv * du - dv) / den : 0.f;
-    v3 pos = ((ea + ua * sa) + (eb + ub * tb)) * 0.5f;
-    push_contacts(s, lane == 0, -ebest, pos, n, pair, ncon, flags, 1);
-    return;
-  }
-  // face contact: reference box (axis ia), incident box
-  bool refis1 = fcode < 3;
-  int ia = refis1 ? fcode : fcode - 3;
-  float bsign = wave_bcast(dp, fcode) < 0.f ? -1.f : 1.f;
-  v3 RA[3], IA[3];
-  float rs[3], is[3];
-#pragma unroll
-  for (int k = 0; k < 3; k++) { RA[k] = refis1 ? Aa[k] : Ba[k]; IA[k] = refis1 ? Ba[k] : Aa[k]; rs[k] = refis1 ? s1[k] : s2[k]; is[k] = refis1 ? s2[k] : s1[k]; }
-  v3 rp = refis1 ? P1.p : P2.p, ip = refis1 ? P2.p : P1.p;
-  // rotate so that the reference axis is index 0 (ia), then iu, iv
-  v3 Rn = ia == 0 ? RA[0] : (ia == 1 ? RA[1] : RA[2]);
-  v3 Ru = ia == 0 ? RA[1] : (ia == 1 ? RA[2] : RA[0]);
-  v3 Rv = ia == 0 ? RA[2] : (ia == 1 ? RA[0] : RA[1]);
-  float rn = ia == 0 ? rs[0] : (ia == 1 ? rs[1] : rs[2]);
-  float a_ = ia == 0 ? rs[1] : (ia == 1 ? rs[2] : rs[0]);
-  float b_ = ia == 0 ? rs[2] : (ia == 1 ? rs[0] : rs[1]);
-  v3 nref = Rn * (refis1 ? bsign : -bsign);
-  // incident face: most anti-parallel to nref (first index wins ties)
-  float d0 = dot(IA[0], nref), d1 = dot(IA[1], nref), d2 = dot(IA[2], nref);
-  int ib = 0;
-  float mind = -fabsf(d0);
-  if (-fabsf(d1) < mind) { mind = -fabsf(d1); ib = 1; }
-  if (-fabsf(d2) < mind) { mind = -fabsf(d2); ib = 2; }
-  float dd = ib == 0 ? d0 : (ib == 1 ? d1 : d2), isg = dd > 0.f ? -1.f : 1.f;
-  v3 In = ib == 0 ? IA[0] : (ib == 1 ? IA[1] : IA[2]);
-  v3 Iu = ib == 0 ? IA[1] : (ib == 1 ? IA[2] : IA[0]);
-  v3 Iv = ib == 0 ? IA[2] : (ib == 1 ? IA[0] : IA[1]);
-  float in_ = ib == 0 ? is[0] : (ib == 1 ? is[1] : is[2]);
-  float iu_ = ib == 0 ? is[1] : (ib == 1 ? is[2] : is[0]);
-  float iv_ = ib == 0 ? is[2] : (ib == 1 ? is[0] : is[1]);
-  v3 fc = ip + In * (isg * in_);
-  v3 rel = fc - rp;
-  v3 c2 = mk3(dot(rel, Ru), dot(rel, Rv), dot(rel, nref) - rn);
-  v3 eu = mk3(dot(Iu, Ru), dot(Iu, Rv), dot(Iu, nref)) * iu_;
-  v3 ev = mk3(dot(Iv, Ru), dot(Iv, Rv), dot(Iv, nref)) * iv_;
-  // candidate points: lanes 0..3 incident vertices, 4..7 reference corners, 8..23 edge crossings (k*4+e)
-  const float sgx[4] = {-1.f, 1.f, 1.f, -1.f}, sgy[4] = {-1.f, -1.f, 1.f, 1.f};
-  bool have = false;
-  v3 pt = mk3(0, 0, 0);
-  int k = lane < 8 ? (lane & 3) : ((lane - 8) >> 2) & 3;
-  float kx = k == 0 ? sgx[0] : (k == 1 ? sgx[1] : (k == 2 ? sgx[2] : sgx[3]));
-  float ky = k == 0 ? sgy[0] : (k == 1 ? sgy[1] : (k == 2 ? sgy[2] : sgy[3]));
-  int k1 = (k + 1) & 3;
-  float k1x = k1 == 0 ? sgx[0] : (k1 == 1 ? sgx[1] : (k1 == 2 ? sgx[2] : sgx[3]));
-  float k1y = k1 == 0 ? sgy[0] : (k1 == 1 ? sgy[1] : (k1 == 2 ? sgy[2] : sgy[3]));
-  v3 q0 = c2 + eu * kx + ev * ky, q1 = c2 + eu * k1x + ev * k1y;
-  if (lane < 4) {
-    have = fabsf(q0.x) <= a_ && fabsf(q0.y) <= b_;
-    pt = q0;
-  } else if (lane < 8) {
-    float det = eu.x * ev.y - eu.y * ev.x;
-    if (fabsf(det) > 1e-14f) {
-      float x = kx * a_ - c2.x, y = ky * b_ - c2.y;
-      float al = (x * ev.y - y * ev.x) / det, be = (eu.x * y - eu.y * x) / det;
-      have = fabsf(al) < 1.f && fabsf(be) < 1.f;
-      pt = mk3(kx * a_, ky * b_, c2.z + al * eu.z + be * ev.z);
+    if (alive && edge) {
+      h1 = a == 0; d1 = -ebest; nrm = n;
+      x1 = ((ea + ua * sa) + (eb + ub * tb)) * 0.5f;
     }
-  } else if (lane < 24) {
-    int e = (lane - 8) & 3, axn = e & 1;
-    float lim = ((e & 2) ? 1.f : -1.f) * (axn ? b_ : a_), other = axn ? a_ : b_;
-    float q0a = axn ? q0.y : q0.x, q1a = axn ? q1.y : q1.x, q0o = axn ? q0.x : q0.y, q1o = axn ? q1.x : q1.y;
-    float e0 = q0a - lim, e1 = q1a - lim;
-    if (!((e0 < 0.f) == (e1 < 0.f) || e0 == e1)) {
-      float t = e0 / (e0 - e1);
-      float o = q0o + t * (q1o - q0o);
-      if (t > 0.f && t < 1.f && fabsf(o) < other) {
-        have = true;
-        pt = axn ? mk3(o, lim, q0.z + t * (q1.z - q0.z)) : mk3(lim, o, q0.z + t * (q1.z - q0.z));
+  }
+  if (wave_ballot(alive && !edge)) {
+    // face contact: reference box (axis ia), incident box
+    bool refis1 = fcode < 3;
+    int ia = refis1 ? fcode : fcode - 3;
+    float bsign = wave_shfl(dp, rb + fcode) < 0.f ? -1.f : 1.f;
+    v3 RA[3], IA[3];
+    float rs[3], is[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { RA[k] = refis1 ? Aa[k] : Ba[k]; IA[k] = refis1 ? Ba[k] : Aa[k]; rs[k] = refis1 ? s1[k] : s2[k]; is[k] = refis1 ? s2[k] : s1[k]; }
+    v3 rp = refis1 ? P1.p : P2.p, ip = refis1 ? P2.p : P1.p;
+    // rotate so that the reference axis is index 0 (ia), then iu, iv
+    v3 Rn = ia == 0 ? RA[0] : (ia == 1 ? RA[1] : RA[2]);
+    v3 Ru = ia == 0 ? RA[1] : (ia == 1 ? RA[2] : RA[0]);
+    v3 Rv = ia == 0 ? RA[2] : (ia == 1 ? RA[0] : RA[1]);
+    float rn = ia == 0 ? rs[0] : (ia == 1 ? rs[1] : rs[2]);
+    float a_ = ia == 0 ? rs[1] : (ia == 1 ? rs[2] : rs[0]);
+    float b_ = ia == 0 ? rs[2] : (ia == 1 ? rs[0] : rs[1]);
+    v3 nref = Rn * (refis1 ? bsign : -bsign);
+    // incident face: most anti-parallel to nref (first index wins ties)
+    float d0 = dot(IA[0], nref), dd1 = dot(IA[1], nref), dd2 = dot(IA[2], nref);
+    int ib = 0;
+    float mind = -fabsf(d0);
+    if (-fabsf(dd1) < mind) { mind = -fabsf(dd1); ib = 1; }
+    if (-fabsf(dd2) < mind) { mind = -fabsf(dd2); ib = 2; }
+    float dd = ib == 0 ? d0 : (ib == 1 ? dd1 : dd2), isg = dd > 0.f ? -1.f : 1.f;
+    v3 In = ib == 0 ? IA[0] : (ib == 1 ? IA[1] : IA[2]);
+    v3 Iu = ib == 0 ? IA[1] : (ib == 1 ? IA[2] : IA[0]);
+    v3 Iv = ib == 0 ? IA[2] : (ib == 1 ? IA[0] : IA[1]);
+    float in_ = ib == 0 ? is[0] : (ib == 1 ? is[1] : is[2]);
+    float iu_ = ib == 0 ? is[1] : (ib == 1 ? is[2] : is[0]);
+    float iv_ = ib == 0 ? is[2] : (ib == 1 ? is[0] : is[1]);
+    v3 fc = ip + In * (isg * in_);
+    v3 rel = fc - rp;
+    v3 c2 = mk3(dot(rel, Ru), dot(rel, Rv), dot(rel, nref) - rn);
+    v3 eu = mk3(dot(Iu, Ru), dot(Iu, Rv), dot(Iu, nref)) * iu_;
+    v3 ev = mk3(dot(Iv, Ru), dot(Iv, Rv), dot(Iv, nref)) * iv_;
+    // corner k of the (+-1, +-1) square, counter-clockwise from (-1, -1)
+    bool hv1 = false, hv2 = false;
+    v3 pt1 = mk3(0, 0, 0), pt2 = mk3(0, 0, 0);
+    {   // round 1: lanes 0..3 incident vertex k inside the reference face; lanes 4..7 reference corner k inside the incident face
+      const int k = a & 3;
+      const float kx = (k == 1 || k == 2) ? 1.f : -1.f, ky = k >= 2 ? 1.f : -1.f;
+      const v3 q0 = c2 + eu * kx + ev * ky;
+      if (a < 4) {
+        hv1 = fabsf(q0.x) <= a_ && fabsf(q0.y) <= b_;
+        pt1 = q0;
+      } else if (a < 8) {
+        float det = eu.x * ev.y - eu.y * ev.x;
+        if (fabsf(det) > 1e-14f) {
+          float x = kx * a_ - c2.x, y = ky * b_ - c2.y;
+          float al = (x * ev.y - y * ev.x) / det, be = (eu.x * y - eu.y * x) / det;
+          hv1 = fabsf(al) < 1.f && fabsf(be) < 1.f;
+          pt1 = mk3(kx * a_, ky * b_, c2.z + al * eu.z + be * ev.z);
+        }
       }
     }
+    {   // round 2: incident edge k (corner k to corner k + 1) against reference side e
+      const int k = a >> 2, k1 = (k + 1) & 3;
+      const float kx = (k == 1 || k == 2) ? 1.f : -1.f, ky = k >= 2 ? 1.f : -1.f;
+      const float k1x = (k1 == 1 || k1 == 2) ? 1.f : -1.f, k1y = k1 >= 2 ? 1.f : -1.f;
+      const v3 q0 = c2 + eu * kx + ev * ky, q1 = c2 + eu * k1x + ev * k1y;
+      const int e = a & 3, axn = e & 1;
+      float lim = ((e & 2) ? 1.f : -1.f) * (axn ? b_ : a_), other = axn ? a_ : b_;
+      float q0a = axn ? q0.y : q0.x, q1a = axn ? q1.y : q1.x, q0o = axn ? q0.x : q0.y, q1o = axn ? q1.x : q1.y;
+      float e0 = q0a - lim, e1 = q1a - lim;
+      if (!((e0 < 0.f) == (e1 < 0.f) || e0 == e1)) {
+        float t = e0 / (e0 - e1);
+        float o = q0o + t * (q1o - q0o);
+        if (t > 0.f && t < 1.f && fabsf(o) < other) {
+          hv2 = true;
+          pt2 = axn ? mk3(o, lim, q0.z + t * (q1.z - q0.z)) : mk3(lim, o, q0.z + t * (q1.z - q0.z));
+        }
+      }
+    }
+    if (alive && !edge) {
+      h1 = hv1 && !(pt1.z > 0.f); h2 = hv2 && !(pt2.z > 0.f);
+      d1 = pt1.z; d2 = pt2.z;
+      x1 = rp + Ru * pt1.x + Rv * pt1.y + nref * (rn + 0.5f * pt1.z);
+      x2 = rp + Ru * pt2.x + Rv * pt2.y + nref * (rn + 0.5f * pt2.z);
+      nrm = nref * (refis1 ? 1.f : -1.f);
+    }
   }
-  have = have && !(pt.z > 0.f);
-  v3 pos = rp + Ru * pt.x + Rv * pt.y + nref * (rn + 0.5f * pt.z);
-  v3 n12 = nref * (refis1 ? 1.f : -1.f);
-  push_contacts(s, have, pt.z, pos, n12, pair, ncon, flags, 64);
+  // append: row by row; inside a row the first round's contacts (lane order), then the second round's
+  const unsigned long long M1 = wave_ballot(h1), M2 = wave_ballot(h2);
+  int off = 0, tot = 0;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int cr = popc64((M1 >> (16 * r)) & 0xffffull) + popc64((M2 >> (16 * r)) & 0xffffull);
+    off += r < g ? cr : 0;
+    tot += cr;
+  }
+  const unsigned long long r1 = (M1 >> rb) & 0xffffull, r2 = (M2 >> rb) & 0xffffull, below = (1ull << a) - 1ull;
+  const int i1 = ncon + off + popc64(r1 & below), i2 = ncon + off + popc64(r1) + popc64(r2 & below);
+  if (h1 && i1 < MAXCON) {
+    s.c_dist[i1] = d1; st3(s.c_pos[i1], x1); make_frame(nrm, s.c_frame[i1]); s.c_pair[i1] = pair;
+    s.c_m1[i1] = pm1; s.c_m2[i1] = pm2; s.c_ob[i1] = pob; s.c_dim[i1] = pdim;
+  }
+  if (h2 && i2 < MAXCON) {
+    s.c_dist[i2] = d2; st3(s.c_pos[i2], x2); make_frame(nrm, s.c_frame[i2]); s.c_pair[i2] = pair;
+    s.c_m1[i2] = pm1; s.c_m2[i2] = pm2; s.c_ob[i2] = pob; s.c_dim[i2] = pdim;
+  }
+  if (ncon + tot > MAXCON) { flags |= JFLAG_CON_OVERFLOW; tot = MAXCON - ncon; }
+  ncon += tot;
 }
 
 // ---------------------------------------------------------------- MPR (all lanes run the same serial control flow)
@@ -521,46 +571,49 @@ JDEV void stage_collision(const JacoStepArgs& A, const JacoModelDev* m, L& s, in
   JSTAMP(10);
   // phase 3: narrowphase, whole wave per candidate
   int ncon = 0;
-  // the first 64 candidates' pair index, code and contact bookkeeping are fetched by lane c in one go and broadcast inside the
-  // loop (instead of an LDS read + two dependent scalar loads in front of every narrowphase call)
-  const int pkA = s.cand[lane < ncand ? lane : 0];
-  const int codeA = m->pair_code[pkA];
-  const unsigned m1A = m->pair[pkA].m1, m2A = m->pair[pkA].m2;
-  const int obA = m->pair[pkA].ob, dimA = m->pair[pkA].condim;
-  for (int c = 0; c < ncand; c++) {
-    // contact buffer full and a bigger tier to hand the env to: the rest of the narrowphase would be thrown away with the substep
-    if (L::Caps::MAXEFC < JacoHuge::MAXEFC && (wave_uniform_i((int)flags) & (int)JFLAG_CON_OVERFLOW)) break;
-    int pk, code, pob, pdim;
-    unsigned pm1, pm2;
-    if (c < 64) {
-      pk = wave_bcast_i(pkA, c); code = wave_bcast_i(codeA, c);
-      pm1 = (unsigned)wave_bcast_i((int)m1A, c); pm2 = (unsigned)wave_bcast_i((int)m2A, c); pob = wave_bcast_i(obA, c); pdim = wave_bcast_i(dimA, c);
-    } else {
-      pk = wave_uniform_i(s.cand[c]); code = m->pair_code[pk];
-      const JacoPairParam& P = m->pair[pk];
-      pm1 = P.m1; pm2 = P.m2; pob = P.ob; pdim = P.condim;
-    }
-    int g1 = code & 255, g2 = (code >> 8) & 255, t1 = (code >> 16) & 15, t2 = (code >> 20) & 15;
-    int before = ncon;
-    if (t1 == JG_PLANE) {
-      if (t2 == JG_BOX) collide_plane_box(m, s, g1, g2, pk, lane, ncon, flags);
-      else if (t2 == JG_SPHERE) collide_plane_sphere(m, s, g1, g2, pk, lane, ncon, flags);
-      else if (t2 == JG_MESH) collide_plane_convex(A, m, s, g1, g2, t2, pk, lane, ncon, flags);
-    } else if (t1 == JG_BOX && t2 == JG_BOX) {
-      collide_box_box(m, s, g1, g2, pk, lane, ncon, flags);
-    } else {
-      float depth;
-      v3 dir, pos;
-      bool hit = mpr_penetration(A, m, s, g1, t1, g2, t2, lane, &depth, &dir, &pos);
+  // 64 candidates at a time: their pair index, code and contact bookkeeping are fetched by lane c in one go and broadcast inside
+  // the loop (instead of an LDS read + two dependent scalar loads in front of every narrowphase call)
+  for (int cb = 0; cb < ncand; cb += 64) {
+    const int nhere = ncand - cb < 64 ? ncand - cb : 64;
+    const int pkA = s.cand[lane < nhere ? cb + lane : cb];
+    const int codeA = m->pair_code[pkA];
+    const unsigned m1A = m->pair[pkA].m1, m2A = m->pair[pkA].m2;
+    const int obA = m->pair[pkA].ob, dimA = m->pair[pkA].condim;
+    const unsigned long long boxes = wave_ballot(lane < nhere && ((codeA >> 16) & 255) == (JG_BOX | (JG_BOX << 4)));
+    for (int c = 0; c < nhere;) {
+      // contact buffer full and a bigger tier to hand the env to: the rest of the narrowphase would be thrown away with the substep
+      if (L::Caps::MAXEFC < JacoHuge::MAXEFC && (wave_uniform_i((int)flags) & (int)JFLAG_CON_OVERFLOW)) break;
+      if ((boxes >> c) & 1ull) {   // a run of up to four box-box pairs, one 16-lane row each
+        const int run = ffs64(~(boxes >> c) | 16ull);
+        collide_box_box4(m, s, c, run, pkA, codeA, m1A, m2A, obA, dimA, lane, ncon, flags);
+        c += run;
+        continue;
+      }
+      const int pk = wave_bcast_i(pkA, c), code = wave_bcast_i(codeA, c);
+      const unsigned pm1 = (unsigned)wave_bcast_i((int)m1A, c), pm2 = (unsigned)wave_bcast_i((int)m2A, c);
+      const int pob = wave_bcast_i(obA, c), pdim = wave_bcast_i(dimA, c);
+      const int g1 = code & 255, g2 = (code >> 8) & 255, t1 = (code >> 16) & 15, t2 = (code >> 20) & 15;
+      const int before = ncon;
+      if (t1 == JG_PLANE) {
+        if (t2 == JG_BOX) collide_plane_box(m, s, g1, g2, pk, lane, ncon, flags);
+        else if (t2 == JG_SPHERE) collide_plane_sphere(m, s, g1, g2, pk, lane, ncon, flags);
+        else if (t2 == JG_MESH) collide_plane_convex(A, m, s, g1, g2, t2, pk, lane, ncon, flags);
+      } else {
+        float depth;
+        v3 dir, pos;
+        bool hit = mpr_penetration(A, m, s, g1, t1, g2, t2, lane, &depth, &dir, &pos);
 #ifdef JACO_TRACE_MPR
-      if (lane == 0) printf("mpr g1 %d g2 %d hit %d depth %g\n", g1, g2, (int)hit, hit ? depth : 0.f);
+        if (lane == 0) printf("mpr g1 %d g2 %d hit %d depth %g\n", g1, g2, (int)hit, hit ? depth : 0.f);
 #endif
-      push_contacts(s, hit && lane == 0, -depth, pos, dir, pk, ncon, flags, 1);
+        push_contacts(s, hit && lane == 0, -depth, pos, dir, pk, ncon, flags, 1);
+      }
+      if (ncon > before) {   // dof chain masks / body ids of the two geoms, for the row builder and the touch stage
+        int cc = before + lane;
+        if (cc < ncon) { s.c_m1[cc] = pm1; s.c_m2[cc] = pm2; s.c_ob[cc] = pob; s.c_dim[cc] = pdim; }
+      }
+      c++;
     }
-    if (ncon > before) {   // dof chain masks / body ids of the two geoms, for the row builder and the touch stage
-      int cc = before + lane;
-      if (cc < ncon) { s.c_m1[cc] = pm1; s.c_m2[cc] = pm2; s.c_ob[cc] = pob; s.c_dim[cc] = pdim; }
-    }
+    if (L::Caps::MAXEFC < JacoHuge::MAXEFC && (wave_uniform_i((int)flags) & (int)JFLAG_CON_OVERFLOW)) break;
   }
   if (lane == 0) { s.ncon = ncon; s.ncand = ncand; }
 }
@@ -649,7 +702,9 @@ JDEV void stage_contact_rows(const JacoModelDev* m, L& s, int lane, unsigned& fl
     // JSIDE_ROWS rows and no other contact reaches into that block (every tier counts them: "would the light tier cope?" needs the number)
     const unsigned mm = cm1 | cm2;
     bool sidec = false;
-    if (JNV - JB1 == 6 && cb == 0) {
+    int end = rowbase + wave_scan_incl(nrow, lane);
+    // (only looked for when the rows exceed the light tier's buffer: nobody asks for the number otherwise)
+    if (JNV - JB1 == 6 && cb == 0 && wave_bcast_i(end, nhere - 1) > JSIDE_BASE) {
       const bool only2 = lane < nhere && mm != 0u && (mm & ((1u << JB1) - 1u)) == 0u && nrow <= 4;
       const bool reach2 = lane < nhere && !only2 && (mm >> JB1) != 0u;
       const unsigned long long o2 = wave_ballot(only2);
@@ -659,7 +714,6 @@ JDEV void stage_contact_rows(const JacoModelDev* m, L& s, int lane, unsigned& fl
         if (srows <= JSIDE_ROWS) { side_cand = srows; sidec = only2; }
       }
     }
-    int end = rowbase + wave_scan_incl(nrow, lane);
     bool split = false;
     int r0s = 0;
     if (SIDE && side_cand > 0 && wave_bcast_i(end, nhere - 1) > MAXEFC && wave_bcast_i(end, nhere - 1) - side_cand <= MAXEFC) {

@@ -70,7 +70,6 @@ JDEV float wave_max(float v) {
 JDEV float wave_min(float v) { return -wave_max(-v); }
 
 // argmax with lowest-index tie-break; returns the winning index in all lanes, *best gets the value.
-JDEV int wave_argmax(float v, int idx, float* best) {
 #define JACO_ARGMAX_STEP(CTRL)                              \
   {                                                         \
     float v2 = dpp_f<CTRL>(v);                              \
@@ -79,11 +78,11 @@ JDEV int wave_argmax(float v, int idx, float* best) {
     v = take ? v2 : v;                                      \
     idx = take ? i2 : idx;                                  \
   }
+JDEV int wave_argmax(float v, int idx, float* best) {
   JACO_ARGMAX_STEP(0xB1)
   JACO_ARGMAX_STEP(0x4E)
   JACO_ARGMAX_STEP(0x141)
   JACO_ARGMAX_STEP(0x140)
-#undef JACO_ARGMAX_STEP
   float bv = wave_bcast(v, 0);
   int bi = wave_bcast_i(idx, 0);
 #pragma unroll
@@ -97,6 +96,16 @@ JDEV int wave_argmax(float v, int idx, float* best) {
   *best = bv;
   return bi;
 }
+// the same inside each 16-lane row: every lane gets its own row's winner
+JDEV int row_argmax(float v, int idx, float* best) {
+  JACO_ARGMAX_STEP(0xB1)
+  JACO_ARGMAX_STEP(0x4E)
+  JACO_ARGMAX_STEP(0x141)
+  JACO_ARGMAX_STEP(0x140)
+  *best = v;
+  return idx;
+}
+#undef JACO_ARGMAX_STEP
 
 JDEV unsigned long long wave_clock() { return __builtin_amdgcn_s_memtime(); }   // free-running shader clock
 JDEV int grid_size() { return (int)gridDim.x; }

@@ -484,24 +484,25 @@ JDEV void load_rows(float (&h)[JNV], const float* M, int nv, int lane) {
 }
 
 // ---------------------------------------------------------------- stage K: kinematic tree
-// K1 (lane = body): joint-local transform T_b = [R_b0 Rot(axis, q - q0) | pos_b] (free bodies: world pose from qpos).
-// K2 (lane = body): world frame = product of the ancestors' T, by pointer jumping: round r composes each body's partial
-//                   product with the one 2^r levels up (3 rounds cover the 7-body chain link1..link6, finger).
-// K2b (lane = dof): motion subspaces S_d and S_d * qvel_d.
-// K3 (lane = body): body velocity = sum of S_d qvel_d over the dofs that move it (bit mask of the body's dof chain);
-// K4 (lane = dof): S_d-dot * qvel_d with the velocity "before" that dof;  K5 (lane = body): bias acceleration = -gravity +
-//                   sum over the chain.
-// Scratch: s.cinert/s.crb (rebuilt right after) and the not-yet-built constraint-row area s.J.
-JDEV void ld_frame(const float* T, m3& R, v3& p) {   // 12 floats, 16-byte aligned: rotation (row-major), position
-  v4 a = ld4(T), b = ld4(T + 4), c = ld4(T + 8);
-  R.m[0] = a.x; R.m[1] = a.y; R.m[2] = a.z; R.m[3] = a.w; R.m[4] = b.x; R.m[5] = b.y; R.m[6] = b.z; R.m[7] = b.w; R.m[8] = c.x;
-  p = mk3(c.y, c.z, c.w);
+// Frames are handled column-wise: lane 4 b + c owns column c of body b's frame (c < 3: rotation column, c = 3: position), a 16-byte
+// record slot, so that composing with a parent is one 3 x 3 times vector product per lane instead of a matrix product per body.
+// K1: joint-local transform T_b = [R_b0 Rot(axis, q - q0) | pos_b] (free bodies: world pose from qpos).
+// K2: world frame = product of the ancestors' T, by pointer jumping: round r composes each body's partial product with the one 2^r
+//     levels up (3 rounds cover the 7-body chain link1..link6, finger).  The two task-layer markers ride along as records nb, nb + 1.
+// K3 (one interval, everything that only needs the frames): spatial inertias (lane 4 b + i: row i of R I R^T; lane 4 b + 3: mass,
+//     first moment), geom poses (lane = geom), motion subspaces S_d and S_d * qvel_d (lane = dof).
+// K4: body velocity = sum of S_d qvel_d over the dofs that move it (bit mask of the body's dof chain), lanes 4 b (angular), 4 b + 1 (linear);
+// K5 (lane = dof): S_d-dot * qvel_d with the velocity "before" that dof;  K6 (lane = body): bias acceleration = -gravity + sum over
+//     the chain, and the body's RNE force.
+// Scratch: s.cinert/s.crb (rebuilt in K3) and the not-yet-built constraint-row area s.J.
+JDEV void ld_cols(const float* T, v3& c0, v3& c1, v3& c2, v3& p) {   // 16 floats, 16-byte aligned: three rotation columns, position
+  v4 a = ld4(T), b = ld4(T + 4), c = ld4(T + 8), d = ld4(T + 12);
+  c0 = mk3(a.x, a.y, a.z); c1 = mk3(b.x, b.y, b.z); c2 = mk3(c.x, c.y, c.z); p = mk3(d.x, d.y, d.z);
 }
-JDEV void st_frame(float* T, const m3& R, v3 p) {
-  v4 a, b, c;
-  a.x = R.m[0]; a.y = R.m[1]; a.z = R.m[2]; a.w = R.m[3]; b.x = R.m[4]; b.y = R.m[5]; b.z = R.m[6]; b.w = R.m[7]; c.x = R.m[8];
-  c.y = p.x; c.z = p.y; c.w = p.z;
-  *reinterpret_cast<v4*>(T) = a; *reinterpret_cast<v4*>(T + 4) = b; *reinterpret_cast<v4*>(T + 8) = c;
+JDEV void st_col(float* T, v3 v) { v4 a; a.x = v.x; a.y = v.y; a.z = v.z; a.w = 0.f; *reinterpret_cast<v4*>(T) = a; }
+// R v with R given by its columns: the same expression, element by element, as mul(m3, v3)
+JDEV v3 mul_cols(v3 c0, v3 c1, v3 c2, v3 v) {
+  return mk3(c0.x * v.x + c1.x * v.y + c2.x * v.z, c0.y * v.x + c1.y * v.y + c2.y * v.z, c0.z * v.x + c1.z * v.y + c2.z * v.z);
 }
 // sum of the 6-vectors T[d] over the dofs d of a chain mask.  A body is moved by at most JMAXCHAIN dofs (6 arm joints + its own
 // finger joint; a free body's 6): the loads of all terms are issued together (one LDS round trip) instead of one dependent
@@ -520,6 +521,21 @@ JDEV sv chain_sum(const float* T, unsigned mask) {
   for (int k = 0; k < JMAXCHAIN; k++) if (on[k]) v = v + t[k];
   return v;
 }
+JDEV v3 chain_sum3(const float* T, unsigned mask) {   // one half (3 components) of the same sum, same order
+  v3 t[JMAXCHAIN];
+  bool on[JMAXCHAIN];
+#pragma unroll
+  for (int k = 0; k < JMAXCHAIN; k++) {
+    on[k] = mask != 0u;
+    t[k] = ld3(T + 6 * (on[k] ? __builtin_ctz(mask) : 0));
+    mask &= mask - 1u;
+  }
+  v3 v = mk3(0.f, 0.f, 0.f);
+#pragma unroll
+  for (int k = 0; k < JMAXCHAIN; k++) if (on[k]) v = v + t[k];
+  return v;
+}
+static_assert(4 * (JNB + 2) <= 64 && 256 + 16 * (JNB + 2) <= JSCRATCH && 16 * JNB <= 20 * JNB, "frame records: one lane per column, scratch sizes");
 template <class L>
 JDEV void stage_walk(const JacoModelDev* m, L& s, int lane, bool markers, JProfCtx* wpc = nullptr) {
 #ifdef JACO_WALK_PROFILE   // diagnostic: split this stage over profile slots 9..14 (their usual owners are wrong in such a build)
@@ -529,15 +545,19 @@ JDEV void stage_walk(const JacoModelDev* m, L& s, int lane, bool markers, JProfC
 #endif
   (void)wpc;
   const int nb = m->nbody, nv = m->nv;
-  float* TA = &s.cinert[0][0];   // [JNB][12] frames, ping  (cinert+crb are contiguous: 2 * JNB * 10 floats)
-  float* TB = s.J + 256;         // [JNB][12] frames, pong  (the first JSCRATCH floats of the constraint-row area are free at this point)
+  float* TA = &s.cinert[0][0];   // [JNB][16] frame records, ping  (cinert+crb are contiguous: 2 * JNB * 10 floats)
+  float* TB = s.J + 256;         // [JNB + 2][16] frame records, pong  (the first JSCRATCH floats of the constraint-row area are free at this point)
   float* Sq = s.J;               // [JNV][6] S_d * qvel_d
   float* Sq2 = s.J + JNV * 6;    // [JNV][6] S_d-dot * qvel_d
+  const int fb = lane >> 2, fc = lane & 3;
+  const bool isf = fb < nb;                            // frame lane: column fc of body fb
+  const bool ismk = markers && fb >= nb && fb < nb + 2;   // ... of marker fb - nb
+  const int b = isf ? fb : 0;
   const bool isb = lane < nb;
-  const int b = isb ? lane : 0;
   const int jt = s.mc.b_jtype[b], qa = s.mc.b_qadr[b];
   const int a1 = s.mc.b_anc[b][0], a2 = s.mc.b_anc[b][1], a4 = s.mc.b_anc[b][2];
-  const unsigned chain = isb ? m->b_chainmask[b] : 0u;   // dofs that move this body (used two stages further down)
+  const unsigned chain = isf ? m->b_chainmask[b] : 0u;             // dofs that move body fb
+  const unsigned chainb = isb ? m->b_chainmask[isb ? lane : 0] : 0u;   // ... body `lane`
   const float q0lo = m->b_qpos0_lo[b];
   // Model constants of the later phases, issued now: their L2 latency overlaps the frame composition below instead of being paid
   // right before their use (nothing may cross the wave_sync fences on its own).
@@ -549,80 +569,96 @@ JDEV void stage_walk(const JacoModelDev* m, L& s, int lane, bool markers, JProfC
   const int gl = isg ? lane : 0;
   const int gb = m->g_body[gl], km = markers ? m->g_marker[gl] : -1;
   const float grb = m->g_rbound[gl];
-  const v3 gp0 = ld3(km >= 0 && gb < 0 ? m->g_lpos[gl] : m->g_pos[gl]);
-  const m3 gR0 = ldm(km >= 0 && gb < 0 ? m->g_lmat[gl] : m->g_mat[gl]);
-  m3 R; v3 pos;
-  float io[10];
-#pragma unroll
-  for (int k = 0; k < 10; k++) io[k] = 0.f;
-  if (isb) {
+  const bool onmk = km >= 0 && gb < 0;
+  const v3 gp0 = ld3(onmk ? m->g_lpos[gl] : m->g_pos[gl]);
+  const m3 gR0 = ldm(onmk ? m->g_lmat[gl] : m->g_mat[gl]);
+  v3 v = mk3(0.f, 0.f, 0.f);   // my column
+  if (isf) {
     if (jt == JJ_HINGE) {
       // joint angle relative to the reference, from the compensated state: hi part q - q0 with its exact rounding error (two-sum),
       // low part = state's low part - reference's low part (ref 3.14: 1.05e-7 off its float) + that error
       const float q = s.qpos[qa], q0 = s.mc.b_qpos0[b];
       const float ah = q - q0, bb = ah - q;
       const float al = ((q - (ah - bb)) + (-q0 - bb)) + (s.qpos_lo[qa] - q0lo);
-      R = mul(ldm(s.mc.b_mat[b]), axis_rot(ld3(s.mc.b_axis[b]), ah, al));
-      pos = ld3(s.mc.b_pos[b]);
+      const m3 Rj = axis_rot(ld3(s.mc.b_axis[b]), ah, al);
+      const v3 rc = fc == 0 ? col(Rj, 0) : (fc == 1 ? col(Rj, 1) : col(Rj, 2));
+      v = fc == 3 ? ld3(s.mc.b_pos[b]) : mul(ldm(s.mc.b_mat[b]), rc);
     } else {
       float w = s.qpos[qa + 3], x = s.qpos[qa + 4], y = s.qpos[qa + 5], z = s.qpos[qa + 6];
       float n = sqrtf(w * w + x * x + y * y + z * z);
       if (n < JMINVAL) { w = 1.f; x = y = z = 0.f; } else { float in = 1.f / n; w *= in; x *= in; y *= in; z *= in; }
-      R = quat2mat(w, x, y, z);
-      pos = ld3(&s.qpos[qa]);
+      const m3 R = quat2mat(w, x, y, z);
+      v = fc == 0 ? col(R, 0) : (fc == 1 ? col(R, 1) : (fc == 2 ? col(R, 2) : ld3(&s.qpos[qa])));
     }
-    st_frame(TA + 12 * b, R, pos);
+    st_col(TA + 4 * lane, v);
   }
   wave_sync();
   JWSTAMP(9);
-  if (isb) {
-    if (a1 >= 0) { m3 Rp; v3 pp; ld_frame(TA + 12 * a1, Rp, pp); pos = pp + mul(Rp, pos); R = mul(Rp, R); }
-    st_frame(TB + 12 * b, R, pos);
+  if (isf) {
+    if (a1 >= 0) { v3 c0, c1, c2, pp; ld_cols(TA + 16 * a1, c0, c1, c2, pp); v = mul_cols(c0, c1, c2, v); if (fc == 3) v = pp + v; }
+    st_col(TB + 4 * lane, v);
   }
   wave_sync();
-  if (isb) {
-    if (a2 >= 0) { m3 Rp; v3 pp; ld_frame(TB + 12 * a2, Rp, pp); pos = pp + mul(Rp, pos); R = mul(Rp, R); }
-    st_frame(TA + 12 * b, R, pos);
+  if (isf) {
+    if (a2 >= 0) { v3 c0, c1, c2, pp; ld_cols(TB + 16 * a2, c0, c1, c2, pp); v = mul_cols(c0, c1, c2, v); if (fc == 3) v = pp + v; }
+    st_col(TA + 4 * lane, v);
   }
   wave_sync();
-  if (isb) {
-    if (a4 >= 0) { m3 Rp; v3 pp; ld_frame(TA + 12 * a4, Rp, pp); pos = pp + mul(Rp, pos); R = mul(Rp, R); }
-    st3(s.xpos[b], pos);
-    stm(s.xmat[b], R);
-    const v3 c = pos + mul(R, ld3(s.mc.b_com[b]));
-    // spatial inertia about the world origin [m, m c, I_O], from the frame still in registers
-    const float* I = Imod;
-    m3 Il;
-    Il.m[0] = I[0]; Il.m[4] = I[1]; Il.m[8] = I[2];
-    Il.m[1] = Il.m[3] = I[3]; Il.m[2] = Il.m[6] = I[4]; Il.m[5] = Il.m[7] = I[5];
-    m3 T = mul(R, Il), Iw;
-#pragma unroll
-    for (int i = 0; i < 3; i++)
-#pragma unroll
-      for (int j = 0; j < 3; j++) Iw.m[3 * i + j] = T.m[3 * i] * R.m[3 * j] + T.m[3 * i + 1] * R.m[3 * j + 1] + T.m[3 * i + 2] * R.m[3 * j + 2];
-    const float cc = dot(c, c);
-    io[0] = mass; io[1] = mass * c.x; io[2] = mass * c.y; io[3] = mass * c.z;
-    io[4] = Iw.m[0] + mass * (cc - c.x * c.x); io[5] = Iw.m[4] + mass * (cc - c.y * c.y); io[6] = Iw.m[8] + mass * (cc - c.z * c.z);
-    io[7] = Iw.m[1] - mass * c.x * c.y; io[8] = Iw.m[2] - mass * c.x * c.z; io[9] = Iw.m[5] - mass * c.y * c.z;
+  if (isf) {
+    if (a4 >= 0) { v3 c0, c1, c2, pp; ld_cols(TA + 16 * a4, c0, c1, c2, pp); v = mul_cols(c0, c1, c2, v); if (fc == 3) v = pp + v; }
+    st_col(TB + 4 * lane, v);
+    if (fc == 3) st3(s.xpos[b], v);
+    else { s.xmat[b][fc] = v.x; s.xmat[b][3 + fc] = v.y; s.xmat[b][6 + fc] = v.z; }
+  } else if (ismk) {   // marker frames as records nb, nb + 1 (set_mocap_xyz / set_mocap_orientation between env steps): one path for the geoms below
+    const float* P = s.mk + 12 * (fb - nb);
+    st_col(TB + 4 * lane, fc == 3 ? ld3(P) : mk3(P[3 + fc], P[6 + fc], P[9 + fc]));
   }
-  wave_sync();   // the frame scratch TA (= cinert / crb) is dead from here on
+  wave_sync();   // the frame scratch TA (= cinert / crb) is dead from here on; TB holds the world frames
   JWSTAMP(10);
-  // one interval for everything that only needs the body frames: inertias out of the registers, moving geom poses, S_d
-  if (isb) {
-#pragma unroll
-    for (int k = 0; k < 10; k++) { s.cinert[b][k] = io[k]; s.crb[b][k] = io[k]; }
+  // one interval for everything that only needs the body frames: inertias, moving geom poses, S_d
+  if (isf) {
+    v3 c0, c1, c2, pos;
+    ld_cols(TB + 16 * b, c0, c1, c2, pos);
+    const v3 c = pos + mul_cols(c0, c1, c2, ld3(s.mc.b_com[b]));
+    if (fc == 3) {   // [m, m c]
+      s.cinert[b][0] = mass; s.crb[b][0] = mass;
+      const v3 mc_ = mk3(mass * c.x, mass * c.y, mass * c.z);
+      st3(&s.cinert[b][1], mc_); st3(&s.crb[b][1], mc_);
+    } else {
+      // row i = fc of I_w = R I R^T (T = R I first, as a matrix product would), shifted to the world origin
+      const float* I = Imod;
+      const v3 Ri = fc == 0 ? mk3(c0.x, c1.x, c2.x) : (fc == 1 ? mk3(c0.y, c1.y, c2.y) : mk3(c0.z, c1.z, c2.z));
+      const v3 Ti = mk3(Ri.x * I[0] + Ri.y * I[3] + Ri.z * I[4], Ri.x * I[3] + Ri.y * I[1] + Ri.z * I[5], Ri.x * I[4] + Ri.y * I[5] + Ri.z * I[2]);
+      const float w0 = Ti.x * c0.x + Ti.y * c1.x + Ti.z * c2.x;   // I_w[i][0]
+      const float w1 = Ti.x * c0.y + Ti.y * c1.y + Ti.z * c2.y;   // I_w[i][1]
+      const float w2 = Ti.x * c0.z + Ti.y * c1.z + Ti.z * c2.z;   // I_w[i][2]
+      const float cc = dot(c, c);
+      if (fc == 0) {
+        const float d = w0 + mass * (cc - c.x * c.x), o1 = w1 - mass * c.x * c.y, o2 = w2 - mass * c.x * c.z;
+        s.cinert[b][4] = d; s.cinert[b][7] = o1; s.cinert[b][8] = o2;
+        s.crb[b][4] = d; s.crb[b][7] = o1; s.crb[b][8] = o2;
+      } else if (fc == 1) {
+        const float d = w1 + mass * (cc - c.y * c.y), o = w2 - mass * c.y * c.z;
+        s.cinert[b][5] = d; s.cinert[b][9] = o;
+        s.crb[b][5] = d; s.crb[b][9] = o;
+      } else {
+        const float d = w2 + mass * (cc - c.z * c.z);
+        s.cinert[b][6] = d; s.crb[b][6] = d;
+      }
+    }
   }
   if (isg) {   // geom poses (they share LDS with the constraint rows: every substep writes all of them)
     v3 gp = gp0; m3 gR = gR0;   // static: world pose from the model
-    if (gb >= 0) {            // rides on a moving body
-      m3 Rg = ldm(s.xmat[gb]);
-      gp = ld3(s.xpos[gb]) + mul(Rg, gp0);
-      gR = mul(Rg, gR0);
-    } else if (km >= 0) {     // rides on one of the two task-layer markers (set_mocap_xyz / set_mocap_orientation between env steps)
-      const float* P = s.mk + 12 * km;
-      m3 Rm = ldm(P + 3);
-      gp = ld3(P) + mul(Rm, gp0);
-      gR = mul(Rm, gR0);
+    const int src = gb >= 0 ? gb : (km >= 0 ? nb + km : -1);   // rides on a moving body / on one of the two task-layer markers
+    if (src >= 0) {
+      v3 c0, c1, c2, pos;
+      ld_cols(TB + 16 * src, c0, c1, c2, pos);
+      gp = pos + mul_cols(c0, c1, c2, gp0);
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        const v3 gc = mul_cols(c0, c1, c2, col(gR0, j));
+        gR.m[j] = gc.x; gR.m[3 + j] = gc.y; gR.m[6 + j] = gc.z;
+      }
     }
     st3(s.gpos[lane], gp);
     s.gpos[lane][3] = grb;
@@ -632,17 +668,19 @@ JDEV void stage_walk(const JacoModelDev* m, L& s, int lane, bool markers, JProfC
     const int d = lane, bd = s.mc.d_body[d], k = d - s.mc.b_dadr[bd];
     const bool hinge = s.mc.b_jtype[bd] == JJ_HINGE, rotational = hinge || k >= 3;
     v3 al = hinge ? ld3(s.mc.b_axis[bd]) : mk3((k % 3) == 0 ? 1.f : 0.f, (k % 3) == 1 ? 1.f : 0.f, (k % 3) == 2 ? 1.f : 0.f);
+    v3 c0, c1, c2, pos;
+    ld_cols(TB + 16 * bd, c0, c1, c2, pos);
     sv S;
-    S.a = mul(ldm(s.xmat[bd]), al);   // (the joint rotation leaves its own axis invariant)
-    S.b = cross(ld3(s.xpos[bd]), S.a);
+    S.a = mul_cols(c0, c1, c2, al);   // (the joint rotation leaves its own axis invariant)
+    S.b = cross(pos, S.a);
     if (!rotational) { S.b = al; S.a = mk3(0.f, 0.f, 0.f); }
     stsv(s.cdof[d], S);
     stsv(Sq + 6 * d, S * s.qvel[d]);
   }
   wave_sync();
   JWSTAMP(11);
-  if (isb) {   // body velocity: sum of S_d qvel_d over the dofs that move the body (own + all ancestors'), straight from the mask
-    stsv(s.cvel[b], chain_sum(Sq, chain));
+  if (isf && fc < 2) {   // body velocity: sum of S_d qvel_d over the dofs that move the body (own + all ancestors'), straight from the mask
+    st3(s.cvel[b] + 3 * fc, chain_sum3(Sq + 3 * fc, chain));
   }
   wave_sync();
   JWSTAMP(12);
@@ -665,11 +703,11 @@ JDEV void stage_walk(const JacoModelDev* m, L& s, int lane, bool markers, JProfC
   if (isb) {   // bias acceleration: -gravity + sum of S_d-dot qvel_d over the same dofs; then the body's RNE force right away
     sv a; a.a = mk3(0, 0, 0);
     a.b = mk3(-m->gravity[0], -m->gravity[1], -m->gravity[2]);
-    a = a + chain_sum(Sq2, chain);
-    const sv v = ldsv(s.cvel[b]);
-    const sv f = inert_mul(s.cinert[b], a) + cross_force(v, inert_mul(s.cinert[b], v));
-    stsv(s.cfrc[b], f);
-    stsv(s.cacc[b], f);   // subtree force sum, completed for bodies with children by stage_accumulate
+    a = a + chain_sum(Sq2, chainb);
+    const sv vv = ldsv(s.cvel[lane]);
+    const sv f = inert_mul(s.cinert[lane], a) + cross_force(vv, inert_mul(s.cinert[lane], vv));
+    stsv(s.cfrc[lane], f);
+    stsv(s.cacc[lane], f);   // subtree force sum, completed for bodies with children by stage_accumulate
   }
 }
 

@@ -92,6 +92,24 @@ JDEV int wave_argmax(float v, int idx, float* best) {
   *best = bv;
   return bi;
 }
+JDEV int row_argmax(float v, int idx, float* best) {
+  int p = emu_post_f(v);
+  emu_collective();
+  float vs[64];
+  for (int l = 0; l < 64; l++) vs[l] = emu_x[p][l].f;
+  int q = emu_post_i(idx);
+  emu_collective();
+  const int r0 = emu_cur_lane & 48;
+  float bv = vs[r0];
+  int bi = emu_x[q][r0].i;
+  for (int l = r0 + 1; l < r0 + 16; l++) {
+    float v2 = vs[l];
+    int i2 = emu_x[q][l].i;
+    if (v2 > bv || (v2 == bv && i2 < bi)) { bv = v2; bi = i2; }
+  }
+  *best = bv;
+  return bi;
+}
 
 extern int emu_grid;
 JDEV int grid_size() { return emu_grid; }

@@ -15,13 +15,25 @@ presteps = int(sys.argv[sys.argv.index("--presteps") + 1]) if "--presteps" in sy
 prof = np.zeros((B, 16), np.uint64)
 if envlevel:
     from mujoco_jaco_amd.env import JacoBatchedEnv
-    genv = JacoBatchedEnv(num_envs=B, seed=1000, task="picking", frame_skip=nsub)
+    genv = JacoBatchedEnv(num_envs=B, seed=1000, task="picking", frame_skip=nsub, auto_reset="--policy" in sys.argv)
     env = genv.sim
     genv.reset()
     gen = torch.Generator(device=env.device); gen.manual_seed(2000)
     ascale = float(sys.argv[sys.argv.index("--action-scale") + 1]) if "--action-scale" in sys.argv else 1.0
     acts = [(torch.rand(B, 7, device=env.device, generator=gen) * 2 - 1) * ascale for _ in range(4)]
-    for i in range(presteps): genv.step(acts[i % 4])
+    pol = None
+    if "--policy" in sys.argv:   # actions from the reference's shipped picking policy; episode ages staggered as in bench.py
+        from mujoco_jaco_amd.policy import HPCPolicy
+        pol = HPCPolicy.load(os.path.join(ROOT, "tests", "golden", "policy_picking.npz"), device=env.device)
+        ts = genv.task_state()
+        ts[:, 1] = torch.randint(0, genv.task_max_steps, (B,), device=env.device, generator=gen).float()
+        genv.set_task_state(ts)
+        obs = genv.make_observation()
+        for i in range(presteps):
+            obs, _, _, _ = genv.step(pol.predict(obs)[0])
+        acts = [pol.predict(obs)[0]] * 4
+    else:
+        for i in range(presteps): genv.step(acts[i % 4])
     torch.cuda.synchronize()
     env._chk(env.L.jaco_stage_profile(env.h, prof.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), 1))
     env.clear_flags()
