@@ -1,0 +1,13 @@
+#!/bin/bash
+# The round's whole profile set in one GPU call (run on the GPU box; every step bounded): stage profiles (headline + policy-driven
+# regimes), rocprofv3 kernel trace of the default bench command, PMC passes, and the default bench line itself.
+# Outputs under gpurun_out/; tools/install_profiles.sh copies them into profiles/ with the round's prefix.
+set -o pipefail
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
+timeout -k 10 200 python3 $R/tools/gpu_stage_profile.py 16384 50 --env > $O/stage_profile.txt 2>&1 || exit 1
+timeout -k 10 300 python3 $R/tools/gpu_stage_profile.py 16384 50 --env --policy --presteps 150 --by-rows > $O/stage_profile_policy.txt 2>&1 || exit 1
+timeout -k 10 500 bash $R/tools/profile_bench.sh final > $O/profile_bench.log 2>&1 || exit 1
+timeout -k 10 100 python3 $R/tools/profile_window.py $O/rocprof_final $O/rocprof_final/bench.log $O/bench_kernel_stats.csv $O/bench_kernel_window.txt > /dev/null 2>&1 || exit 1
+timeout -k 10 500 bash $R/tools/profile_pmc.sh final env > $O/pmc_final.log 2>&1 || exit 1
+cd $R && timeout -k 10 600 python3 bench.py > $O/bench_final.json 2> $O/bench_final.err || exit 1
+tail -1 $O/bench_final.json
