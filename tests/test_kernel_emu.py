@@ -70,6 +70,52 @@ def test_in_hand_grasp_with_hull_contacts(model_arrays, names):
     assert np.median(sens) < 1e-3
 
 
+def test_box_box_contact_lists_match_oracle(model_arrays):
+    """collide_box_box4 (up to four box-box pairs per pass, collision.h) against the oracle's box-box, contact by contact and in order:
+    the object box dropped in random attitudes onto the pedestal's top, its rim (edge-edge contacts) and next to the holder, so that a
+    substep holds one to three box-box pairs (object-pedestal, object-holder, pedestal-floor is plane-box) in face and edge regimes."""
+    from mujoco_jaco_amd.modelc import rot
+    rng = np.random.default_rng(5)
+    o = Oracle(); e = EmuEnv()
+    nd = JDBG = None
+    L = e.L
+    off_ncon = 3 * 11 + 9 * 11 + 21 * 21 + 5 * 24
+    seen_edge = seen_face = multi = 0
+    for trial in range(40):
+        q = model_arrays["qpos0"].copy()
+        q[16:19] = [0.0, 0.345, 0.0899]                 # pedestal next to the holder (0, 0.6), 0.1 mm into the floor (at 0.09 exactly the
+                                                        # presence of its floor contacts hangs on the rounding of 0.09 + 0.07 - 0.16)
+        ang = rng.uniform(-np.pi, np.pi, 3) * (0.15 if trial % 3 == 0 else 1.0)
+        qq = rot.euler_to_quat(ang) if hasattr(rot, "euler_to_quat") else None
+        if qq is None:
+            ax = rng.normal(size=3); ax /= np.linalg.norm(ax); th = np.linalg.norm(ang)
+            qq = np.concatenate([[np.cos(th / 2)], np.sin(th / 2) * ax])
+        where = trial % 4
+        top = 0.09 + 0.07 + 0.16                         # pedestal top
+        if where == 0: pos = [rng.uniform(-0.06, 0.06), 0.345 + rng.uniform(-0.06, 0.06), top + 0.03]          # on the top face
+        elif where == 1: pos = [0.1 + rng.uniform(-0.01, 0.01), 0.345 + rng.uniform(-0.05, 0.05), top + 0.02]  # over the rim
+        elif where == 2: pos = [rng.uniform(-0.05, 0.05), 0.447 + rng.uniform(-0.004, 0.004), 0.17 + 0.03]     # in the gap: holder top and pedestal side
+        else: pos = [rng.uniform(-0.1, 0.1), 0.6 + rng.uniform(-0.1, 0.1), 0.17 + 0.035]                      # on the holder
+        q[9:12] = pos; q[12:16] = qq
+        qf = q.astype(np.float32).astype(np.float64)
+        o.reset(); o.set("qpos", qf); o.forward()
+        e.qpos[0] = qf; e.qvel[0] = 0; e.qacc_ws[0] = 0
+        e.step(np.zeros(9), nsub=1, dbg_env=0)
+        D = e.dbg
+        ncon = int(D[off_ncon])
+        oc = o.get("contact").reshape(-1, 11)
+        assert ncon == o.ncon == len(oc), (trial, ncon, o.ncon)
+        C = D[off_ncon + 4:off_ncon + 4 + 8 * ncon].reshape(ncon, 8)
+        if ncon:
+            assert np.abs(C[:, 0] - oc[:, 0]).max() < 2e-6 and np.abs(C[:, 1:4] - oc[:, 1:4]).max() < 2e-6, trial
+            assert np.abs(C[:, 4:7] - oc[:, 4:7]).max() < 2e-5, trial
+        pairs = {(int(a), int(b)) for a, b in oc[:, 7:9]}
+        multi += len(pairs) >= 3
+        per_pair = [int(((oc[:, 7] == a) & (oc[:, 8] == b)).sum()) for a, b in pairs]
+        seen_edge += any(n == 1 for n in per_pair); seen_face += any(n >= 3 for n in per_pair)
+    assert seen_edge >= 3 and seen_face >= 10 and multi >= 5, (seen_edge, seen_face, multi)
+
+
 def test_arm_only_model_config2():
     o = Oracle("jaco2_reaching_torque"); o.option("disable_contact", 1)
     e = EmuEnv("jaco2_reaching_torque")
