@@ -581,6 +581,7 @@ JDEV void stage_collision(const JacoStepArgs& A, const JacoModelDev* m, L& s, in
     const int obA = m->pair[pkA].ob, dimA = m->pair[pkA].condim;
     const unsigned long long boxes = wave_ballot(lane < nhere && ((codeA >> 16) & 255) == (JG_BOX | (JG_BOX << 4)));
     for (int c = 0; c < nhere;) {
+      lane = wave_opaque_i(lane);   // (lane-id predicates of the narrowphase routines stay inside the loop: physics_kernel.h stage_newton)
       // contact buffer full and a bigger tier to hand the env to: the rest of the narrowphase would be thrown away with the substep
       if (L::Caps::MAXEFC < JacoHuge::MAXEFC && (wave_uniform_i((int)flags) & (int)JFLAG_CON_OVERFLOW)) break;
       if ((boxes >> c) & 1ull) {   // a run of up to four box-box pairs, one 16-lane row each

@@ -341,8 +341,11 @@ JDEV float gj_inverse6(float (&A)[6], float (&B)[6], int lane) {
 #pragma unroll
     for (int j = 0; j < 6; j++) { A[j] *= sc; B[j] *= sc; }
     float f = lane == k ? 0.f : A[k];
+    float pa[6], pb[6];   // (broadcasts first, then the updates: physics_kernel.h ldl_solve)
 #pragma unroll
-    for (int j = 0; j < 6; j++) { A[j] -= f * wave_bcast(A[j], k); B[j] -= f * wave_bcast(B[j], k); }
+    for (int j = 0; j < 6; j++) { pa[j] = wave_bcast(A[j], k); pb[j] = wave_bcast(B[j], k); }
+#pragma unroll
+    for (int j = 0; j < 6; j++) { A[j] -= f * pa[j]; B[j] -= f * pb[j]; }
   }
   return det;
 }
@@ -359,9 +362,13 @@ JDEV float gj_solve6(float (&A)[6], float& b, int lane) {
     for (int j = 0; j < 6; j++) A[j] *= sc;
     b *= sc;
     float f = lane == k ? 0.f : A[k];
+    float pa[6];
 #pragma unroll
-    for (int j = 0; j < 6; j++) A[j] -= f * wave_bcast(A[j], k);
-    b -= f * wave_bcast(b, k);
+    for (int j = 0; j < 6; j++) pa[j] = wave_bcast(A[j], k);
+    const float pbk = wave_bcast(b, k);
+#pragma unroll
+    for (int j = 0; j < 6; j++) A[j] -= f * pa[j];
+    b -= f * pbk;
   }
   return det;
 }

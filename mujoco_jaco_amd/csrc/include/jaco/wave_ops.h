@@ -60,6 +60,17 @@ JDEV float wave_sum(float v) {
   v += dpp_f<0x140>(v);
   return (wave_bcast(v, 0) + wave_bcast(v, 16)) + (wave_bcast(v, 32) + wave_bcast(v, 48));
 }
+// two independent sums, interleaved step by step: a DPP operand written by the instruction right in front of it costs two wait states
+JDEV void wave_sum2(float a, float b, float* ra, float* rb) {
+  a += dpp_f<0xB1>(a); b += dpp_f<0xB1>(b);
+  a += dpp_f<0x4E>(a); b += dpp_f<0x4E>(b);
+  a += dpp_f<0x141>(a); b += dpp_f<0x141>(b);
+  a += dpp_f<0x140>(a); b += dpp_f<0x140>(b);
+  const float a0 = wave_bcast(a, 0), a1 = wave_bcast(a, 16), a2 = wave_bcast(a, 32), a3 = wave_bcast(a, 48);
+  const float b0 = wave_bcast(b, 0), b1 = wave_bcast(b, 16), b2 = wave_bcast(b, 32), b3 = wave_bcast(b, 48);
+  *ra = (a0 + a1) + (a2 + a3);
+  *rb = (b0 + b1) + (b2 + b3);
+}
 JDEV float wave_max(float v) {
   v = fmaxf(v, dpp_f<0xB1>(v));
   v = fmaxf(v, dpp_f<0x4E>(v));

@@ -136,6 +136,22 @@ struct JacoStepArgs {
   int dbg_env;
 };
 
+// The kernel's argument block, read afresh from the kernarg segment.  The block holds ~50 pointers (100 SGPRs' worth); read through
+// the by-value parameter they are all loaded at kernel entry and the ones the epilogue needs stay live -- in SGPRs, in VGPR lanes
+// (v_writelane / v_readlane spill code around every SGPR-hungry stretch of the substep loop) and, as per-lane row addresses, in
+// scratch -- across the whole substep loop.  run_env re-reads the block at the start of the env, of every substep and of the
+// epilogue instead: an s_load per use, nothing carried.  Every kernel that reaches run_env takes the block as its only parameter.
+#ifdef JACO_EMULATED
+JDEV const JacoStepArgs* args_view(const JacoStepArgs& A) { return &A; }
+#else
+JDEV const JacoStepArgs* args_view(const JacoStepArgs&) {
+  typedef const JacoStepArgs __attribute__((address_space(4))) * KP;
+  KP p = (KP)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return (const JacoStepArgs*)p;
+}
+#endif
+
 // debug dump layout (floats)
 #define JDBG_XPOS 0                       // [JNB][3]
 #define JDBG_XMAT (JDBG_XPOS + 3 * JNB)   // [JNB][9]
@@ -374,9 +390,15 @@ JDEV float ldl_solve(float (&h)[JNV], float b, int lane) {
     float inv = 1.f / dk;
     dinv = lane == k ? inv : dinv;
     float lik = lane > k ? h[k] * inv : 0.f;
+    // (all of the pivot row's broadcasts first, then the updates: a v_readlane straight in front of the VALU that reads its SGPR
+    // costs two wait states on gfx950, and the compiler pairs them up when the source does)
+    float pk[JNV];
 #pragma unroll
-    for (int j = k + 1; j < jend; j++) h[j] -= lik * wave_bcast(h[j], k);
-    b -= lik * wave_bcast(b, k);
+    for (int j = k + 1; j < jend; j++) pk[j] = wave_bcast(h[j], k);
+    const float bk = wave_bcast(b, k);
+#pragma unroll
+    for (int j = k + 1; j < jend; j++) h[j] -= lik * pk[j];
+    b -= lik * bk;
   }
   // now: b = y (L y = rhs); h[k>lane] = d_lane * L[k][lane]
   float z = b * dinv, acc = 0.f, x = 0.f;
@@ -399,9 +421,13 @@ JDEV float ldl_block(float (&h)[JNV], float b, int lane) {
     float inv = 1.f / dk;
     dinv = lane == k ? inv : dinv;
     float lik = (lane > k && lane < HI) ? h[k] * inv : 0.f;
+    float pk[JNV];
 #pragma unroll
-    for (int j = k + 1; j < HI; j++) h[j] -= lik * wave_bcast(h[j], k);
-    b -= lik * wave_bcast(b, k);
+    for (int j = k + 1; j < HI; j++) pk[j] = wave_bcast(h[j], k);
+    const float bk = wave_bcast(b, k);
+#pragma unroll
+    for (int j = k + 1; j < HI; j++) h[j] -= lik * pk[j];
+    b -= lik * bk;
   }
   float z = b * dinv, acc = 0.f, x = 0.f;
 #pragma unroll
@@ -432,9 +458,13 @@ JDEV float ldl_block0_dual(float (&h)[JNV], float b, float hd, int lane, float* 
     float inv = 1.f / dk;
     dinv = lane == k ? inv : dinv;
     float lik = (lane > k && lane < JB0) ? h[k] * inv : 0.f;
+    float pk[JNV];
 #pragma unroll
-    for (int j = k + 1; j < JB0; j++) h[j] -= lik * wave_bcast(h[j], k);
-    b -= lik * wave_bcast(b, k);
+    for (int j = k + 1; j < JB0; j++) pk[j] = wave_bcast(h[j], k);
+    const float bk = wave_bcast(b, k);
+#pragma unroll
+    for (int j = k + 1; j < JB0; j++) h[j] -= lik * pk[j];
+    b -= lik * bk;
   }
   // trailing block, twice: plain (h, b, dinv) and damped (g, bd, dinvd)
   float g[JB0 - JLDL_NSH], bd = b, dinvd = dinv;
@@ -448,10 +478,14 @@ JDEV float ldl_block0_dual(float (&h)[JNV], float b, float hd, int lane, float* 
     dinvd = lane == k ? invd : dinvd;
     const bool below = lane > k && lane < JB0;
     float lik = below ? h[k] * inv : 0.f, likd = below ? g[k - JLDL_NSH] * invd : 0.f;
+    float pk[JNV], pg[JNV];
 #pragma unroll
-    for (int j = k + 1; j < JB0; j++) { h[j] -= lik * wave_bcast(h[j], k); g[j - JLDL_NSH] -= likd * wave_bcast(g[j - JLDL_NSH], k); }
-    b -= lik * wave_bcast(b, k);
-    bd -= likd * wave_bcast(bd, k);
+    for (int j = k + 1; j < JB0; j++) { pk[j] = wave_bcast(h[j], k); pg[j] = wave_bcast(g[j - JLDL_NSH], k); }
+    const float bk = wave_bcast(b, k), bdk = wave_bcast(bd, k);
+#pragma unroll
+    for (int j = k + 1; j < JB0; j++) { h[j] -= lik * pk[j]; g[j - JLDL_NSH] -= likd * pg[j]; }
+    b -= lik * bk;
+    bd -= likd * bdk;
   }
   // back-substitution: h[k > lane] = d_lane * L[k][lane] (shared for k < NSH columns... rows < NSH use h for both systems)
   float z = b * dinv, zd = bd * dinvd, acc = 0.f, accd = 0.f, x = 0.f, xd = 0.f;
@@ -880,10 +914,14 @@ struct NewtonOut { float qacc, qfrc_con, qdamped; int iters; bool have_qdamped; 
 // NR == 1 keeps the lane's J row in registers (jrow) for the whole solve: no LDS traffic here.
 template <int NR>
 JDEV void rows_dot(const float* J, const float (&jrow)[JNV], float vk, int lane, int ne, int nv, float (&out)[NR]) {
+  // (the broadcasts first, then the products: a v_readlane straight in front of the VALU that reads its SGPR costs wait states)
+  float vb[JNV];
+#pragma unroll
+  for (int k = 0; k < JNV; k++) vb[k] = wave_bcast(vk, k);
   if (NR == 1) {
     float acc = 0.f;
 #pragma unroll
-    for (int k = 0; k < JNV; k++) acc += jrow[k] * wave_bcast(vk, k);
+    for (int k = 0; k < JNV; k++) acc += jrow[k] * vb[k];
     out[0] = acc;
     return;
   }
@@ -892,16 +930,18 @@ JDEV void rows_dot(const float* J, const float (&jrow)[JNV], float vk, int lane,
   for (int q = 0; q < NR; q++) { int r = lane + 64 * q; Jr[q] = J + (r < ne ? r : 0) * JLD; out[q] = 0.f; }
 #pragma unroll
   for (int k = 0; k < JNV; k++) {
-    float vb = wave_bcast(vk, k);
 #pragma unroll
-    for (int q = 0; q < NR; q++) out[q] += Jr[q][k] * vb;
+    for (int q = 0; q < NR; q++) out[q] += Jr[q][k] * vb[k];
   }
   (void)nv;
 }
 JDEV float mat_vec(const float (&mrow)[JNV], float vk) {  // (M v)[lane], mrow = M[lane][:] (zero for lanes >= nv)
+  float vb[JNV];
+#pragma unroll
+  for (int k = 0; k < JNV; k++) vb[k] = wave_bcast(vk, k);
   float acc = 0.f;
 #pragma unroll
-  for (int k = 0; k < JNV; k++) acc += mrow[k] * wave_bcast(vk, k);
+  for (int k = 0; k < JNV; k++) acc += mrow[k] * vb[k];
   return acc;
 }
 // sum_r J[r][lane] * f_r, f distributed over the row slots; 4 rows in flight per step to cover LDS latency
@@ -917,7 +957,8 @@ JDEV float jt_vec(const float* J, const float (&f)[NR], int ne, int lane, int nv
     int rl = 0;
     for (; rl + 4 <= n; rl += 4) {
       float j0 = Jq[(rl + 0) * JLD], j1 = Jq[(rl + 1) * JLD], j2 = Jq[(rl + 2) * JLD], j3 = Jq[(rl + 3) * JLD];
-      acc += j0 * wave_bcast(f[q], rl) + j1 * wave_bcast(f[q], rl + 1) + j2 * wave_bcast(f[q], rl + 2) + j3 * wave_bcast(f[q], rl + 3);
+      const float f0 = wave_bcast(f[q], rl), f1 = wave_bcast(f[q], rl + 1), f2 = wave_bcast(f[q], rl + 2), f3 = wave_bcast(f[q], rl + 3);
+      acc += j0 * f0 + j1 * f1 + j2 * f2 + j3 * f3;
     }
     for (; rl < n; rl++) acc += Jq[rl * JLD] * wave_bcast(f[q], rl);
   }
@@ -982,6 +1023,9 @@ JDEV NewtonOut stage_newton(const JacoModelDev* m, L& s, const float (&mrow)[JNV
   JSTAMP(11);
   int it = 0, nls = 0;
   for (; it < m->iterations; it++) {
+    // (lane-id predicates are recomputed inside the iteration: hoisted out of it they live as ~60 SGPR masks, spilled to VGPR lanes
+    //  on entry and fetched back with two v_readlane per use -- a v_cmp at the use is one instruction)
+    lane = wave_opaque_i(lane);
     bool coupled = false;
 #pragma unroll
     for (int q = 0; q < NR; q++) {
@@ -1069,7 +1113,8 @@ JDEV NewtonOut stage_newton(const JacoModelDev* m, L& s, const float (&mrow)[JNV
     JSTAMP(13);
     // exact line search on phi(al) = cost(a + al p)
     float Mp = mat_vec(mrow, p);
-    float pMp = wave_sum(p * Mp), pMa = wave_sum(p * Ma);
+    float pMp, pMa;
+    wave_sum2(p * Mp, p * Ma, &pMp, &pMa);
     rows_dot<NR>(s.J, jrow, p, lane, ne, nv, jp);
 #pragma unroll
     for (int q = 0; q < NR; q++) jp[q] = valid[q] ? jp[q] : 0.f;
@@ -1082,7 +1127,9 @@ JDEV NewtonOut stage_newton(const JacoModelDev* m, L& s, const float (&mrow)[JNV
         s1 += xa < 0.f ? D[q] * xa * jp[q] : 0.f;
         s2 += xa < 0.f ? D[q] * jp[q] * jp[q] : 0.f;
       }
-      float d1 = pMa + al * pMp + wave_sum(s1), d2 = pMp + wave_sum(s2);
+      float w1, w2;
+      wave_sum2(s1, s2, &w1, &w2);
+      float d1 = pMa + al * pMp + w1, d2 = pMp + w2;
       if (ls == 0) d10 = fabsf(d1);
 #ifdef JACO_TRACE_LS
       if (lane == 0) printf("it %d ls %d al %.9g d1 %.6g d2 %.6g lo %.9g hi %.9g pMa %.6g pMp %.6g\n", it, ls, al, d1, d2, lo, hi, pMa, pMp);
@@ -1220,6 +1267,7 @@ JDEV void newton_side(const JacoModelDev* m, L& s, const float (&mrow)[JNV], flo
   float jtf = 0.f;
   int it = 0;
   for (; it < m->iterations; it++) {
+    lane = wave_opaque_i(lane);   // (as in stage_newton)
     if (vr) { sd[JSIDE_F + lane] = x < 0.f ? D : 0.f; sd[JSIDE_AREF + lane] = x < 0.f ? -D * x : 0.f; }
     wave_sync();
     float h[JNV];
@@ -1243,12 +1291,15 @@ JDEV void newton_side(const JacoModelDev* m, L& s, const float (&mrow)[JNV], flo
     for (int j = 0; j < 6; j++) { const float pj = wave_bcast(p, JB1 + j); Mp += mrow[JB1 + j] * pj; jp += js[j] * pj; }
     Mp = mine ? Mp : 0.f;
     jp = vr ? jp : 0.f;
-    const float pMp = wave_sum(p * Mp), pMa = wave_sum(p * Ma);
+    float pMp, pMa;
+    wave_sum2(p * Mp, p * Ma, &pMp, &pMa);
     float al = 0.f, lo = 0.f, hi = 3.0e38f, d10 = 0.f, dlo = 0.f, dhi = 0.f;
     for (int ls = 0; ls < m->ls_iterations; ls++) {   // exact line search, as in stage_newton
       const float xa = x + al * jp;
       const float s1 = xa < 0.f ? D * xa * jp : 0.f, s2 = xa < 0.f ? D * jp * jp : 0.f;
-      const float d1 = pMa + al * pMp + wave_sum(s1), d2 = pMp + wave_sum(s2);
+      float w1, w2;
+      wave_sum2(s1, s2, &w1, &w2);
+      float d1 = pMa + al * pMp + w1, d2 = pMp + w2;
       if (ls == 0) d10 = fabsf(d1);
       if (ls > 0 && fabsf(d1) <= 1e-6f * d10) break;
       if (d1 < 0.f) { lo = al; dlo = -d1; } else { hi = al; dhi = d1; }
@@ -1303,7 +1354,9 @@ JDEV void hint_raise(const JacoStepArgs& A, int env, int tier, int lane) {
 // and 1 (env step): the reset-time modes (forward pass, placing hold, grasping pre-reach, take_action / terminal_inspection on their own)
 // fold away at compile time and stay out of the hot kernel's code and register budget; their launches use jaco_physics_kernel_listed.
 template <class C, int TIER, bool FULL = true>
-JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int lane, bool handback = false, int* why = nullptr) {
+JDEV int run_env(const JacoStepArgs& A_, JacoLDS<C>& s, int env, int nsub, int lane, bool handback = false, int* why = nullptr) {
+  const JacoStepArgs* Ap = args_view(A_);
+#define A (*Ap)
   constexpr bool LIGHT = TIER == 0;
   bool bailed = false;
   const JacoModelDev* m = opaque_ptr(A.model);
@@ -1464,6 +1517,7 @@ JDEV int run_env(const JacoStepArgs& A, JacoLDS<C>& s, int env, int nsub, int la
 #endif
 again:
   for (int sub = sub0; sub < nsub; sub++) {
+    Ap = args_view(A_);
     m = opaque_ptr(A.model);
     // Same for the lane id: everything a lane addresses (LDS offsets, "lane < n" masks, model table slots) derives from it, and the
     // optimiser would otherwise compute ~140 such values once, before the loop, and keep them alive across all of it -- in scratch
@@ -1708,6 +1762,7 @@ again:
       break;
     }
   }
+  Ap = args_view(A_);   // (the epilogue reads the argument block afresh: nothing of it was carried through the substep loop)
   bool reset_now = false;
   if (emode != 2) {
     if (bailed) {   // handed over to another workgroup (possibly on another XCD): write-through stores
@@ -1837,6 +1892,7 @@ again:
   wave_sync();
   if (why) *why = left <= 0 ? 0 : (bailed ? 1 : 2);
   return left;
+#undef A
 }
 
 // light tier: one workgroup (= one wavefront) per env

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #define JACO_WAVE 64
+#define JACO_EMULATED 1
 #define JDEV static inline
 
 union EmuWord { float f; int i; unsigned long long u; };
@@ -67,6 +68,7 @@ JDEV float wave_sum(float v) {
   }
   return (row[0] + row[1]) + (row[2] + row[3]);
 }
+JDEV void wave_sum2(float a, float b, float* ra, float* rb) { *ra = wave_sum(a); *rb = wave_sum(b); }
 JDEV float wave_max(float v) {
   int p = emu_post_f(v);
   emu_collective();
