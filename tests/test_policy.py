@@ -122,6 +122,22 @@ def test_shipped_policy_success_rate_on_hip_env(task, mean_len, mean_ret):
 
 
 @pytest.mark.gpu
+def test_graph_replayed_forward_equals_the_eager_one():
+    """HPCPolicy.predict_graphed (one hipGraph replay, what bench.py's policy leg runs) against predict, on fresh observations."""
+    import torch
+    from mujoco_jaco_amd.policy import HPCPolicy
+    pol = HPCPolicy.load(os.path.join(HERE, "golden", "policy_picking.npz"), device="cuda:0")
+    gen = torch.Generator(device="cuda:0"); gen.manual_seed(3)
+    for k in range(3):
+        obs = torch.rand(4096, 26, device="cuda:0", generator=gen) * 2 - 1
+        a0, w0 = pol.predict(obs)
+        a1, w1 = pol.predict_graphed(obs)
+        assert torch.equal(a0, a1) and torch.equal(w0, w1), k
+    obs = torch.rand(512, 26, device="cuda:0", generator=gen)      # another batch size: re-captured
+    assert torch.equal(pol.predict(obs)[0], pol.predict_graphed(obs)[0])
+
+
+@pytest.mark.gpu
 def test_shipped_reaching_policy_on_task_reaching():
     """Third statistic: models_baseline/policies/reaching/policy.zip (a plain SAC MlpPolicy; identical weights to the frozen reaching
     primitive inside the picking zip) on task `reaching`, 2 048 deterministic episodes.  The reference tree holds no logged success
