@@ -1852,7 +1852,7 @@ again:
   if (reset_now) {
     // auto-reset (option "auto_reset"; tasks whose reset is draws + sim.forward(): picking, reaching, pickAndplace): the episode has
     // ended and its reward / done flag are out; the same wave now does what jaco_reset(mask) would do in a launch chain of its own
-    // (0.6 ms of mostly idle GPU per step, profiles/r03_trace_policy.txt): sim.reset(), the draws (env_logic.h reset_draws: the code and
+    // (0.6 ms of mostly idle GPU per step; profiles/r03_trace_policy.txt is the step's timeline without it): sim.reset(), the draws (env_logic.h reset_draws: the code and
     // RNG stream of jaco_reset_kernel), then one more pass through the substep body as sim.forward() and the new episode's observation.
     wave_sync();
     if (lane < nq) { s.qpos[lane] = A.qpos0[lane]; s.qpos_lo[lane] = 0.f; }
