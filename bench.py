@@ -50,7 +50,10 @@ def parse_args(argv=None):
     ap.add_argument("--model", default="jaco2_curtain_torque")
     ap.add_argument("--task", default="picking")
     ap.add_argument("--action-scale", type=float, default=1.0, help="actions are U(-1,1)^7 times this (1.0 = the headline)")
-    ap.add_argument("--preroll", type=int, default=40, help="untimed env steps (with masked resets) before warmup")
+    ap.add_argument("--preroll", type=int, default=700,
+                    help="untimed env steps (finished envs reset as in the timed loop) before warmup; default = one full episode length: with the step "
+                         "counters staggered over [0, 700) every env has then been reset once and the episodes' physical ages are spread over [0, 700) "
+                         "(profiles/r04_soak_curve.txt: ms/step does not depend on the rollout's age from step 50 on)")
     ap.add_argument("--extra-scales", default="0.3,0.05", help="action scales also timed (briefly, each in a child process before the headline run); '' = none")
     ap.add_argument("--policy", default=None,
                     help="actions from one of the reference's shipped policies instead of U(-1,1): 'picking' | 'placing' (tests/golden/policy_<task>.npz) or a policy.zip / .npz path; the policy's forward pass is inside the timed step")
@@ -63,6 +66,7 @@ def parse_args(argv=None):
     ap.add_argument("--explicit-reset", action="store_true", help="reset finished envs with a masked jaco_reset launch chain after every step instead of inside jaco_step (option auto_reset)")
     ap.add_argument("--no-contact", action="store_true", help="contacts disabled (BASELINE config 2: arm-only model)")
     ap.add_argument("--config-legs", default="2,4", help="BASELINE configs also timed (briefly, each in a child process before the headline run); '' = none")
+    ap.add_argument("--flag-census", type=int, default=20, help="untimed env steps after the timed window in which error flags are counted per step (0 = off)")
     ap.add_argument("--set-option", action="append", default=[], help="name=value passed to jaco_set_option (e.g. compensated=0); repeatable")
     ap.add_argument("--dry-gather", action="store_true",
                     help="CPU rehearsal of the N > 1 plumbing (spawn, rendezvous, gather, max-over-ranks timing) on gloo: no GPU, no physics")
@@ -110,6 +114,15 @@ def self_launch(args):
     return max(abs(p.returncode) for p in procs)
 
 
+LEG_FLAGS = {}   # per side leg: capacity / solver error bits seen in its timed window
+
+
+def leg_flags(line):
+    """What a side leg's own JSON line says about dropped contacts / rows (the last capacity tier has nobody to hand over to)."""
+    c = line["config"]
+    return {"error_flags_or": c.get("error_flags_or"), "flagged_env_steps_per_million": c.get("flagged_env_steps_per_million")}
+
+
 def small_action_runs(args):
     """Throughput at the smaller action scales (the regime a converged policy lives in: the EE sits on its "hand" marker), each in
     its own child process started BEFORE this process touches the GPU: the parent's launch statistics (rocprofv3 --stats, HIP-event
@@ -117,12 +130,14 @@ def small_action_runs(args):
     out = {}
     for sc in [x for x in args.extra_scales.split(",") if x]:
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--action-scale", sc, "--steps", "6", "--warmup", "2", "--preroll", "16",
-               "--batch", str(args.batch), "--model", args.model, "--task", args.task, "--no-cpu-baseline", "--extra-scales", ""]
+               "--batch", str(args.batch), "--model", args.model, "--task", args.task, "--no-cpu-baseline", "--extra-scales", "", "--policy-leg", "", "--config-legs", ""]
         if args.frame_skip is not None:
             cmd += ["--frame-skip", str(args.frame_skip)]
         try:
             p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
-            out[sc] = json.loads(p.stdout.strip().splitlines()[-1])["value"]
+            line = json.loads(p.stdout.strip().splitlines()[-1])
+            out[sc] = line["value"]
+            LEG_FLAGS["action_scale_%s" % sc] = leg_flags(line)
         except Exception as e:  # a failed side measurement must not take the headline down
             out[sc] = None
             print("bench.py: action scale %s run failed: %r" % (sc, e), file=sys.stderr)
@@ -135,12 +150,13 @@ def policy_run(args):
     if not args.policy_leg or args.policy:
         return None
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--policy", args.policy_leg, "--task", args.policy_leg, "--steps", "10", "--warmup", "2",
-           "--preroll", "180", "--batch", str(args.batch), "--model", args.model, "--no-cpu-baseline", "--extra-scales", "", "--policy-leg", ""]
+           "--preroll", "180", "--batch", str(args.batch), "--model", args.model, "--no-cpu-baseline", "--extra-scales", "", "--policy-leg", "", "--config-legs", ""]
     if args.frame_skip is not None:
         cmd += ["--frame-skip", str(args.frame_skip)]
     try:
         p = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
         line = json.loads(p.stdout.strip().splitlines()[-1])
+        LEG_FLAGS["policy_%s" % args.policy_leg] = leg_flags(line)
         return {"policy": args.policy_leg, "value": line["value"], "ms_per_step": line["ms_per_step"], "done_fraction": line["config"]["done_fraction"],
                 "mean_rows": line["config"]["mean_rows"], "heavy_tier_fraction": line["config"]["heavy_tier_fraction"], "preroll_steps": 180}
     except Exception as e:
@@ -163,6 +179,7 @@ def config_legs(args):
         try:
             p = subprocess.run([sys.executable, os.path.abspath(__file__)] + legs[c] + common, capture_output=True, text=True, timeout=600)
             line = json.loads(p.stdout.strip().splitlines()[-1])
+            LEG_FLAGS["config%s" % c] = leg_flags(line)
             out["config%s" % c] = {"env_steps_per_s": line["value"], "ms_per_step": line["ms_per_step"], "kernel_ms": line["roofline"]["kernel_ms"],
                                    "frame_skip": line["config"]["frame_skip"], "envs": line["config"]["envs_per_gpu"], "substeps_per_s": line["config"]["substeps_per_s"],
                                    "launches_per_step": line["config"].get("launches_per_step"), "done_fraction": line["config"]["done_fraction"]}
@@ -300,12 +317,14 @@ def dry_rank(args, world, rank):
     for _ in range(args.steps):
         full = gather(local)
     dist.barrier()
-    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt, -dt], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)   # (max, -min) over ranks in one reduction, as the GPU path does
     ok = bool(torch.equal(full.view(world, B, 26)[:, 0, 0], torch.arange(world, dtype=torch.float32)))
     if rank == 0:
-        print(json.dumps({"metric": "dry-gather rehearsal (no GPU, no physics)", "value": world * B * args.steps / float(t.item()), "unit": "rows/s",
-                          "n_gpus": world, "steps": args.steps, "warmup": 0, "data": "dry-run", "gather_ok": ok}))
+        print(json.dumps({"metric": "dry-gather rehearsal (no GPU, no physics)", "value": world * B * args.steps / float(t[0].item()), "unit": "rows/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": 0, "data": "dry-run", "gather_ok": ok,
+                          "per_rank": {"ms_per_step_max": 1e3 * float(t[0]) / args.steps, "ms_per_step_min": -1e3 * float(t[1]) / args.steps}}))
     dist.destroy_process_group()
     return 0 if ok else 1
 
@@ -422,6 +441,8 @@ def main():
         name, val = kv.split("=")
         env.set_option(name, float(val))
 
+    per_rank, t_loop = {}, [0.0]
+
     def timed(nsteps):
         if world > 1:
             dist.barrier()
@@ -430,13 +451,16 @@ def main():
         for _ in range(nsteps):
             step()
         torch.cuda.synchronize()
+        t_loop[0] = time.perf_counter() - t0   # this rank's own steps, before it waits for the others
         if world > 1:
             dist.barrier()
         dt = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if world > 1:   # MAX over ranks is the job's time; the spread (and each rank's own loop time, before the closing barrier) explains it
+            t = torch.tensor([dt, -dt, t_loop[0], -t_loop[0]], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+            per_rank.update({"ms_per_step_max": 1e3 * float(t[0]) / nsteps, "ms_per_step_min": -1e3 * float(t[1]) / nsteps,
+                             "own_loop_ms_per_step_max": 1e3 * float(t[2]) / nsteps, "own_loop_ms_per_step_min": -1e3 * float(t[3]) / nsteps})
+            dt = float(t[0].item())
         return dt
 
     for _ in range((args.preroll if args.level == "env" else 0) + args.warmup):
@@ -444,7 +468,10 @@ def main():
     done_count.zero_()
     env.launch_count()   # (reset the kernel-launch counter)
     env.enable_timing(True)
+    if world > 1 and args.level == "env":
+        gather.enable_timing(True)
     dt = timed(args.steps)
+    gather_ms = gather.gather_time_ms() if (world > 1 and args.level == "env") else None
     step_ms = env.step_time_ms()
     kern_ms, launches = env.kernel_time_ms()
     env.enable_timing(False)
@@ -453,6 +480,17 @@ def main():
     flags = int(np.bitwise_or.reduce(env.flags().cpu().numpy().astype(np.uint32)))   # OR over the batch (a max would let a big informational bit hide a small error bit)
     stats = env.stats().float().mean(0).cpu().numpy()
     heavy = float(((env.flags() & 32) != 0).float().mean().item())
+    # flag census (untimed, after the timed window, same regime): env steps in which contacts / rows beyond the last capacity tier were
+    # dropped (bits 1 | 2 | 4), the state went non-finite (8) or the solver hit its iteration cap (16), counted per step
+    flagged = None
+    if args.flag_census > 0 and args.level == "env":
+        env.clear_flags()
+        nfl = torch.zeros((), dtype=torch.int64, device=dev)
+        for _ in range(args.flag_census):
+            step()
+            nfl += ((env.flags() & 31) != 0).sum()
+            env.clear_flags()
+        flagged = 1e6 * float(nfl.item()) / (B * args.flag_census)
 
     if rank == 0:
         # algorithmic HBM bytes per env per launch.  SURVEY 8(d): A = 4 (2 nq + 2 nv + n_act + n_obs + 1) + 1 = 489 B for the env
@@ -501,6 +539,10 @@ def main():
                        "mean_contacts": float(stats[0]), "mean_rows": float(stats[1]), "mean_newton_iters": float(stats[2]),
                        "reset": ("none (finished envs frozen)" if args.no_reset else ("inside jaco_step (auto_reset)" if (args.level == "env" and genv.auto_reset) else "masked jaco_reset launch chain after every step")),
                        "error_flags_or": flags & 31, "info_flags_or": flags & ~31, "launches_per_step": launches_per_step,
+                       "flagged_env_steps_per_million": flagged, "flag_census_steps": args.flag_census if flagged is not None else 0,
+                       "side_leg_flags": LEG_FLAGS,
+                       "per_rank": (dict(per_rank, gather_ms_mean=gather_ms[0] if gather_ms else None, gather_ms_max=gather_ms[1] if gather_ms else None,
+                                         gather_note="device time of the all_gather on its side stream (rank 0's view); it overlaps the next step's launch set") if world > 1 else None),
                        "config2_env_steps_per_s": (cfg_legs.get("config2") or {}).get("env_steps_per_s"), "config4_env_steps_per_s": (cfg_legs.get("config4") or {}).get("env_steps_per_s"),
                        "config_legs": cfg_legs,
                        "heavy_tier_fraction": heavy},

@@ -498,16 +498,45 @@ JDEV bool mpr_penetration(const JacoStepArgs& A, const JacoModelDev* m, const L&
 }
 
 // ---------------------------------------------------------------- stage C
-// bounding-sphere test of the pairs of chunks 4 G .. 4 G + 3 (lane = pair); survivors are appended to s.cand in pair order
+// Pair list of the bounding-sphere phase (temporal coherence across the substeps of a launch).  Geoms move well under a
+// millimetre per 1 ms substep, yet the phase used to test all ~720 whitelisted pairs every substep.  A full pass now also lists,
+// in pair order, the pairs whose sphere gap is below JACO_PAIRLIST_SLACK (lane l keeps entries l, l + 64, ... in registers) and
+// remembers where every geom was; a later substep runs the SAME exact test on the listed pairs only, as long as no geom centre has
+// moved further than 0.45 x slack since (an unlisted pair then still has a gap of a tenth of the slack: it would fail the exact test
+// by millimetres).  The survivors -- and through them every contact -- are identical to those of the all-pairs pass; the marker
+// geoms that _take_action moves and a reset trigger the rebuild through the same displacement test.
+#ifndef JACO_PAIRLIST_SLACK
+#define JACO_PAIRLIST_SLACK 0.03f
+#endif
+template <class C>
+struct PairList {
+  static constexpr int NV = C::MAXCAND > 256 ? 8 : 4;   // registers per lane, 64 entries each
+  unsigned e[NV];        // pair index | g1 << 10 | g2 << 16 | (g1 is a plane) << 22
+  float px, py, pz;      // lane = geom: its position when the list was built
+  int n;                 // entries (wave-uniform); -1: no list (first substep of a launch, or more near pairs than the registers hold)
+  unsigned planes;       // bit j: entries 64 j .. 64 j + 63 hold a plane pair
+};
+static_assert(JMAXPAIR <= 1024 && JMAXGEOM <= 64, "pair-list entry packing");
+// the exact bounding test of one pair: fixed fma chains, so that the all-pairs pass and the list pass round identically
+JDEV bool sphere_test(const v4& pa, const v4& pb, const v3& nrm, bool plane, float slack) {
+  const float dx = pb.x - pa.x, dy = pb.y - pa.y, dz = pb.z - pa.z;
+  const float dd = fmaf(dz, dz, fmaf(dy, dy, dx * dx)), dn = fmaf(dz, nrm.z, fmaf(dy, nrm.y, dx * nrm.x));
+  const float r = (pa.w + pb.w) + slack, rp = pb.w + slack;
+  return !((plane ? dn : dd) > (plane ? rp : r * r));
+}
+// all-pairs pass over the chunks 4 G .. 4 G + 3 (lane = pair): survivors are appended to s.cand in pair order, near pairs to `tmp`
 template <int G, bool PLANES, class L>
-JDEV void sphere_group(L& s, const int (&codes)[JMAXPAIR / 64], int npair, int lane, int& n1) {
+JDEV void sphere_group(L& s, const JacoModelDev* m, int npair, int lane, int& n1, int& nl, unsigned* tmp, int tmpcap) {
   v4 pa[4], pb[4];
   v3 nrm[4];
+  int codes[4];
+#pragma unroll
+  for (int c = 0; c < 4; c++) codes[c] = m->pair_code[(4 * G + c) * 64 + lane];   // (zero-padded to JMAXPAIR: straight-line loads)
 #pragma unroll
   for (int c = 0; c < 4; c++) {
-    const int code = codes[4 * G + c];
-    const int g1 = code & 255, g2 = (code >> 8) & 255;
+    const int g1 = codes[c] & 255, g2 = (codes[c] >> 8) & 255;
     pa[c] = ld4(s.gpos[g1]); pb[c] = ld4(s.gpos[g2]);
+    nrm[c] = mk3(0.f, 0.f, 0.f);
     if (PLANES) {   // branch-free: every lane also evaluates the plane form (normal = third column of g1's frame)
       nrm[c] = mk3(s.gmat[g1][2], s.gmat[g1][5], s.gmat[g1][8]);
       keep_loaded(nrm[c].x, nrm[c].y, nrm[c].z);
@@ -517,35 +546,82 @@ JDEV void sphere_group(L& s, const int (&codes)[JMAXPAIR / 64], int npair, int l
   for (int c = 0; c < 4; c++) {
     const int k = (4 * G + c) * 64 + lane;
     const bool valid = k < npair;
-    const int t1 = (codes[4 * G + c] >> 16) & 15;
-    const v3 df = mk3(pb[c].x - pa[c].x, pb[c].y - pa[c].y, pb[c].z - pa[c].z);
-    const float r = pa[c].w + pb[c].w, dd = dot(df, df);
-    float lhs = dd, rhs = r * r;
-    if (PLANES) {
-      const float dn = dot(df, nrm[c]);
-      const bool plane = t1 == JG_PLANE;
-      lhs = plane ? dn : dd; rhs = plane ? pb[c].w : r * r;
-    }
-    const bool pass = !(lhs > rhs) & valid;
-    const unsigned long long mask = wave_ballot(pass);
-    const int idx = n1 + wave_prefix_count(mask);
+    const int g1 = codes[c] & 255, g2 = (codes[c] >> 8) & 255;
+    const bool plane = PLANES && ((codes[c] >> 16) & 15) == JG_PLANE;
+    const bool pass = sphere_test(pa[c], pb[c], nrm[c], plane, 0.f) & valid;
+    const bool near = sphere_test(pa[c], pb[c], nrm[c], plane, JACO_PAIRLIST_SLACK) & valid;
+    const unsigned long long mask = wave_ballot(pass), nmask = wave_ballot(near);
+    const int idx = n1 + wave_prefix_count(mask), nidx = nl + wave_prefix_count(nmask);
     if (pass && idx < L::Caps::MAXCAND) s.cand[idx] = k;
+    if (near && nidx < tmpcap) tmp[nidx] = (unsigned)k | ((unsigned)g1 << 10) | ((unsigned)g2 << 16) | (plane ? 1u << 22 : 0u);
     n1 += popc64(mask);
+    nl += popc64(nmask);
   }
+}
+// list pass over entries 64 j .. 64 j + 63
+template <bool PLANES, class L>
+JDEV void list_chunk(L& s, unsigned ent, bool valid, int& n1) {
+  const int k = (int)(ent & 1023u), g1 = (int)((ent >> 10) & 63u), g2 = (int)((ent >> 16) & 63u);
+  const v4 pa = ld4(s.gpos[g1]), pb = ld4(s.gpos[g2]);
+  v3 nrm = mk3(0.f, 0.f, 0.f);
+  if (PLANES) nrm = mk3(s.gmat[g1][2], s.gmat[g1][5], s.gmat[g1][8]);
+  const bool pass = sphere_test(pa, pb, nrm, PLANES && ((ent >> 22) & 1u) != 0u, 0.f) & valid;
+  const unsigned long long mask = wave_ballot(pass);
+  const int idx = n1 + wave_prefix_count(mask);
+  if (pass && idx < L::Caps::MAXCAND) s.cand[idx] = k;
+  n1 += popc64(mask);
 }
 
 template <class L>
-JDEV void stage_collision(const JacoStepArgs& A, const JacoModelDev* m, L& s, int lane, unsigned& flags, JProfCtx& pc, const int (&codes)[JMAXPAIR / 64]) {
+JDEV void stage_collision(const JacoStepArgs& A, const JacoModelDev* m, L& s, int lane, unsigned& flags, JProfCtx& pc, PairList<typename L::Caps>& pl) {
   (void)pc;
-  // phase 1: bounding spheres, lane = pair; the pair codes of all chunks were fetched ahead (stage_prefetch).  Four chunks per
-  // straight-line group: all their LDS gathers are in flight before the first ballot.  Plane pairs sit in the leading chunks
-  // only (pairs are ordered by geom id and planes are static world geoms), so the groups behind them skip the plane form.
+  typedef PairList<typename L::Caps> PL;
+  // phase 1: bounding spheres.  How far has any geom centre moved since the list was built?
   int n1 = 0;
   const int npair = m->npair, plane_chunks = m->plane_chunks;
   static_assert(JMAXPAIR == 768, "three groups of four 64-pair chunks");
-  if (0 < plane_chunks) sphere_group<0, true>(s, codes, npair, lane, n1); else sphere_group<0, false>(s, codes, npair, lane, n1);
-  if (256 < npair) { if (4 < plane_chunks) sphere_group<1, true>(s, codes, npair, lane, n1); else sphere_group<1, false>(s, codes, npair, lane, n1); }
-  if (512 < npair) { if (8 < plane_chunks) sphere_group<2, true>(s, codes, npair, lane, n1); else sphere_group<2, false>(s, codes, npair, lane, n1); }
+  const bool isg = lane < m->ngeom;
+  const v3 gp = isg ? ld3(s.gpos[isg ? lane : 0]) : mk3(0.f, 0.f, 0.f);
+  bool rebuild = pl.n < 0 || A.no_pairlist;
+  if (!rebuild) {
+    const float dx = gp.x - pl.px, dy = gp.y - pl.py, dz = gp.z - pl.pz;
+    const float d2 = isg ? fmaf(dz, dz, fmaf(dy, dy, dx * dx)) : 0.f;
+    const float lim = 0.45f * JACO_PAIRLIST_SLACK;
+    rebuild = wave_ballot(!(d2 < lim * lim)) != 0ull;   // (a non-finite position rebuilds, too)
+  }
+#ifdef JACO_EMULATED
+  if (lane == 0) { emu_counter[rebuild ? 0 : 1]++; if (!rebuild) emu_counter[2] += pl.n; }   // (CPU tests: how often each pass ran, entries tested by the list passes)
+#endif
+  if (rebuild) {
+    // all pairs, lane = pair.  Four chunks per straight-line group: all their LDS gathers are in flight before the first ballot.
+    // Plane pairs sit in the leading chunks only (pairs are ordered by geom id and planes are static world geoms), so the groups
+    // behind them skip the plane form.  The near pairs are collected in the early stages' scratch area (dead by now) ...
+    unsigned* tmp = reinterpret_cast<unsigned*>(s.early_scratch);
+    static_assert(PL::NV * 64 <= JSCRATCH, "pair-list staging area");
+    int nl = 0;
+    if (0 < plane_chunks) sphere_group<0, true>(s, m, npair, lane, n1, nl, tmp, PL::NV * 64); else sphere_group<0, false>(s, m, npair, lane, n1, nl, tmp, PL::NV * 64);
+    if (256 < npair) { if (4 < plane_chunks) sphere_group<1, true>(s, m, npair, lane, n1, nl, tmp, PL::NV * 64); else sphere_group<1, false>(s, m, npair, lane, n1, nl, tmp, PL::NV * 64); }
+    if (512 < npair) { if (8 < plane_chunks) sphere_group<2, true>(s, m, npair, lane, n1, nl, tmp, PL::NV * 64); else sphere_group<2, false>(s, m, npair, lane, n1, nl, tmp, PL::NV * 64); }
+    wave_sync();
+    // ... and dealt out to the lanes' registers
+    pl.n = nl <= PL::NV * 64 ? nl : -1;
+    pl.planes = 0u;
+#pragma unroll
+    for (int j = 0; j < PL::NV; j++) {
+      const bool have = j * 64 + lane < nl && pl.n >= 0;
+      pl.e[j] = have ? tmp[have ? j * 64 + lane : 0] : 0u;
+      pl.planes |= wave_ballot(have && ((pl.e[j] >> 22) & 1u) != 0u) ? 1u << j : 0u;
+    }
+    pl.px = gp.x; pl.py = gp.y; pl.pz = gp.z;
+  } else {
+#pragma unroll
+    for (int j = 0; j < PL::NV; j++) {
+      if (j * 64 < pl.n) {
+        const bool valid = j * 64 + lane < pl.n;
+        if ((pl.planes >> j) & 1u) list_chunk<true>(s, pl.e[j], valid, n1); else list_chunk<false>(s, pl.e[j], valid, n1);
+      }
+    }
+  }
   JSTAMP(9);
   if (lane == 0) s.nsphere = n1;
   if (n1 > L::Caps::MAXCAND) { flags |= JFLAG_CAND_OVERFLOW; n1 = L::Caps::MAXCAND; }

@@ -14,6 +14,25 @@
 #include "model_blob.h"
 #include "physics_kernel.h"
 
+// the physics kernels live in their own translation units (kernels.hip, one per kernel)
+#define JACO_DECLARE_LAUNCHER(n) void jaco_launch_kernel_##n(unsigned grid, hipStream_t st, const JacoStepArgs& A);
+JACO_DECLARE_LAUNCHER(0) JACO_DECLARE_LAUNCHER(1) JACO_DECLARE_LAUNCHER(2) JACO_DECLARE_LAUNCHER(3)
+JACO_DECLARE_LAUNCHER(4) JACO_DECLARE_LAUNCHER(5) JACO_DECLARE_LAUNCHER(6) JACO_DECLARE_LAUNCHER(7)
+enum { JK_STEP = 0, JK_LISTED = 1, JK_MEDIUM = 2, JK_MEDIUM_DRAIN = 3, JK_HEAVY = 4, JK_HEAVY_DRAIN = 5, JK_HUGE = 6, JK_HUGE_DRAIN = 7 };
+void jaco_launch_kernel(int k, unsigned grid, hipStream_t st, const JacoStepArgs& A) {
+  switch (k) {
+    case 0: jaco_launch_kernel_0(grid, st, A); break;
+    case 1: jaco_launch_kernel_1(grid, st, A); break;
+    case 2: jaco_launch_kernel_2(grid, st, A); break;
+    case 3: jaco_launch_kernel_3(grid, st, A); break;
+    case 4: jaco_launch_kernel_4(grid, st, A); break;
+    case 5: jaco_launch_kernel_5(grid, st, A); break;
+    case 6: jaco_launch_kernel_6(grid, st, A); break;
+    default: jaco_launch_kernel_7(grid, st, A); break;
+  }
+}
+#define JLAUNCHK(h, k, grid, st, A) do { jaco_launch_kernel((k), (grid), (st), (A)); (h)->nlaunch++; } while (0)
+
 static_assert(JFLAG_CON_OVERFLOW == JACO_FLAG_CON_OVERFLOW && JFLAG_EFC_OVERFLOW == JACO_FLAG_EFC_OVERFLOW &&
                   JFLAG_CAND_OVERFLOW == JACO_FLAG_CAND_OVERFLOW && JFLAG_NAN == JACO_FLAG_NAN &&
                   JFLAG_SOLVER_MAXITER == JACO_FLAG_SOLVER_MAXITER && JFLAG_HEAVY_TIER == JACO_FLAG_HEAVY_TIER,
@@ -45,6 +64,7 @@ struct JacoHandle {
   int launch_id = 0;
   hipStream_t side[3] = {nullptr, nullptr, nullptr};   // the tiers' resident workers run here, concurrently with the light grid
   hipEvent_t ev_pre = nullptr, ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+  int pair_list = 1;   // option "pair_list"
   int concurrent = 1, workers = 1024, workers_heavy = 256, workers_huge = 32, tier_return = 1, use_hints = 2, handdown = 1;   // options "concurrent_heavy", "heavy_workers", "hints"
   float *task_rows = nullptr, *cache = nullptr;
   float* marker = nullptr;    // [num_envs][2][12] poses of the "hand" / "subgoal_reach" markers (mocap bodies the task layer moves)
@@ -429,7 +449,7 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
   A.model = h->model_dev; A.hull = h->hull_dev; A.qpos = h->qpos; A.qvel = h->qvel; A.qacc_ws = h->qacc_ws; A.qpos_lo = h->qpos_lo; A.qvel_lo = h->qvel_lo;
   A.ctrl = ctrl ? ctrl : h->qvel;   // env modes compute ctrl in-kernel; the pointer only has to be readable
   A.sensordata = h->sensordata; A.flags = h->flags; A.stats = h->stats; A.nenv = h->num_envs; A.nsub = nsub;
-  A.disable_contact = h->disable_contact; A.no_tier_return = !h->tier_return; A.dbg = dbg; A.dbg_env = dbg_env; A.prof = h->prof;
+  A.disable_contact = h->disable_contact; A.no_pairlist = !h->pair_list; A.no_tier_return = !h->tier_return; A.dbg = dbg; A.dbg_env = dbg_env; A.prof = h->prof;
   A.remaining = h->remaining; A.light_left = h->qctl + JQ_LIGHT; A.hint = h->use_hints ? h->hint : nullptr; A.hint_mode = h->use_hints;
   for (int t = 0; t < 3; t++) { A.q[t].list = h->qlist + (size_t)t * 2 * h->num_envs; A.q[t].count = h->qctl + JQ_COUNT + t; A.q[t].taken = h->qctl + JQ_TAKEN + t; A.q[t].limit = h->qctl + JQ_LIMIT + t; A.q[t].reserve = h->qctl + JQ_RESERVE + t; }
   A.routed_mark = nullptr; A.launch_id = ++h->launch_id;
@@ -483,9 +503,9 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
   if (conc) {
     HIPCHK(h, hipEventRecord(h->ev_fork, st));
     for (int t = 2; t >= 0; t--) HIPCHK(h, hipStreamWaitEvent(h->side[t], h->ev_fork, 0));
-    JLAUNCH(h, jaco_physics_kernel_huge_workers, dim3((unsigned)h->workers_huge), dim3(64), 0, h->side[2], A);
-    JLAUNCH(h, jaco_physics_kernel_heavy_workers, dim3((unsigned)h->workers_heavy), dim3(64), 0, h->side[1], A);
-    JLAUNCH(h, jaco_physics_kernel_medium, dim3((unsigned)h->workers), dim3(64), 0, h->side[0], A);
+    JLAUNCHK(h, JK_HUGE, (unsigned)h->workers_huge, h->side[2], A);
+    JLAUNCHK(h, JK_HEAVY, (unsigned)h->workers_heavy, h->side[1], A);
+    JLAUNCHK(h, JK_MEDIUM, (unsigned)h->workers, h->side[0], A);
     HIPCHK(h, hipGetLastError());
     for (int t = 0; t < 3; t++) HIPCHK(h, hipEventRecord(h->ev_join[t], h->side[t]));
   }
@@ -499,8 +519,8 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
   }
   if (conc) HIPCHK(h, hipEventRecord(h->ev_pre, st));
   if (kev) HIPCHK(h, hipEventRecord(kev->first, st));
-  if (A.nslots || io.mode >= 2) JLAUNCH(h, jaco_physics_kernel_listed, dim3(light_grid), dim3(64), 0, st, A);   // (resets: forward passes, placing hold)
-  else JLAUNCH(h, jaco_physics_kernel, dim3(light_grid), dim3(64), 0, st, A);
+  if (A.nslots || io.mode >= 2) JLAUNCHK(h, JK_LISTED, light_grid, st, A);   // (resets: forward passes, placing hold)
+  else JLAUNCHK(h, JK_STEP, light_grid, st, A);
   if (kev) HIPCHK(h, hipEventRecord(kev->second, st));
   HIPCHK(h, hipGetLastError());
   if (conc) for (int t = 0; t < 3; t++) HIPCHK(h, hipStreamWaitEvent(st, h->ev_join[t], 0));
@@ -509,18 +529,18 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
   unsigned mg = ne < 2048 ? ne : 2048, hg = ne < JACO_HEAVY_GRID ? ne : JACO_HEAVY_GRID, gg = ne < 512 ? ne : 512;
   if (io.mode == 2) { mg = mg < 64 ? mg : 64; hg = hg < 64 ? hg : 64; gg = gg < 256 ? gg : 256; }   // (reset-time forward passes: overflows of the light tier go straight to the last one)
   if (io.mode == 4 || io.mode == 5) { if (ev) HIPCHK(h, hipEventRecord(ev->second, st)); return JACO_OK; }   // take_action / terminal_inspection run no substep: nothing can overflow
-  if (io.mode != 2) JLAUNCH(h, jaco_physics_kernel_medium_drain, dim3(mg), dim3(64), 0, st, A);   // (mode 2 queues for the last tier only)
+  if (io.mode != 2) JLAUNCHK(h, JK_MEDIUM_DRAIN, mg, st, A);   // (mode 2 queues for the last tier only)
   if (h->handdown && io.mode == 1) {
     // the heavy tier holds 4 envs per CU: an env that needed it for a few substeps is passed back down to a second medium drain
     // (8 per CU) rather than kept there for the rest of its step; what overflows again is served by a second, final heavy drain
     A.handdown = 1;
-    JLAUNCH(h, jaco_physics_kernel_heavy_drain, dim3(hg), dim3(64), 0, st, A);
+    JLAUNCHK(h, JK_HEAVY_DRAIN, hg, st, A);
     A.handdown = 0;
     JLAUNCH(h, jaco_drain_round2_kernel, dim3(1), dim3(1), 0, st, h->qctl, (int)mg, (int)hg);
-    JLAUNCH(h, jaco_physics_kernel_medium_drain, dim3(mg), dim3(64), 0, st, A);
+    JLAUNCHK(h, JK_MEDIUM_DRAIN, mg, st, A);
   }
-  if (io.mode != 2) JLAUNCH(h, jaco_physics_kernel_heavy_drain, dim3(hg), dim3(64), 0, st, A);
-  JLAUNCH(h, jaco_physics_kernel_huge_drain, dim3(gg), dim3(64), 0, st, A);
+  if (io.mode != 2) JLAUNCHK(h, JK_HEAVY_DRAIN, hg, st, A);
+  JLAUNCHK(h, JK_HUGE_DRAIN, gg, st, A);
   HIPCHK(h, hipGetLastError());
   if (ev) HIPCHK(h, hipEventRecord(ev->second, st));
   return JACO_OK;
@@ -704,6 +724,7 @@ extern "C" int jaco_set_option(JacoHandle* h, const char* name, double v) {
   ENTER(h);
   JacoModelDev& m = h->model_host;
   if (!strcmp(name, "disable_contact")) { h->disable_contact = v != 0; return JACO_OK; }
+  if (!strcmp(name, "pair_list")) { h->pair_list = v != 0; return JACO_OK; }
   if (!strcmp(name, "schedule")) { h->schedule = v != 0; return JACO_OK; }
   if (!strcmp(name, "concurrent_heavy")) { h->concurrent = v != 0; return JACO_OK; }
   if (!strcmp(name, "tier_return")) { h->tier_return = v != 0; return JACO_OK; }

@@ -103,6 +103,7 @@ struct JacoStepArgs {
   int* light_left;     // [1] light-tier workgroups still running (0: the resident workers leave, the drains take the rest)
   int* hint;           // [nenv] highest tier (0..3) the env's last step really needed, or nullptr: where its next step starts
   int nenv, nsub, disable_contact;
+  int no_pairlist;     // 1: the bounding-sphere phase tests every pair in every substep (option "pair_list" = 0: comparison runs)
   int handdown;        // 1: a heavy-tier workgroup (4 per CU) passes an env that has calmed down on to the medium queue instead of running the
                        //    medium / light code itself for the rest of the step (first heavy drain only: a second medium drain follows it)
   int hint_mode;       // 1: an env's next step starts in the biggest tier this step really needed; 2: in the tier its last substep needed
@@ -785,7 +786,6 @@ JDEV void stage_accumulate(const JacoModelDev* m, L& s, int lane) {
 // Per-lane model constants of the stages after the tree walk, fetched in one go right after it: their L2 round trip is hidden
 // behind the subtree sums and the mass matrix instead of being paid, one dependent load at a time, in front of every stage.
 struct StagePrefetch {
-  int codes[JMAXPAIR / 64];   // stage C, phase 1: this lane's pair of every 64-pair chunk
   int mp0, mp1;               // stage M: this lane's mass-matrix entries
   float damping;              // joint damping of dof `lane`
   float stiffness, springref; int sqadr;   // joint spring of dof `lane` (models that have any)
@@ -793,8 +793,6 @@ struct StagePrefetch {
 };
 JDEV StagePrefetch stage_prefetch(const JacoModelDev* m, int lane) {
   StagePrefetch P;
-#pragma unroll
-  for (int ch = 0; ch < JMAXPAIR / 64; ch++) P.codes[ch] = m->pair_code[ch * 64 + lane];   // (zero-padded to JMAXPAIR: straight-line loads)
   P.mp0 = m->mpair[lane]; P.mp1 = m->mpair[64 + lane];                                     // (zero-padded to JMAXMPAIR)
   P.damping = m->d_damping[lane < JNV ? lane : 0];
   P.stiffness = 0.f; P.springref = 0.f; P.sqadr = 0;
@@ -1515,7 +1513,9 @@ JDEV int run_env(const JacoStepArgs& A_, JacoLDS<C>& s, int env, int nsub, int l
   pc.row = A.prof ? A.prof + (size_t)env * JPROF_N : nullptr;
   pc.tprev = __builtin_amdgcn_s_memtime();
 #endif
+  PairList<C> pl;   // broadphase pair list, carried from substep to substep (collision.h)
 again:
+  pl.n = -1;
   for (int sub = sub0; sub < nsub; sub++) {
     Ap = args_view(A_);
     m = opaque_ptr(A.model);
@@ -1583,7 +1583,7 @@ again:
     // which are dead once the contact list exists.  (Actuation touches neither: no synchronisation of its own.)
     unsigned cflags = 0;
     if (!A.disable_contact) {
-      stage_collision(A, m, s, lane, cflags, pc, pf.codes);
+      stage_collision(A, m, s, lane, cflags, pc, pl);
       wave_sync();
       JSTAMP(4);
       stage_limit_rows(m, s, lane, pf);
@@ -1895,6 +1895,15 @@ again:
 #undef A
 }
 
+// The library is built from several translation units so that the long device compiles run side by side (__graft_entry__.build):
+// kernels.hip is compiled once per kernel with -DJACO_TU=<n> (JACO_TU_HAS(n): this unit defines kernel n), jaco_env.hip (host side,
+// -DJACO_TU=-1) defines none and launches them through the jaco_launch_* functions below.  Without JACO_TU (CPU emulator build)
+// every kernel is defined.
+#ifdef JACO_TU
+#define JACO_TU_HAS(n) (JACO_TU == (n))
+#else
+#define JACO_TU_HAS(n) 1
+#endif
 // light tier: one workgroup (= one wavefront) per env
 #ifndef JACO_LIGHT_WAVES
 #define JACO_LIGHT_WAVES 3   // waves per SIMD the light kernel is compiled for: 13.3 KB of LDS per env allow 12 envs per CU, 168 VGPRs each
@@ -1926,18 +1935,22 @@ JDEV void light_grid(const JacoStepArgs& A, JacoLDS<JacoLight>& s) {
   }
   if (lane == 0 && A.light_left) jaco_atomic_dec(A.light_left, false);
 }
+#if JACO_TU_HAS(0)
 __global__ __launch_bounds__(64, JACO_LIGHT_WAVES) void jaco_physics_kernel(JacoStepArgs A) {   // modes 0 and 1 only
   __shared__ JacoLDS<JacoLight> s;
   JEMU_POISON(s);
   light_grid<false>(A, s);
 }
+#endif
 // the full code under its own name for reset-time launches (forward pass, placing hold; for a masked reset a small grid that walks
 // the list of reset envs): the step kernel's launch statistics (rocprofv3 --stats, bench.py's kernel_ms) then hold step launches only
+#if JACO_TU_HAS(1)
 __global__ __launch_bounds__(64, JACO_LIGHT_WAVES) void jaco_physics_kernel_listed(JacoStepArgs A) {   // every mode
   __shared__ JacoLDS<JacoLight> s;
   JEMU_POISON(s);
   light_grid<true>(A, s);
 }
+#endif
 // One handed-over env on a bigger-tier workgroup: the big code (medium: TB = 1, heavy: TB = 2) runs while the overflow
 // lasts, the light code in between, until the env's step is complete.  Returns 0, or -- medium only -- the substeps left
 // when the env overflowed the medium capacities too (the caller passes it on to the heavy tier).
@@ -2091,37 +2104,73 @@ JDEV void tier_drain(const JacoStepArgs& A, LDS& u, int lane) {
 // The resident workers run with a raised wave priority (s_setprio): the envs they serve are the step's critical path -- a huge-tier
 // env step (hand inside the pedestal after a reset: ~400 rows) takes as long as the whole light grid, and every issue slot it loses
 // to the three light waves sharing its SIMD is added to the step's tail.
+#if JACO_TU_HAS(2)
 __global__ __launch_bounds__(64, 2) void jaco_physics_kernel_medium(JacoStepArgs A) {
   __builtin_amdgcn_s_setprio(1);
   __shared__ JacoMediumLDS u;
   JEMU_POISON(u);
   tier_workers<0>(A, u, lane_id());
 }
+#endif
+#if JACO_TU_HAS(3)
 __global__ __launch_bounds__(64, 2) void jaco_physics_kernel_medium_drain(JacoStepArgs A) {
   __shared__ JacoMediumLDS u;
   JEMU_POISON(u);
   tier_drain<0>(A, u, lane_id());
 }
+#endif
+#if JACO_TU_HAS(4)
 __global__ __launch_bounds__(64, JACO_HEAVY_WAVES) void jaco_physics_kernel_heavy_workers(JacoStepArgs A) {
   __builtin_amdgcn_s_setprio(2);
   __shared__ JacoAllLDS u;
   JEMU_POISON(u);
   tier_workers<1>(A, u, lane_id());
 }
+#endif
+#if JACO_TU_HAS(5)
 __global__ __launch_bounds__(64, JACO_HEAVY_WAVES) void jaco_physics_kernel_heavy_drain(JacoStepArgs A) {
   __shared__ JacoAllLDS u;
   JEMU_POISON(u);
   tier_drain<1>(A, u, lane_id());
 }
+#endif
+#if JACO_TU_HAS(6)
 __global__ __launch_bounds__(64) void jaco_physics_kernel_huge_workers(JacoStepArgs A) {
   __builtin_amdgcn_s_setprio(3);
   __shared__ JacoHugeLDS u;
   JEMU_POISON(u);
   tier_workers<2>(A, u, lane_id());
 }
+#endif
+#if JACO_TU_HAS(7)
 __global__ __launch_bounds__(64) void jaco_physics_kernel_huge_drain(JacoStepArgs A) {
   __builtin_amdgcn_s_setprio(3);
   __shared__ JacoHugeLDS u;
   JEMU_POISON(u);
   tier_drain<2>(A, u, lane_id());
 }
+#endif
+
+// Launchers, one per kernel, defined next to it (kernels.hip) and called by the host side (jaco_env.hip).  k: 0 step kernel, 1 full-code
+// twin (reset-time modes), 2 / 3 medium workers / drain, 4 / 5 heavy, 6 / 7 huge.
+#ifndef JACO_EMULATED
+void jaco_launch_kernel(int k, unsigned grid, hipStream_t st, const JacoStepArgs& A);
+#define JACO_DEFINE_LAUNCHER(n, kernel) void jaco_launch_kernel_##n(unsigned grid, hipStream_t st, const JacoStepArgs& A) { hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), 0, st, A); }
+#if defined(JACO_TU) && JACO_TU == 0
+JACO_DEFINE_LAUNCHER(0, jaco_physics_kernel)
+#elif defined(JACO_TU) && JACO_TU == 1
+JACO_DEFINE_LAUNCHER(1, jaco_physics_kernel_listed)
+#elif defined(JACO_TU) && JACO_TU == 2
+JACO_DEFINE_LAUNCHER(2, jaco_physics_kernel_medium)
+#elif defined(JACO_TU) && JACO_TU == 3
+JACO_DEFINE_LAUNCHER(3, jaco_physics_kernel_medium_drain)
+#elif defined(JACO_TU) && JACO_TU == 4
+JACO_DEFINE_LAUNCHER(4, jaco_physics_kernel_heavy_workers)
+#elif defined(JACO_TU) && JACO_TU == 5
+JACO_DEFINE_LAUNCHER(5, jaco_physics_kernel_heavy_drain)
+#elif defined(JACO_TU) && JACO_TU == 6
+JACO_DEFINE_LAUNCHER(6, jaco_physics_kernel_huge_workers)
+#elif defined(JACO_TU) && JACO_TU == 7
+JACO_DEFINE_LAUNCHER(7, jaco_physics_kernel_huge_drain)
+#endif
+#endif

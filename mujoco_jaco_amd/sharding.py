@@ -36,6 +36,7 @@ class ObsGather:
         self.out = torch.empty(self.world * local_rows, width, device=device, dtype=dtype)
         self.device = torch.device(device)
         self._overlap = self.device.type == "cuda" and self.world > 1
+        self.timing, self._timed = False, []   # enable_timing(): event pairs around each collective on the side stream
         if self._overlap:
             self.stage = torch.empty(local_rows, width, device=device, dtype=dtype)
             self.side = torch.cuda.Stream(device=device)
@@ -61,14 +62,32 @@ class ObsGather:
         try:
             with torch.cuda.stream(self.side):
                 self.side.wait_event(self._ready)
+                t0 = None
+                if self.timing:
+                    t0 = torch.cuda.Event(enable_timing=True); t0.record(self.side)
                 dist.all_gather_into_tensor(self.out, self.stage, group=self.group)
-                self._done = torch.cuda.Event()
+                self._done = torch.cuda.Event(enable_timing=self.timing)
                 self._done.record(self.side)
+                if t0 is not None:
+                    self._timed.append((t0, self._done))
         except RuntimeError as e:   # a backend that cannot issue the collective from a side stream: same collective, caller's stream, said out loud
             import sys
             print("ObsGather: overlapped gather unavailable (%s); using the blocking form" % (str(e).splitlines()[0],), file=sys.stderr)
             self._overlap, self._done = False, None
             self(local_obs)
+
+    def enable_timing(self, on=True):
+        """Time every collective started from here on with an event pair on the side stream (what the gather itself costs, as
+        opposed to what it adds to a step: it runs under the next step's launch set)."""
+        self.timing, self._timed = bool(on), []
+
+    def gather_time_ms(self):
+        """(mean, max, count) of the timed collectives' device time in ms; synchronises the side stream.  None if nothing was timed."""
+        if not self._timed:
+            return None
+        self.side.synchronize()
+        ms = [a.elapsed_time(b) for a, b in self._timed]
+        return sum(ms) / len(ms), max(ms), len(ms)
 
     def wait(self):
         if self._overlap and self._done is not None:

@@ -25,11 +25,16 @@ static int g_use_hints = 0;
 static int g_obs_mode = 0;
 extern "C" void emu_set_obs_mode(int v) { g_obs_mode = v; }
 extern "C" void emu_set_hints(int on) { g_use_hints = on; }
+long emu_counter[4] = {0, 0, 0, 0};
+extern "C" long emu_get_counter(int i, int reset) { long v = emu_counter[i & 3]; if (reset) emu_counter[i & 3] = 0; return v; }
+static int g_no_pairlist = 0;
+extern "C" void emu_set_pair_list(int on) { g_no_pairlist = !on; }   // 0: every pair tested in every substep (option "pair_list" = 0 of the library)
 static int g_handdown = 0, g_handed_down = 0;
 extern "C" void emu_set_handdown(int on) { g_handdown = on; }
 extern "C" int emu_handed_down() { return g_handed_down; }   // envs passed from the heavy drain to the second medium drain so far
 static int emu_launch(JacoStepArgs A, int* heavy_envs) {
   A.no_tier_return = g_no_tier_return_fwd();
+  A.no_pairlist = g_no_pairlist;
   A.obs_mode = g_obs_mode;
   std::vector<int> remaining(A.nenv, 0), lists(6 * (size_t)A.nenv, -1);
   int count[3] = {0, 0, 0}, taken[3] = {0, 0, 0}, light_left = A.nenv;

@@ -437,3 +437,39 @@ def test_side_rows_keep_a_68_row_env_in_the_light_tier(names, model_arrays):
             if 64 < e.stats[0, 1] <= 80 and not (e.flags[0] & 32):
                 seen += 1                                                                    # more rows than the main buffer holds, and no bigger tier was used
     assert seen >= 2
+
+
+def test_pair_list_does_not_change_results(names, model_arrays):
+    """Broadphase pair list (collision.h "Pair list"): the list pass runs the same exact test on a superset of the pairs that can
+    pass it, so state, observation, contact / row / candidate counts must equal those of the all-pairs pass BIT FOR BIT -- over
+    env steps with large actions (the list is rebuilt inside a step: markers jump, the arm sweeps several cm) and with the arm at rest."""
+    import ctypes
+    nenv, fs = 6, 25
+    runs, passes = [], {}
+    for on in (1, 0):
+        e = EmuJacoEnv(nenv=nenv, frame_skip=fs)
+        e.L.emu_set_pair_list.argtypes = [ctypes.c_int]
+        e.L.emu_get_counter.argtypes = [ctypes.c_int, ctypes.c_int]; e.L.emu_get_counter.restype = ctypes.c_long
+        e.L.emu_set_pair_list(on)
+        e.L.emu_get_counter(0, 1); e.L.emu_get_counter(1, 1)
+        try:
+            q = workload.reset_states(model_arrays["qpos0"], nenv, seed=17)
+            e.qpos[:] = q; e.task[:, 4:7] = q[:, 9:12]; e.task[:, 7] = q[:, 16]; e.task[:, 8] = q[:, 17]; e.task[:, 9] = 0.3468
+            rng = np.random.default_rng(5)
+            e.forward(rng.uniform(size=(nenv, 12)).astype(np.float32))
+            trace = []
+            for step in range(3):
+                a = rng.uniform(-1, 1, (nenv, 7)).astype(np.float32) * (1.0 if step < 2 else 0.02)
+                obs, rew, done = e.env_step(a, rng.uniform(size=(nenv, 12)).astype(np.float32))
+                trace.append((e.qpos.copy(), e.qvel.copy(), obs, rew, done, e.stats.copy(), e.sensordata.copy(), e.flags.copy()))
+            runs.append(trace)
+            passes[on] = (e.L.emu_get_counter(0, 1), e.L.emu_get_counter(1, 1), e.L.emu_get_counter(2, 1))
+        finally:
+            e.L.emu_set_pair_list(1)
+    for ta, tb in zip(*runs):
+        for x, y in zip(ta, tb):
+            assert np.array_equal(x, y)
+    assert runs[0][-1][5][:, 0].max() > 0          # contacts were present
+    full, listed, entries = passes[1]
+    assert passes[0][1] == 0 and listed > 2 * full > 0, passes   # the list really carried most substeps, and was rebuilt inside the steps
+    print("pair list: %d all-pairs passes, %d list passes (%.0f entries each) over %d env substeps" % (full, listed, entries / listed, nenv * fs * 3))

@@ -66,3 +66,4 @@ def test_bench_self_launch_dry_gather():
     assert p.returncode == 0, p.stderr[-2000:]
     line = json.loads(p.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["gather_ok"] and line["steps"] == 3
+    assert 0 < line["per_rank"]["ms_per_step_min"] <= line["per_rank"]["ms_per_step_max"]
