@@ -431,7 +431,16 @@ def main():
             env.set_option("disable_contact", 1)
         gathered = torch.empty(world * B, env.nq, device=dev) if world > 1 else None
 
+        # "random-action rollouts": fresh motor torques U(-1, 1) x 0.2 x force range every launch (one launch = `fs` substeps), fingers held at
+        # 0.6 -- the same distribution as workload.random_ctrl, drawn on the GPU.  (Constant torques for the whole run, as rounds 1-3 had it,
+        # spin the limit-free arm joints up to hundreds of rad/s within the 11 000 substeps of the config-2 leg: a non-physical workload
+        # that ended in the velocity quarantine for some envs.)
+        tq = torch.tensor([30, 30, 30, 15, 15, 15] + [0] * (env.nu - 6), dtype=torch.float32, device=dev)[:env.nu] * 0.2
+        hold = torch.tensor([0] * 6 + [0.6] * (env.nu - 6), dtype=torch.float32, device=dev)[:env.nu]
+        cgen = torch.Generator(device=dev); cgen.manual_seed(3000 + rank)
+
         def step():
+            ctrl.copy_((torch.rand(B, env.nu, device=dev, generator=cgen) * 2 - 1) * tq + hold)
             env.send_forces(ctrl, nsub=fs)
             if world > 1:
                 qpos, _, _ = env.state_views()

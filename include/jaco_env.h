@@ -48,6 +48,9 @@ extern "C" {
 #define JACO_TASK_REACHING 2
 #define JACO_TASK_GRASPING 3       /* reward env_mujoco_util.py:352-391, termination :521-536 (+ the success flag its 3-tuple lacks), reset pre-reach :123-170 */
 #define JACO_TASK_PICKANDPLACE 4   /* reward 0, termination :585-600 with the `picked` flag, 1200-step episodes */
+#define JACO_TASK_CARRYING 5       /* reset = in-hand hold :106-117 + pre-reach :123-170; reward 0; every episode ends in its first step (:549-550) */
+#define JACO_TASK_RELEASING 6      /* own init pose :186-189, in-hand hold :106-117; reward 0; termination :551-566 (+ success flag) */
+#define JACO_TASK_PUSHING 7        /* 6-wide action (env_mujoco.py:79-82); reward 0; every episode ends in its first step (:583-584) */
 
 typedef struct JacoHandle JacoHandle;
 

@@ -332,6 +332,9 @@ JDEV v3 support_prim(const MprGeom& G, v3 l) {   // box / sphere, local frame
 // of its own best vertex, so after the DPP argmax the winner is broadcast from its lane instead of being re-fetched from
 // memory.  Lowest vertex index wins ties (a serial first-max scan), as in support_geom.
 JDEV Sup mpr_support(const JacoStepArgs& A, const MprGeom& G1, const MprGeom& G2, v3 dir, int lane) {
+#ifdef JACO_EMULATED
+  if (lane == 0) emu_counter[7]++;
+#endif
   const v3 l1 = mulT(G1.P.R, dir), l2 = mulT(G2.P.R, -dir);
   // hulls with a support table (modelc/supportmap.py): the cell of the direction lists every vertex that can be the
   // maximiser, one slot per lane -> one 16-byte load instead of a scan; the others are scanned (both hulls in one loop)
@@ -678,7 +681,13 @@ JDEV void stage_collision(const JacoStepArgs& A, const JacoModelDev* m, L& s, in
       } else {
         float depth;
         v3 dir, pos;
+#ifdef JACO_EMULATED
+        const long q0_ = emu_counter[7];
+#endif
         bool hit = mpr_penetration(A, m, s, g1, t1, g2, t2, lane, &depth, &dir, &pos);
+#ifdef JACO_EMULATED
+        if (lane == 0) { emu_counter[3]++; emu_counter[4] += hit; emu_counter[hit ? 5 : 6] += emu_counter[7] - q0_; }   // (CPU diagnostics: tools/mpr_query_stats.py)
+#endif
 #ifdef JACO_TRACE_MPR
         if (lane == 0) printf("mpr g1 %d g2 %d hit %d depth %g\n", g1, g2, (int)hit, hit ? depth : 0.f);
 #endif
@@ -712,7 +721,7 @@ JDEV void stage_collision(const JacoStepArgs& A, const JacoModelDev* m, L& s, in
 #define JSIDE_F 128      // [JSIDE_ROWS] row weights during the side solve, row forces after it
 template <class L>
 struct SideRows {
-  static constexpr bool on = L::Caps::MAXEFC == 64 && JNV - JB1 == 6 && (JNV - 6) * 6 + JNB * 6 >= JSIDE_F + JSIDE_ROWS;
+  static constexpr bool on = L::Caps::CONTACT && L::Caps::MAXEFC == 64 && JNV - JB1 == 6 && (JNV - 6) * 6 + JNB * 6 >= JSIDE_F + JSIDE_ROWS;
 };
 template <class L>
 JDEV float* side_buf(L& s) { return &s.cdof[6][0]; }

@@ -48,6 +48,9 @@ static_assert(JTASK_N == JTASK_FLOATS, "task row size");
 #define JTASK_REACHING 2
 #define JTASK_GRASPING 3
 #define JTASK_PICKANDPLACE 4
+#define JTASK_CARRYING 5     // object in hand after the hold AND the pre-reach loops (:106-117,123-170); every episode ends in its first step (:549-550)
+#define JTASK_RELEASING 6    // own init pose with the fingers at 0.6 (:186-189), object in hand (:106-117), termination :551-566 (reads the object's velocity)
+#define JTASK_PUSHING 7      // 6-wide action (env_mujoco.py:79-82); every episode ends in its first step (:583-584)
 
 #define JOSC_KP 50.f
 #define JOSC_KO 180.f
@@ -206,10 +209,10 @@ JDEV float reward_reaching(v3 ee, const float* eul, const float* goal, v3 base) 
 // ---------------------------------------------------------------- a11: termination (env_mujoco.py:144-150, env_mujoco_util.py:492-582)
 // returns done; *bonus, *succ; updates steps / episodes counters in the task row
 JDEV bool terminal_inspection(int task, float* trow, float q2, v3 ee, v3 base, v3 obj, v3 dest_goal, int touch, float* bonus, int* succ, float* wb,
-                              const float* eul = nullptr, const float* reachgoal = nullptr, float* picked = nullptr) {
+                              const float* eul = nullptr, const float* reachgoal = nullptr, float* picked = nullptr, float objvel = 0.f) {
   float steps = trow[JT_STEPS] + 1.f;
   trow[JT_STEPS] = steps;
-  // picking / placing 700, pickAndplace 1200, reaching / grasping 500 (env_mujoco.py:18-23)
+  // picking / placing 700, pickAndplace 1200, reaching / grasping / carrying / releasing / pushing 500 (env_mujoco.py:18-23)
   const float task_max = (task == JTASK_PICKING || task == JTASK_PLACING) ? 700.f : (task == JTASK_PICKANDPLACE ? 1200.f : 500.f);
   *succ = 0; *wb = 0.f;
   if (!(steps < task_max)) { *bonus = -10.f; return true; }
@@ -236,6 +239,15 @@ JDEV bool terminal_inspection(int task, float* trow, float q2, v3 ee, v3 base, v
     if (obj.z > 0.1898f + 0.07f && (touch == 1 || touch == 3) && *picked == 0.f) { *picked = 1.f; *bonus = 20.f; return false; }
     if (dd < 0.04f && touch == 0 && obj.z < 0.35f) { *bonus = 180.f; *succ = 1; return true; }
     if (obj.z < 0.1f) { *bonus = -20.f; return true; }
+    *bonus = 0.f;
+    return false;
+  }
+  if (task == JTASK_CARRYING || task == JTASK_PUSHING) { *bonus = 0.f; return true; }   // `return True, 0, wb` (:549-550,583-584; 3-tuples: success flag 0 added)
+  if (task == JTASK_RELEASING) {   // :551-566 (3-tuple in the reference: the success flag is the fix); objvel = |qvel[9:12]| (mujoco.py:212-215)
+    const float dx = dest_goal.x - obj.x, dy = dest_goal.y - obj.y, dd = sqrtf(dx * dx + dy * dy);
+    if (obj.z < 0.1f) { *bonus = -20.f; return true; }
+    if (dd < 0.04f && touch == 0 && obj.z < 0.35f && objvel < 0.01f) { *bonus = 200.f - n * 0.1f; *succ = 1; return true; }
+    if (dd > 0.04f && touch == 0 && obj.z < 0.20f) { *bonus = -20.f; return true; }
     *bonus = 0.f;
     return false;
   }
@@ -296,11 +308,16 @@ JDEV void reset_draws(int task_id, unsigned long long seed, unsigned env, int ha
   unsigned c = __float_as_uint(t[JT_RNG]);
 #define JRU(lo, hi) ((lo) + ((hi) - (lo)) * rng_uniform(seed, env, c++))
   const float PI = 3.14159265358979323846f;
-  if (task_id == JTASK_PLACING || task_id == JTASK_GRASPING) {   // 'carrying', 'grasping', 'placing' (:181-185)
+  if (task_id == JTASK_PLACING || task_id == JTASK_GRASPING || task_id == JTASK_CARRYING) {   // 'carrying', 'grasping', 'placing' (:181-185)
     const float pick = JRU(0.f, 1.f);
     const float a0 = pick < 0.5f ? JRU(3.f * PI / 8.f, PI / 2.f) : JRU(PI / 2.f, 5.f * PI / 8.f);
     q[0] = a0; q[1] = 3.85f; q[2] = JRU(1.f, 1.1f); q[3] = JRU(2.f, 2.1f); q[4] = JRU(0.8f, 2.3f); q[5] = JRU(-1.2f, -1.1f);
-  } else {                                                       // 'reaching', 'picking', 'pickAndplace' (:177-180)
+  } else if (task_id == JTASK_RELEASING) {                       // 'releasing' (:186-189): nine values, the finger joints start at 0.6
+    q[0] = JRU(1.9f, 2.f); q[1] = JRU(3.3f, 3.6f); q[2] = JRU(0.5f, 0.8f); q[3] = JRU(1.8f, 2.5f); q[4] = JRU(1.3f, 2.f);
+    q[5] = JRU(-0.4f, -0.9f);   // (uniform(-0.4, -0.9): numpy draws low + (high - low) u whatever the order of the bounds)
+    q[6] = 0.6f; q[7] = 0.6f; q[8] = 0.6f;
+  } else {                                                       // 'reaching', 'picking', 'pickAndplace' (:177-180); 'pushing': the reference has
+                                                                 // no branch for it (UnboundLocalError in _create_init_angle) -- this one is used
     q[0] = JRU(0.7f, 2.5f); q[1] = JRU(3.8f, 4.f); q[2] = JRU(1.f, 1.7f); q[3] = JRU(1.8f, 2.5f); q[4] = JRU(1.f, 2.5f); q[5] = JRU(0.8f, 2.3f);
   }
   for (int k = 0; k < JTASK_N; k++) if (k != JT_RNG) t[k] = 0.f;

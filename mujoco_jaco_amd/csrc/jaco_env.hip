@@ -17,8 +17,8 @@
 // the physics kernels live in their own translation units (kernels.hip, one per kernel)
 #define JACO_DECLARE_LAUNCHER(n) void jaco_launch_kernel_##n(unsigned grid, hipStream_t st, const JacoStepArgs& A);
 JACO_DECLARE_LAUNCHER(0) JACO_DECLARE_LAUNCHER(1) JACO_DECLARE_LAUNCHER(2) JACO_DECLARE_LAUNCHER(3)
-JACO_DECLARE_LAUNCHER(4) JACO_DECLARE_LAUNCHER(5) JACO_DECLARE_LAUNCHER(6) JACO_DECLARE_LAUNCHER(7)
-enum { JK_STEP = 0, JK_LISTED = 1, JK_MEDIUM = 2, JK_MEDIUM_DRAIN = 3, JK_HEAVY = 4, JK_HEAVY_DRAIN = 5, JK_HUGE = 6, JK_HUGE_DRAIN = 7 };
+JACO_DECLARE_LAUNCHER(4) JACO_DECLARE_LAUNCHER(5) JACO_DECLARE_LAUNCHER(6) JACO_DECLARE_LAUNCHER(7) JACO_DECLARE_LAUNCHER(8)
+enum { JK_STEP = 0, JK_LISTED = 1, JK_MEDIUM = 2, JK_MEDIUM_DRAIN = 3, JK_HEAVY = 4, JK_HEAVY_DRAIN = 5, JK_HUGE = 6, JK_HUGE_DRAIN = 7, JK_ARM = 8 };
 void jaco_launch_kernel(int k, unsigned grid, hipStream_t st, const JacoStepArgs& A) {
   switch (k) {
     case 0: jaco_launch_kernel_0(grid, st, A); break;
@@ -28,7 +28,8 @@ void jaco_launch_kernel(int k, unsigned grid, hipStream_t st, const JacoStepArgs
     case 4: jaco_launch_kernel_4(grid, st, A); break;
     case 5: jaco_launch_kernel_5(grid, st, A); break;
     case 6: jaco_launch_kernel_6(grid, st, A); break;
-    default: jaco_launch_kernel_7(grid, st, A); break;
+    case 7: jaco_launch_kernel_7(grid, st, A); break;
+    default: jaco_launch_kernel_8(grid, st, A); break;
   }
 }
 #define JLAUNCHK(h, k, grid, st, A) do { jaco_launch_kernel((k), (grid), (st), (A)); (h)->nlaunch++; } while (0)
@@ -240,7 +241,7 @@ extern "C" int jaco_dims(const JacoHandle* h, int* nq, int* nv, int* nu, int* ns
   if (nu) *nu = h->model_host.nu;
   if (nsensor) *nsensor = h->model_host.nsensor;
   if (nobs) *nobs = 26;
-  if (nact) *nact = h->task == JACO_TASK_REACHING ? 6 : 7;
+  if (nact) *nact = (h->task == JACO_TASK_REACHING || h->task == JACO_TASK_PUSHING) ? 6 : 7;
   return JACO_OK;
 }
 extern "C" int jaco_num_envs(const JacoHandle* h) { return h ? h->num_envs : JACO_EINVAL; }
@@ -453,12 +454,12 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
   A.remaining = h->remaining; A.light_left = h->qctl + JQ_LIGHT; A.hint = h->use_hints ? h->hint : nullptr; A.hint_mode = h->use_hints;
   for (int t = 0; t < 3; t++) { A.q[t].list = h->qlist + (size_t)t * 2 * h->num_envs; A.q[t].count = h->qctl + JQ_COUNT + t; A.q[t].taken = h->qctl + JQ_TAKEN + t; A.q[t].limit = h->qctl + JQ_LIMIT + t; A.q[t].reserve = h->qctl + JQ_RESERVE + t; }
   A.routed_mark = nullptr; A.launch_id = ++h->launch_id;
-  A.env_mode = io.mode; A.task_id = h->task; A.nact = h->task == JACO_TASK_REACHING ? 6 : 7; A.seed = h->seed;
+  A.env_mode = io.mode; A.task_id = h->task; A.nact = (h->task == JACO_TASK_REACHING || h->task == JACO_TASK_PUSHING) ? 6 : 7; A.seed = h->seed;
   A.task = h->task_rows; A.cache = h->cache; A.action = io.action; A.noise = h->noise; A.obs_mode = h->obs_mode; A.subgoal = h->subgoal; A.obs = io.obs; A.reward = io.reward; A.done = io.done; A.mask = io.mask; A.marker = h->marker;
   A.cost = h->cost;
   // auto-reset folds draws + sim.forward() + observation into the step wave: the tasks whose reset is nothing more (placing holds the
   // object for 150 substeps, grasping pre-reaches: those keep the explicit jaco_reset)
-  A.auto_reset = h->auto_reset && io.mode == 1 && (h->task == JACO_TASK_PICKING || h->task == JACO_TASK_REACHING || h->task == JACO_TASK_PICKANDPLACE);
+  A.auto_reset = h->auto_reset && io.mode == 1 && (h->task == JACO_TASK_PICKING || h->task == JACO_TASK_REACHING || h->task == JACO_TASK_PICKANDPLACE || h->task == JACO_TASK_PUSHING);
   A.qpos0 = h->qpos0_dev;
   const bool reorder = io.mode == 1 && h->schedule && nsub >= h->min_nsub_sched && h->num_envs >= 4096;
   std::pair<hipEvent_t, hipEvent_t>*ev = nullptr, *kev = nullptr;
@@ -475,6 +476,17 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
     kev = &h->kevents[h->events_used];
     ev = &h->events[h->events_used++];
     HIPCHK(h, hipEventRecord(ev->first, st));
+  }
+  // Contact-free step (option disable_contact, or a model without a collidable pair): its own lean kernel, alone -- no capacity can
+  // overflow (at most one limit row per joint), so there is nothing to route, order, serve or drain.
+  if ((h->disable_contact || h->model_host.npair == 0) && io.mode <= 1) {
+    A.disable_contact = 1; A.hint = nullptr;
+    if (kev) HIPCHK(h, hipEventRecord(kev->first, st));
+    JLAUNCHK(h, JK_ARM, (unsigned)h->num_envs, st, A);
+    if (kev) HIPCHK(h, hipEventRecord(kev->second, st));
+    HIPCHK(h, hipGetLastError());
+    if (ev) HIPCHK(h, hipEventRecord(ev->second, st));
+    return JACO_OK;
   }
   // masked reset: the reset kernel has listed its envs; a small grid walks that list instead of 65 536 workgroups finding out one by
   // one that they have nothing to do (0.9 ms per launch)
@@ -598,11 +610,11 @@ extern "C" int jaco_reset(JacoHandle* h, const uint8_t* mask_dev, float* obs_dev
   h->reset_listed = mask_dev != nullptr;
   JLAUNCH(h, jaco_reset_kernel, dim3((unsigned)((h->num_envs + 255) / 256)), dim3(256), 0, st, R);
   HIPCHK(h, hipGetLastError());
-  if (h->task == JACO_TASK_PLACING) {   // object into the hand, 150 held substeps while the fingers close (env_mujoco_util.py:106-117)
+  if (h->task == JACO_TASK_PLACING || h->task == JACO_TASK_CARRYING || h->task == JACO_TASK_RELEASING) {   // object into the hand, 150 held substeps while the fingers close (env_mujoco_util.py:106-117)
     int rc = jaco_placing_hold(h, mask_dev, JACO_PLACING_HOLD_SUBSTEPS, stream);
     if (rc) { h->reset_listed = false; return rc; }
   }
-  if (h->task == JACO_TASK_GRASPING) {   // the pre-reach loops (env_mujoco_util.py:123-170); the observation comes from their last substep's mjData
+  if (h->task == JACO_TASK_GRASPING || h->task == JACO_TASK_CARRYING) {   // the pre-reach loops (env_mujoco_util.py:123-170); the observation comes from their last substep's mjData
     int rc = jaco_grasping_prereach(h, mask_dev, JACO_PREREACH_MAX_SUBSTEPS, obs_dev, stream);
     h->reset_listed = false;
     return rc;

@@ -23,11 +23,16 @@
 //   heavy: <= 256 rows / 64 contacts -> 4 rows per lane, ~43 KB LDS, for envs that overflow medium;
 //   huge: <= 512 rows / 128 contacts -> 8 rows per lane, ~80 KB LDS, for envs that overflow heavy (beyond that rows are dropped and flagged).
 // A light wave that meets an overflow hands its env (state untouched for that substep) to the heavy launch.
-template <int MAXEFC_, int MAXCON_, int MAXCAND_>
+template <int MAXEFC_, int MAXCON_, int MAXCAND_, bool CONTACT_ = true>
 struct JacoCaps {
   static_assert(MAXEFC_ % 64 == 0, "rows are dealt out 64 at a time (one per lane): the row capacity must be a multiple of 64");
   static_assert(MAXCAND_ <= MAXEFC_ * 25 - 520 - 256 - 576, "the candidate list must fit behind the geom poses in the constraint-row area");
   static constexpr int MAXEFC = MAXEFC_, MAXCON = MAXCON_, MAXCAND = MAXCAND_, NR = MAXEFC_ / 64;
+  // CONTACT = false: the contact-free instantiation (arm-only models, option disable_contact): no geom poses, no contact list, and
+  // Jacobian storage for the joint-limit rows only (at most one per body)
+  static constexpr bool CONTACT = CONTACT_;
+  static constexpr int JROWS = CONTACT_ ? MAXEFC_ : 16, NGEOM = CONTACT_ ? JMAXGEOM : 1;
+  static_assert(CONTACT_ || JNB <= 16, "limit rows of the contact-free instantiation");
 };
 // Candidates = bounding-sphere survivors (closed fingers alone contribute > 64; with the EE sticks on the marker's sticks 130-200): their
 // list shares LDS with the constraint rows, which are bigger, so its capacity costs nothing -- and it must not be what sends
@@ -40,6 +45,7 @@ typedef JacoCaps<128, 32, 512> JacoMedium;   // (32 contacts x 4 pyramid rows = 
 #define JACO_HEAVY_WAVES 1
 #endif
 typedef JacoCaps<JACO_HEAVY_ROWS, JACO_HEAVY_CON, 512> JacoHeavy;
+typedef JacoCaps<64, 1, 1, false> JacoArm;    // contact-free: 8.4 KB of LDS, 128 VGPRs -> 16 envs per CU = 4 waves per SIMD (BASELINE config 2: 4 096 envs resident in one round)
 typedef JacoCaps<512, 128, 512> JacoHuge;    // 8 rows per lane: a reset that puts the hand inside the pedestal (1 % of picking resets: up to ~90 contacts / ~410 rows)
 #define JDBG_MAXCON 64
 #define JDBG_MAXEFC 256
@@ -211,14 +217,14 @@ struct JacoLDS {
   };
   union {
     struct {                                    // row builders .. Euler: constraint rows
-      alignas(16) float J[C::MAXEFC * JLD];
+      alignas(16) float J[C::JROWS * JLD];
       float e_aref[C::MAXEFC], e_D[C::MAXEFC], e_f[C::MAXEFC];
       int e_con[C::MAXEFC];                     // contact | edge << 8 | block bits << 16
     };
     struct {                                    // tree walk .. collision: geom poses, broadphase survivors
       float early_scratch[JSCRATCH];
-      alignas(16) float gpos[JMAXGEOM][4];      // world position + bounding radius: one 16-byte LDS read per geom in the broadphase
-      float gmat[JMAXGEOM][9];
+      alignas(16) float gpos[C::NGEOM][4];      // world position + bounding radius: one 16-byte LDS read per geom in the broadphase
+      float gmat[C::NGEOM][9];
       int cand[C::MAXCAND];
     };
   };
@@ -600,13 +606,20 @@ JDEV void stage_walk(const JacoModelDev* m, L& s, int lane, bool markers, JProfC
 #pragma unroll
   for (int k = 0; k < 6; k++) Imod[k] = m->b_inertia[b][k];
   const float mass = m->b_mass[b];
-  const bool isg = lane < m->ngeom;
+  constexpr bool GEOMS = L::Caps::CONTACT;   // (the contact-free instantiation has no use for geom poses)
+  const bool isg = GEOMS && lane < m->ngeom;
   const int gl = isg ? lane : 0;
-  const int gb = m->g_body[gl], km = markers ? m->g_marker[gl] : -1;
-  const float grb = m->g_rbound[gl];
-  const bool onmk = km >= 0 && gb < 0;
-  const v3 gp0 = ld3(onmk ? m->g_lpos[gl] : m->g_pos[gl]);
-  const m3 gR0 = ldm(onmk ? m->g_lmat[gl] : m->g_mat[gl]);
+  int gb = -1, km = -1;
+  float grb = 0.f;
+  v3 gp0 = mk3(0.f, 0.f, 0.f);
+  m3 gR0;
+  if (GEOMS) {
+    gb = m->g_body[gl]; km = markers ? m->g_marker[gl] : -1;
+    grb = m->g_rbound[gl];
+    const bool onmk = km >= 0 && gb < 0;
+    gp0 = ld3(onmk ? m->g_lpos[gl] : m->g_pos[gl]);
+    gR0 = ldm(onmk ? m->g_lmat[gl] : m->g_mat[gl]);
+  }
   v3 v = mk3(0.f, 0.f, 0.f);   // my column
   if (isf) {
     if (jt == JJ_HINGE) {
@@ -682,7 +695,7 @@ JDEV void stage_walk(const JacoModelDev* m, L& s, int lane, bool markers, JProfC
       }
     }
   }
-  if (isg) {   // geom poses (they share LDS with the constraint rows: every substep writes all of them)
+  if (GEOMS && isg) {   // geom poses (they share LDS with the constraint rows: every substep writes all of them)
     v3 gp = gp0; m3 gR = gR0;   // static: world pose from the model
     const int src = gb >= 0 ? gb : (km >= 0 ? nb + km : -1);   // rides on a moving body / on one of the two task-layer markers
     if (src >= 0) {
@@ -973,8 +986,13 @@ JDEV NewtonOut stage_newton(const JacoModelDev* m, L& s, const float (&mrow)[JNV
   float h0[JNV];
 #pragma unroll
   for (int j = 0; j < JNV; j++) h0[j] = lane < nv ? mrow[j] : (lane == j ? 1.f : 0.f);
+  // dof blocks the model really has (an arm-only model in the default layout: block 0 alone; the others would be identity rows)
+  const int blockmask = 1 | (nv > JB0 ? 2 : 0) | (nv > JB1 ? 4 : 0);
   if (ne == 0) {   // unconstrained: qacc = M^-1 qfrc_smooth
-    out.qacc = ldl_solve<false>(h0, smooth, lane);
+    if (m->has_damping == 1) {   // ... and the Euler step's (M + h D)^-1 qfrc_smooth out of the same elimination
+      out.qacc = ldl_block0_dual(h0, smooth, hd, lane, &out.qdamped) + ldl_solve_blocks(h0, smooth, lane, blockmask & 6);
+      out.have_qdamped = true;
+    } else out.qacc = ldl_solve_blocks(h0, smooth, lane, blockmask);
     return out;
   }
   if (ne > MAXEFC) ne = MAXEFC;
@@ -1006,8 +1024,8 @@ JDEV NewtonOut stage_newton(const JacoModelDev* m, L& s, const float (&mrow)[JNV
     // (M + h D)^-1 qfrc_smooth comes out of the same elimination (qfrc_constraint is zero on these dofs)
     afree = ldl_block0_dual(h0, smooth, hd, lane, &out.qdamped);
     out.have_qdamped = true;
-    afree += ldl_solve_blocks(h0, smooth, lane, ~rowblocks & 6);
-  } else afree = ldl_solve_blocks(h0, smooth, lane, ~rowblocks & 7);
+    afree += ldl_solve_blocks(h0, smooth, lane, ~rowblocks & 6 & blockmask);
+  } else afree = ldl_solve_blocks(h0, smooth, lane, ~rowblocks & 7 & blockmask);
   // Primal problem in terms of qfrc_smooth (same optimum as MuJoCo's (a - a_s)' M (a - a_s) form, no M^-1 needed for
   // the blocks that carry rows):  minimise 1/2 a'Ma - a'qfrc_smooth + sum_i 1/2 D_i min(0, J_i a - aref_i)^2.
   // Start: warm start on the row-carrying blocks (MuJoCo additionally compares it with the unconstrained point; with
@@ -1168,6 +1186,92 @@ JDEV NewtonOut stage_newton(const JacoModelDev* m, L& s, const float (&mrow)[JNV
   out.iters = it | (nls << 8);
 #pragma unroll
   for (int q = 0; q < NR; q++) if (valid[q]) s.e_f[lane + 64 * q] = f[q];
+  return out;
+}
+
+// Stage S of the contact-free instantiation: every row is a joint-limit row, J_r = +-e_d, at most one per dof.  The same primal Newton
+// iteration as stage_newton (same start point, tolerances, exact line search) with the row of dof k held by lane k: the Hessian is
+// M + diag(D_k [row k active]) and J^T f = +-f_k -- no matrix-core pass, no LDS traffic inside the loop, one 9 x 9 block factorisation per
+// iteration (limits only exist on hinge dofs: block 0).
+template <class L>
+JDEV NewtonOut stage_newton_limits(const JacoModelDev* m, L& s, const float (&mrow)[JNV], float smooth, float hd, int lane) {
+  NewtonOut out;
+  const int nv = m->nv, ne = wave_uniform_i(s.nefc);
+  out.qfrc_con = 0.f; out.iters = 0; out.qdamped = 0.f; out.have_qdamped = false;
+  float h0[JNV];
+#pragma unroll
+  for (int j = 0; j < JNV; j++) h0[j] = lane < nv ? mrow[j] : (lane == j ? 1.f : 0.f);
+  const int blockmask = 1 | (nv > JB0 ? 2 : 0) | (nv > JB1 ? 4 : 0);
+  if (ne == 0) {
+    if (m->has_damping == 1) {
+      out.qacc = ldl_block0_dual(h0, smooth, hd, lane, &out.qdamped) + ldl_solve_blocks(h0, smooth, lane, blockmask & 6);
+      out.have_qdamped = true;
+    } else out.qacc = ldl_solve_blocks(h0, smooth, lane, blockmask);
+    return out;
+  }
+  // my row: the limit row of dof `lane`, if there is one (rows are few: a scan)
+  float sg = 0.f, ar = 0.f, D = 0.f;
+  int myrow = -1;
+  const int kk = lane < nv ? lane : 0;
+  for (int r = 0; r < ne; r++) {
+    const float j = s.J[r * JLD + kk];
+    if (lane < JB0 && j != 0.f) { sg = j; ar = s.e_aref[r]; D = s.e_D[r]; myrow = r; }
+  }
+  const bool has = myrow >= 0;
+  const float scale = 1.f / (m->meaninertia * (float)(nv > 1 ? nv : 1)), tol = m->tolerance;
+  const bool mine = lane < JB0 && lane < nv;
+  const float afree = ldl_solve_blocks(h0, smooth, lane, 6 & blockmask);
+  float a = mine ? s.qacc_ws[lane] : afree;
+  float Ma = mat_vec(mrow, a) - smooth;
+  Ma = mine ? Ma : 0.f;
+  float x = has ? sg * a - ar : 0.f;
+  int it = 0, nls = 0;
+  for (; it < m->iterations; it++) {
+    lane = wave_opaque_i(lane);
+    const bool act = has && x < 0.f;
+    float h[JNV];
+#pragma unroll
+    for (int j = 0; j < JNV; j++) h[j] = lane < nv ? mrow[j] + ((lane == j && act) ? D : 0.f) : (lane == j ? 1.f : 0.f);
+    const float jtf = act ? sg * (-D * x) : 0.f;
+    const float grad = Ma - jtf;
+    const float gn = sqrtf(wave_sum(grad * grad));
+    if (gn * scale < tol) break;
+    float p = ldl_block<0, JB0>(h, -grad, lane);
+    p = lane < nv ? p : 0.f;
+    const float Mp = mat_vec(mrow, p);
+    float pMp, pMa;
+    wave_sum2(p * Mp, p * Ma, &pMp, &pMa);
+    const float jp = has ? sg * p : 0.f;
+    float al = 0.f, lo = 0.f, hi = 3.0e38f, d10 = 0.f, dlo = 0.f, dhi = 0.f;
+    for (int ls = 0; ls < m->ls_iterations; ls++) {   // exact line search, as in stage_newton
+      const float xa = x + al * jp;
+      const float s1 = (has && xa < 0.f) ? D * xa * jp : 0.f, s2 = (has && xa < 0.f) ? D * jp * jp : 0.f;
+      float w1, w2;
+      wave_sum2(s1, s2, &w1, &w2);
+      const float d1 = pMa + al * pMp + w1, d2 = pMp + w2;
+      if (ls == 0) d10 = fabsf(d1);
+      if (ls > 0 && fabsf(d1) <= 1e-6f * d10) break;
+      if (d1 < 0.f) { lo = al; dlo = -d1; } else { hi = al; dhi = d1; }
+      if (hi < 1.0e38f && fmaxf(dlo, dhi) * (hi - lo) * scale < 1e-3f * tol) break;
+      float nx = al - d1 / d2;
+      if (!(nx > lo && nx < hi)) nx = hi < 1.0e38f ? 0.5f * (lo + hi) : 2.f * al + 1.f;
+      if (nx == al) break;
+      al = nx;
+      nls++;
+    }
+    const float dx = al * jp, xn = x + dx;
+    const bool was = has && x < 0.f, is = has && xn < 0.f;
+    const float dc = (was && is) ? 0.5f * D * dx * (2.f * x + dx) : (is ? 0.5f * D * xn * xn : (was ? -0.5f * D * x * x : 0.f));
+    x = xn;
+    const float improvement = -(al * pMa + 0.5f * al * al * pMp + wave_sum(dc));
+    a += al * p; Ma += al * Mp;
+    if (improvement * scale < tol) { it++; break; }
+  }
+  const float f = (has && x < 0.f) ? -D * x : 0.f;
+  out.qacc = a;
+  out.qfrc_con = sg * f;
+  out.iters = it | (nls << 8);
+  if (has) s.e_f[myrow] = f;
   return out;
 }
 
@@ -1563,7 +1667,7 @@ again:
 #endif
     for (int i = lane; i < JMBLK; i += 64) s.M[i] = 0.f;
     wave_sync();
-    if (A.dbg && env == A.dbg_env && sub == nsub - 1 && lane < m->ngeom) for (int k = 0; k < 3; k++) A.dbg[JDBG_GPOS + 3 * lane + k] = s.gpos[lane][k];
+    if constexpr (C::CONTACT) if (A.dbg && env == A.dbg_env && sub == nsub - 1 && lane < m->ngeom) for (int k = 0; k < 3; k++) A.dbg[JDBG_GPOS + 3 * lane + k] = s.gpos[lane][k];
     JSTAMP(0);
     JSTAMP(1);
     const ActParams actp = act_fetch(m, lane);
@@ -1582,7 +1686,7 @@ again:
     // collision first, then the row builders: the constraint rows share LDS with the geom poses and the broadphase survivors,
     // which are dead once the contact list exists.  (Actuation touches neither: no synchronisation of its own.)
     unsigned cflags = 0;
-    if (!A.disable_contact) {
+    if (C::CONTACT && !A.disable_contact) {
       stage_collision(A, m, s, lane, cflags, pc, pl);
       wave_sync();
       JSTAMP(4);
@@ -1630,7 +1734,9 @@ again:
     float qas = 0.f;   // (qacc_smooth is no longer formed; kept in the dump layout)
     wave_sync();
     const float hdamp = (m->has_damping && lane < nv) ? m->timestep * pf.damping : 0.f;
-    NewtonOut nw = stage_newton(m, s, mrow, smooth, hdamp, lane, pc);
+    NewtonOut nw;
+    if constexpr (C::CONTACT) nw = stage_newton(m, s, mrow, smooth, hdamp, lane, pc);
+    else nw = stage_newton_limits(m, s, mrow, smooth, hdamp, lane);
     if (SideRows<JacoLDS<C>>::on) { if (wave_uniform_i(s.nside) > 0) newton_side(m, s, mrow, smooth, lane, nw); }
     JSTAMP(6);
     iters = nw.iters & 255;
@@ -1638,7 +1744,7 @@ again:
     nls_last = nls_dbg;
     if (iters >= m->iterations) flags |= JFLAG_SOLVER_MAXITER;
     wave_sync();
-    stage_touch(m, s, lane, &sens);
+    if (C::CONTACT) stage_touch(m, s, lane, &sens);
     JSTAMP(7);
     // Euler with implicit joint damping
     float total = smooth + nw.qfrc_con, qacc_e = nw.qacc;
@@ -1813,7 +1919,8 @@ again:
                             : (A.task_id == JTASK_GRASPING ? reward_picking(pe, eul, obj, touch, 0.05f) : 0.f));   // (placing, pickAndplace: 0 in the reference)
         float trow[4] = {0.f, s.task[JT_STEPS], s.task[JT_EPISODES], 0.f};
         float picked = s.task[JT_PICKED];
-        done = terminal_inspection(A.task_id, trow, s.qpos[2], pe, ld3(m->base_pos), obj, destgoal, touch, &bonus, &succ, &wb, eul, s.task + JT_REACHGOAL, &picked);
+        const float objvel = nv >= 12 ? norm(ld3(&s.qvel[9])) : 0.f;   // |get_obj_vel()| (mujoco.py:212-215): the object's linear velocity, current state
+        done = terminal_inspection(A.task_id, trow, s.qpos[2], pe, ld3(m->base_pos), obj, destgoal, touch, &bonus, &succ, &wb, eul, s.task + JT_REACHGOAL, &picked, objvel);
         // quarantine (failure row): a state that went non-finite ends the episode with no reward and stays
         // frozen until it is reset -- what MuJoCo's own bad-state check does with mj_resetData, made visible to the learner
         const bool bad = wave_ballot((flags & JFLAG_NAN) != 0u || !(rew == rew)) != 0ull;
@@ -1908,8 +2015,8 @@ again:
 #ifndef JACO_LIGHT_WAVES
 #define JACO_LIGHT_WAVES 3   // waves per SIMD the light kernel is compiled for: 13.3 KB of LDS per env allow 12 envs per CU, 168 VGPRs each
 #endif
-template <bool FULL>
-JDEV void light_grid(const JacoStepArgs& A, JacoLDS<JacoLight>& s) {
+template <bool FULL, class C = JacoLight>
+JDEV void light_grid(const JacoStepArgs& A, JacoLDS<C>& s) {
   const int lane = lane_id();
   if (env_id() >= A.nenv) return;
   const int nslots = A.nslots ? *A.nslots : A.nenv;
@@ -1922,7 +2029,7 @@ JDEV void light_grid(const JacoStepArgs& A, JacoLDS<JacoLight>& s) {
   if (!masked_out) {
     if (FULL && A.hint && (A.env_mode == 2 || A.env_mode == 3 || A.env_mode == 6) && lane == 0) st_wt_i(&A.hint[env], 0);   // a reset env starts from scratch (its forward pass may raise it again)
     const unsigned long long t_start = wave_clock();
-    left = run_env<JacoLight, 0, FULL>(A, s, env, A.nsub, lane);
+    left = run_env<C, 0, FULL>(A, s, env, A.nsub, lane);
     // (only real steps record their cost: the masked forward pass of a reset must not wipe the launch-order heuristic's input)
     if (lane == 0 && A.cost && A.env_mode <= 1) { unsigned c = (unsigned)((wave_clock() - t_start) >> 4); if (left > 0) st_wt_u(&A.cost[env], c); else A.cost[env] = c; }
     // hand-off: the env's state went to memory with write-through stores (run_env); once they are acknowledged the env
@@ -1949,6 +2056,16 @@ __global__ __launch_bounds__(64, JACO_LIGHT_WAVES) void jaco_physics_kernel_list
   __shared__ JacoLDS<JacoLight> s;
   JEMU_POISON(s);
   light_grid<true>(A, s);
+}
+#endif
+// The contact-free instantiation (modes 0 and 1): arm-only models / option disable_contact.  No collision, contact-row or touch code, LDS
+// without the geom, candidate and contact arrays; 128 registers: BASELINE config 2's 4 096 envs are resident at once (16 per CU).  Nothing
+// can overflow a capacity here (at most one limit row per joint), so the host launches no tier workers or drains next to it.
+#if JACO_TU_HAS(8)
+__global__ __launch_bounds__(64, 4) void jaco_physics_kernel_arm(JacoStepArgs A) {
+  __shared__ JacoLDS<JacoArm> s;
+  JEMU_POISON(s);
+  light_grid<false, JacoArm>(A, s);
 }
 #endif
 // One handed-over env on a bigger-tier workgroup: the big code (medium: TB = 1, heavy: TB = 2) runs while the overflow
@@ -2152,7 +2269,7 @@ __global__ __launch_bounds__(64) void jaco_physics_kernel_huge_drain(JacoStepArg
 #endif
 
 // Launchers, one per kernel, defined next to it (kernels.hip) and called by the host side (jaco_env.hip).  k: 0 step kernel, 1 full-code
-// twin (reset-time modes), 2 / 3 medium workers / drain, 4 / 5 heavy, 6 / 7 huge.
+// twin (reset-time modes), 2 / 3 medium workers / drain, 4 / 5 heavy, 6 / 7 huge, 8 contact-free step kernel.
 #ifndef JACO_EMULATED
 void jaco_launch_kernel(int k, unsigned grid, hipStream_t st, const JacoStepArgs& A);
 #define JACO_DEFINE_LAUNCHER(n, kernel) void jaco_launch_kernel_##n(unsigned grid, hipStream_t st, const JacoStepArgs& A) { hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), 0, st, A); }
@@ -2172,5 +2289,7 @@ JACO_DEFINE_LAUNCHER(5, jaco_physics_kernel_heavy_drain)
 JACO_DEFINE_LAUNCHER(6, jaco_physics_kernel_huge_workers)
 #elif defined(JACO_TU) && JACO_TU == 7
 JACO_DEFINE_LAUNCHER(7, jaco_physics_kernel_huge_drain)
+#elif defined(JACO_TU) && JACO_TU == 8
+JACO_DEFINE_LAUNCHER(8, jaco_physics_kernel_arm)
 #endif
 #endif

@@ -19,8 +19,10 @@ from .physics import BatchedMujoco, JacoError
 
 # picking / placing run end to end in the reference; the terminations of reaching / grasping / pickAndplace return 3-tuples there that
 # env_mujoco.py:125 cannot unpack (env_mujoco_util.py:504-536,585-600): built here with the missing success flag added.
-# Not built: carrying / releasing / pushing (terminate at once or need the object in hand with task-specific init poses, :181-189).
-TASK_IDS = {"picking": 0, "placing": 1, "reaching": 2, "grasping": 3, "pickAndplace": 4}
+# carrying / pushing end every episode in their first step (`return True, 0, wb`, :549-550,583-584); releasing has a real rule (:551-566) and
+# its own in-hand reset (:106-117,186-189).  Their terminations are 3-tuples in the reference as well.  'pushing' cannot even be reset
+# there (_create_init_angle has no branch for it: UnboundLocalError); here it starts from the picking pose range.
+TASK_IDS = {"picking": 0, "placing": 1, "reaching": 2, "grasping": 3, "pickAndplace": 4, "carrying": 5, "releasing": 6, "pushing": 7}
 
 
 class Box:
@@ -42,8 +44,6 @@ class JacoBatchedEnv:
     def __init__(self, num_envs=1, device=0, frame_skip=50, seed=0, **kwargs):
         self.task = kwargs.get("task", "picking")
         if self.task not in TASK_IDS:
-            # carrying and pushing end every episode in their first step (`return True, 0, wb`, env_mujoco_util.py:549-550,583-584);
-            # releasing needs its own in-hand reset (:186-189)
             raise NotImplementedError("task %r: supported tasks are %s" % (self.task, sorted(TASK_IDS)))
         # observation / marker branch: the rule-based sub-goal (env_mujoco_util.py:240-254,607-609) is what main.py:44-45,183-184,
         # 223-224 always selects (the default here); rulebased_subgoal=False puts the reaching goal into obs[17:23] (:255-270).
@@ -66,20 +66,24 @@ class JacoBatchedEnv:
         # done flag together with the FIRST observation of the new episode (and the task row, success flag included, is the new
         # episode's: read success as `reward > 100 and done`, main.py:262).  Tasks whose reset is more than draws + forward pass
         # (placing: 150-substep hold; grasping: pre-reach loops) keep the explicit reset(mask).
-        self.auto_reset = bool(kwargs.get("auto_reset", False)) and self.task in ("picking", "reaching", "pickAndplace")
+        want_auto = bool(kwargs.get("auto_reset", False))
+        self.auto_reset = want_auto and self.task in ("picking", "reaching", "pickAndplace", "pushing")
+        if want_auto and not self.auto_reset:
+            import warnings
+            warnings.warn("auto_reset is not available for task %r (its reset is more than draws + forward pass): call reset(done) after step()" % self.task)
         if self.auto_reset:
             self.sim.set_option("auto_reset", 1)
         self._subgoal = None
         # ---- RL setup (env_mujoco.py:15-93)
         self.current_steps = 0
         self.max_steps = 2500
-        self.task_max_steps = 700 if self.task in ("picking", "placing") else (500 if self.task in ("reaching", "grasping") else 1200)   # env_mujoco.py:18-23
+        self.task_max_steps = 700 if self.task in ("picking", "placing") else (1200 if self.task == "pickAndplace" else 500)   # env_mujoco.py:18-23
         self.skip_frames = int(frame_skip)
         obs_max = np.hstack([[3], [1] * 25]).astype(np.float32)
         self.observation_space = Box(-obs_max, obs_max, dtype=np.float32)
         self.state_shape = self.observation_space.shape[0]
         self.pose_action_space_max = 1
-        nact = 6 if self.task == "reaching" else 7
+        nact = 6 if self.task in ("reaching", "pushing") else 7   # env_mujoco.py:79-89
         self.act_max = np.ones(nact)
         self.act_min = -np.ones(nact)
         self.action_space = Box(self.act_min, self.act_max, dtype=np.float32)

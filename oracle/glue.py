@@ -149,15 +149,26 @@ def sample_reach_goal(u01, base_pos):
     return np.hstack([pos, np.array([alpha, beta, gamma], dtype=np.float16)])
 
 
-def terminal(task, q2, ee_pos, obj_pos, dest_goal, touch, num_episodes, base_pos, ee_quat=None, reach_goal=None, picked=None):
+def terminal(task, q2, ee_pos, obj_pos, dest_goal, touch, num_episodes, base_pos, ee_quat=None, reach_goal=None, picked=None, obj_vel=None):
     """_get_terminal_inspection (env_mujoco_util.py:492-600) for picking / placing (4-tuples in the reference) and reaching / grasping /
-    pickAndplace (3-tuples there, which env_mujoco.py:125 cannot unpack: the success flag is the fix).
+    pickAndplace / carrying / releasing / pushing (3-tuples there, which env_mujoco.py:125 cannot unpack: the success flag is the fix).
     `num_episodes` is the counter value *before* the call (the function increments it first).  pickAndplace carries the `picked`
     flag (self.picked): pass a one-element list, updated in place."""
     n = num_episodes + 1
     wb = np.linalg.norm(np.asarray(ee_pos) - base_pos)
     if np.pi - 0.1 < q2 < np.pi + 0.1:
         return True, -1.0, wb, 0
+    if task in ("carrying", "pushing"):   # :549-550, 583-584: `return True, 0, wb` (3-tuples: success flag 0 added)
+        return True, 0.0, wb, 0
+    if task == "releasing":   # :551-566 (3-tuple in the reference); obj_vel = get_obj_vel() = qvel[9:12] (mujoco.py:212-215)
+        dd = np.linalg.norm(np.asarray(dest_goal)[:2] - np.asarray(obj_pos)[:2])
+        if obj_pos[2] < 0.1:
+            return True, -20.0, wb, 0
+        if dd < 0.04 and touch == 0 and obj_pos[2] < 0.35 and np.linalg.norm(obj_vel) < 0.01:
+            return True, 200 - n * 0.1, wb, 1
+        if dd > 0.04 and touch == 0 and obj_pos[2] < 0.20:
+            return True, -20.0, wb, 0
+        return False, 0.0, wb, 0
     if task == "grasping":   # :521-536
         if np.linalg.norm(np.asarray(ee_pos) - np.asarray(obj_pos)) > 0.2:
             return True, -20.0, wb, 0

@@ -25,8 +25,8 @@ static int g_use_hints = 0;
 static int g_obs_mode = 0;
 extern "C" void emu_set_obs_mode(int v) { g_obs_mode = v; }
 extern "C" void emu_set_hints(int on) { g_use_hints = on; }
-long emu_counter[4] = {0, 0, 0, 0};
-extern "C" long emu_get_counter(int i, int reset) { long v = emu_counter[i & 3]; if (reset) emu_counter[i & 3] = 0; return v; }
+long emu_counter[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+extern "C" long emu_get_counter(int i, int reset) { long v = emu_counter[i & 7]; if (reset) emu_counter[i & 7] = 0; return v; }
 static int g_no_pairlist = 0;
 extern "C" void emu_set_pair_list(int on) { g_no_pairlist = !on; }   // 0: every pair tested in every substep (option "pair_list" = 0 of the library)
 static int g_handdown = 0, g_handed_down = 0;
@@ -45,6 +45,13 @@ static int emu_launch(JacoStepArgs A, int* heavy_envs) {
   A.hint = g_use_hints ? g_hint.data() : nullptr; A.hint_mode = g_use_hints;
   emu_grid = A.nenv;
   // (as jaco_env.hip: the step kernel proper serves modes 0 / 1, every other mode the full-code twin)
+  // ... and contact-free steps (disable_contact, models without a collidable pair) the lean kernel, alone
+  if ((A.disable_contact || A.model->npair == 0) && A.env_mode <= 1) {
+    A.disable_contact = 1; A.hint = nullptr;
+    for (int e = 0; e < A.nenv; e++) emu_run_wave(e, [&]() { jaco_physics_kernel_arm(A); });
+    if (heavy_envs) *heavy_envs = 0;
+    return 0;
+  }
   for (int e = 0; e < A.nenv; e++) emu_run_wave(e, [&]() { if (A.env_mode >= 2) jaco_physics_kernel_listed(A); else jaco_physics_kernel(A); });
   emu_grid = 1;
   // (the resident workers of the GPU build leave as soon as the light grid is done: here that is always the case, so the
@@ -88,7 +95,7 @@ extern "C" int emu_env_call(const void* blob, long blob_size, int nenv, int mode
   A.model = &g_model; A.hull = g_hull.data(); A.qpos = qpos; A.qvel = qvel; A.qacc_ws = qacc_ws; A.ctrl = qvel; A.sensordata = sensordata;
   A.flags = flags; A.stats = stats; A.nenv = nenv; A.nsub = mode == 2 ? 1 : frame_skip; A.env_mode = mode; A.task_id = task_id; A.nact = nact;
   A.seed = seed; A.task = task; A.cache = cache; A.action = action; A.noise = noise; A.obs = obs; A.reward = reward; A.done = done; A.marker = marker; A.dbg_env = -1;
-  A.auto_reset = g_auto_reset && mode == 1 && (task_id == 0 || task_id == 2 || task_id == 4); A.qpos0 = g_qpos0.empty() ? nullptr : g_qpos0.data();
+  A.auto_reset = g_auto_reset && mode == 1 && (task_id == 0 || task_id == 2 || task_id == 4 || task_id == 7); A.qpos0 = g_qpos0.empty() ? nullptr : g_qpos0.data();
   return emu_launch(A, heavy_envs);
 }
 // rest pose of the two task-layer markers (what jaco_reset_state writes): 24 floats

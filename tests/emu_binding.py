@@ -87,7 +87,7 @@ class EmuJacoEnv(EmuEnv):
         fp = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_float)) if a is not None else None
         hv = ctypes.c_int(0)
         self.L.emu_set_obs_mode(int(getattr(self, "obs_mode", 0)))
-        rc = self.L.emu_env_call(self.blob, len(self.blob), self.nenv, mode, self.frame_skip, self.task_id, 6 if self.task_id == 2 else 7, self.seed,
+        rc = self.L.emu_env_call(self.blob, len(self.blob), self.nenv, mode, self.frame_skip, self.task_id, 6 if self.task_id in (2, 7) else 7, self.seed,
                                  fp(self.qpos), fp(self.qvel), fp(self.qacc_ws), fp(self.sensordata),
                                  self.flags.ctypes.data_as(ctypes.POINTER(ctypes.c_uint)), self.stats.ctypes.data_as(ctypes.POINTER(ctypes.c_int)),
                                  fp(self.task), fp(self.cache), fp(action), fp(noise), fp(self.obs), fp(self.reward),
@@ -133,6 +133,6 @@ class EmuJacoEnv(EmuEnv):
         return self.obs.copy()
 
     def env_step(self, action, noise=None):
-        a = np.ascontiguousarray(np.broadcast_to(np.asarray(action, np.float32), (self.nenv, 6 if self.task_id == 2 else 7)))
+        a = np.ascontiguousarray(np.broadcast_to(np.asarray(action, np.float32), (self.nenv, 6 if self.task_id in (2, 7) else 7)))
         self._call(1, a, None if noise is None else np.ascontiguousarray(noise, np.float32))
         return self.obs.copy(), self.reward.copy(), self.done.copy()

@@ -81,7 +81,7 @@ class OracleEnv:
             glue.reward_reaching(pe, qe, self.reach_goal, self.base) if self.task == "reaching" else (
                 glue.reward_grasping(pe, qe, obj, touch) if self.task == "grasping" else 0.0))
         done, bonus, wb, succ = glue.env_terminal(self.task, self.steps, o.get("qpos")[2], pe, obj, self.dest_goal, touch, self.episodes, self.base,
-                                                  ee_quat=qe, reach_goal=self.reach_goal, picked=self.picked)
+                                                  ee_quat=qe, reach_goal=self.reach_goal, picked=self.picked, obj_vel=o.get("qvel")[9:12])
         self.steps += 1
         if self.steps < (700 if self.task in ("picking", "placing") else (1200 if self.task == "pickAndplace" else 500)):
             self.episodes += 1

@@ -473,3 +473,50 @@ def test_pair_list_does_not_change_results(names, model_arrays):
     full, listed, entries = passes[1]
     assert passes[0][1] == 0 and listed > 2 * full > 0, passes   # the list really carried most substeps, and was rebuilt inside the steps
     print("pair list: %d all-pairs passes, %d list passes (%.0f entries each) over %d env substeps" % (full, listed, entries / listed, nenv * fs * 3))
+
+
+# ---------------------------------------------------------------- tasks releasing / carrying / pushing (round 4)
+def test_kernel_terminal_releasing_carrying_pushing_against_the_references_own_outputs(model_arrays):
+    """The in-kernel termination rules of tasks releasing / carrying / pushing (csrc/env_logic.h) through the terminal_inspection entry
+    (mode 5) against tests/golden/glue_vectors_releasing.npz = outputs of the reference's own _get_terminal_inspection
+    (env_mujoco_util.py:549-566,583-584): done flag exact, bonus to fp32 rounding; releasing reads the object's velocity (qvel[9:12])."""
+    import os
+    GR = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "glue_vectors_releasing.npz"))
+    n = len(GR["r_q2"])
+    for task_id, key in ((6, "r_term_rel"), (5, "r_term_carry"), (7, "r_term_push")):
+        e = EmuJacoEnv(task_id=task_id, frame_skip=1)
+        nsucc = 0
+        for k in range(0, n, 1 if task_id == 6 else 4):
+            _inject_scene(e, model_arrays, GR["r_ee"][k], GR["r_eeq"][k], GR["r_obj"][k], GR["r_q2"][k], int(GR["r_touch"][k]))
+            e.qvel[0, 9:12] = GR["r_objvel"][k]
+            e.task[0] = 0; e.task[0, 0] = 0.6; e.task[0, 16] = 0.6
+            e.task[0, 2] = GR["r_nsteps"][k]; e.task[0, 7:10] = GR["r_dest_goal"][k]
+            e._call(5)
+            rd, rb, rwb, _ = GR[key][k]
+            assert bool(e.done[0]) == bool(rd), (task_id, k)
+            assert abs(e.reward[0] - rb) < 2e-4 and abs(e.task[0, 30] - rwb) < 1e-5, (task_id, k, e.reward[0], rb)
+            assert e.task[0, 29] == float(bool(rd) and rb > 100)
+            nsucc += int(e.task[0, 29])
+        assert (nsucc > 3) == (task_id == 6)
+
+
+def test_reset_draws_of_releasing_and_carrying_stay_in_the_references_ranges(model_arrays):
+    """reset_draws (csrc/env_logic.h) for tasks carrying / releasing against the min / max of 4 096 draws of the reference's own
+    _create_init_angle (env_mujoco_util.py:181-189): inside the range, and covering most of it; releasing starts with the fingers at 0.6."""
+    import os
+    GR = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "glue_vectors_releasing.npz"))
+    for task_id, name, nang in ((5, "carrying", 6), (6, "releasing", 9)):
+        e = EmuJacoEnv(task_id=task_id, nenv=256, seed=11)
+        for env in range(256):
+            e.reset_env(env)
+        lo, hi = GR["init_%s_min" % name], GR["init_%s_max" % name]
+        q = e.qpos[:, :nang].astype(np.float64)
+        span = hi - lo
+        tol = 2e-3 * span + 1e-6   # (the recorded extremes of 4 096 draws sit a few 1e-4 of the span inside the true bounds)
+        assert np.all(q >= lo - tol) and np.all(q <= hi + tol), (name, q.min(0), lo, q.max(0), hi)
+        wide = span > 1e-9
+        assert np.all((q.max(0) - q.min(0))[wide] > 0.8 * span[wide])
+        if task_id == 6:
+            assert np.all(e.qpos[:, 6:9] == np.float32(0.6))
+        else:
+            assert np.all(e.qpos[:, 6:9] == np.float32(model_arrays["qpos0"][6:9]))   # fingers stay at the joint reference (mujoco.py:342-343)

@@ -153,3 +153,33 @@ def test_grasping_prereach_quantities_match_reference(GG):
     assert glue.env_terminal("grasping", 499, 1.3, np.ones(3), np.ones(3), np.ones(3), 0, 0, np.zeros(3)) == (True, -10.0, 0.0, 0)
     assert glue.env_terminal("pickAndplace", 1198, 1.3, np.ones(3), np.ones(3), np.ones(3), 0, 0, np.zeros(3), picked=[False])[1] != -10.0
     assert glue.env_terminal("pickAndplace", 1199, 1.3, np.ones(3), np.ones(3), np.ones(3), 0, 0, np.zeros(3), picked=[False]) == (True, -10.0, 0.0, 0)
+
+
+# ---------------------------------------------------------------- releasing / carrying / pushing branches (round 4)
+@pytest.fixture(scope="module")
+def GR():
+    return np.load(os.path.join(ROOT, "tests", "golden", "glue_vectors_releasing.npz"))
+
+
+def test_releasing_carrying_pushing_terminal_match_reference(GR):
+    """glue.terminal against the reference's own _get_terminal_inspection (env_mujoco_util.py:549-566,583-584): done flag and bonus
+    exact; the success flag is the value the reference's 3-tuples lack (a 4-tuple only comes back from the singular-pose exit)."""
+    base = np.array([0.0, 0.0, 0.157])
+    seen = set()
+    for k in range(len(GR["r_q2"])):
+        args = (GR["r_q2"][k], GR["r_ee"][k], GR["r_obj"][k], GR["r_dest_goal"][k], int(GR["r_touch"][k]), int(GR["r_nsteps"][k]), base)
+        for task, key in (("releasing", "r_term_rel"), ("carrying", "r_term_carry"), ("pushing", "r_term_push")):
+            d, b, wb, succ = glue.terminal(task, *args, obj_vel=GR["r_objvel"][k])
+            rd, rb, rwb, rlen = GR[key][k]
+            assert bool(rd) == d and abs(rb - b) < 1e-12 and abs(rwb - wb) < 1e-12, (task, k)
+            assert succ == int(d and b > 100)
+            assert rlen == (4 if rb == -1.0 else 3)
+            if task == "releasing":
+                seen.add(round(float(b) if b < 100 else 200.0))
+            else:
+                assert d and b in (0.0, -1.0)                                   # every episode ends in its first step
+        assert list(GR["r_reward"][k]) == [0.0, 0.0, 0.0]                       # _get_reward: 0 for all three (:432-439)
+    assert seen == {-20, -1, 0, 200}
+    assert list(GR["act_width"]) == [7, 7, 6] and list(GR["task_max_steps"]) == [500, 500, 500]
+    assert glue.env_terminal("releasing", 499, 1.3, np.ones(3), np.ones(3), np.ones(3), 0, 0, np.zeros(3), obj_vel=np.zeros(3)) == (True, -10.0, 0.0, 0)
+    assert GR["init_pushing_raises"][0] == 1                                    # the reference cannot reset task 'pushing' (documented in env.py)

@@ -301,7 +301,8 @@ def test_execution_options():
     for other in ((0, 1), (1, 1)):
         dq = (outs[(2, 1)][0] - outs[other][0]).abs().max(1).values
         print("hints 2 vs %d: qpos difference after 2 env steps: median %.2e, p99 %.2e, max %.2e" % (other[0], dq.median().item(), dq.quantile(0.99).item(), dq.max().item()))
-        assert dq.median().item() < 1e-5 and (dq < 1e-3).float().mean().item() > 0.97
+        # every env bounded (MAX over 8 192 envs; bound = 3x the largest difference measured on MI355X: 2.0e-4, hints 2 vs 1, round 3)
+        assert dq.median().item() < 1e-6 and dq.quantile(0.99).item() < 5e-6 and dq.max().item() < 6e-4
 
 
 def test_vec_env_adapter_autoreset():
@@ -662,3 +663,130 @@ def test_auto_reset_equals_step_plus_masked_reset_8192_envs():
         for k in range(5):
             assert torch.equal(x[k], y[k]), (s, k, (x[k].float() - y[k].float()).abs().max())
     assert ndone >= B // 2 and ((outs[0][1] & 15) == 0).all()
+
+
+def test_releasing_carrying_pushing_through_the_c_abi(model_arrays, names):
+    """Tasks releasing / carrying / pushing (round 4) end to end through the C ABI.
+    releasing (env_mujoco_util.py:106-117,186-189,551-566): (A) jaco_reset leaves the arm in the releasing pose range with the object
+    pinned in the hand and the fingers closed onto it; (B) the 150-substep hold from a given pre-hold state (fingers at 0.6) and the env
+    steps that follow (gripper opening) agree with the fp64 oracle env in state, observation, reward + bonus and done flag.
+    carrying (:106-117,123-170,549-550): reset = hold + pre-reach loops, every episode ends in its first step with bonus 0.
+    pushing (:583-584; 6-wide action, env_mujoco.py:79-82): ends in its first step; with auto_reset the observation is the new episode's."""
+    from mujoco_jaco_amd.env import JacoBatchedEnv
+    from oracle_env import OracleEnv
+    B = 4
+    env = JacoBatchedEnv(num_envs=B, task="releasing", seed=9)
+    assert env.action_space.shape == (7,) and env.task_max_steps == 500
+    nz = np.full((B, 12), 0.5, np.float32)
+    env.set_noise(torch.tensor(nz))
+    obs = env.reset().cpu().numpy()
+    q, v, _ = env.sim.get_state()
+    q = q.cpu().numpy()
+    assert np.isfinite(obs).all() and not (env.sim.flags().cpu().numpy() & (1 | 2 | 4 | 8)).any()
+    assert ((q[:, 0] > 1.7) & (q[:, 0] < 2.2) & (q[:, 1] > 3.1) & (q[:, 1] < 3.8)).all()        # (:186-187; the hold barely moves the arm)
+    assert (q[:, 6:9] > 0.55).all() and (q[:, 6:9] < 1.0).all()                               # fingers started at 0.6 and rest on the object
+    # (B) hold + steps from an injected pre-hold state
+    q0 = np.tile(model_arrays["qpos0"], (B, 1)); q0[:, :6] = q[:, :6]; q0[:, 6:9] = 0.6; q0[:, 16:18] = q[:, 16:18]
+    q0 = q0.astype(np.float32).astype(np.float64)
+    dev = env.device
+    env.sim.set_state(torch.tensor(q0, dtype=torch.float32, device=dev), torch.zeros(B, 21, device=dev), torch.zeros(B, 21, device=dev))
+    t = env.task_state(); t[:, 1] = 0; t[:, 2] = 0; t[:, 3] = 0; env.set_task_state(t)
+    env._placing_hold()
+    env.make_observation()
+    q1 = env.sim.get_state()[0].cpu().numpy()
+    t = env.task_state().cpu().numpy()
+    oes = []
+    for k in range(B):
+        oe = OracleEnv(names, task="releasing")
+        oe.set_state(q0[k])
+        oe.dest_goal = t[k, 7:10].astype(np.float64); oe.obj_goal = t[k, 4:7].astype(np.float64)
+        oe.placing_hold(150)
+        oq = oe.o.get("qpos")
+        assert np.abs(q1[k, :9] - oq[:9]).max() < 2.5e-6 and np.abs(q1[k, 9:12] - oq[9:12]).max() < 2.5e-7, (k, np.abs(q1[k, :9] - oq[:9]).max())
+        oes.append(oe)
+    rng = np.random.default_rng(3)
+    oerr, rerr = [], []
+    for s in range(3):
+        a = rng.uniform(-1, 1, (B, 7)).astype(np.float32); a[:, 6] = 1.0     # open the gripper: the object is let go
+        nz = rng.uniform(size=(B, 12)).astype(np.float32)
+        env.set_noise(torch.tensor(nz))
+        o, r, d, _ = env.step(torch.tensor(a))
+        o, r, d = o.cpu().numpy(), r.cpu().numpy(), d.cpu().numpy()
+        for k in range(B):
+            if oes[k] is None:
+                continue
+            oo, orew, odone, _ = oes[k].step(a[k].astype(np.float64), nz[k].astype(np.float64))
+            assert bool(d[k]) == odone and o[k, 0] == oo[0], (s, k)
+            oerr.append(np.abs(o[k] - oo).max()); rerr.append(abs(r[k] - orew))
+            if odone:
+                oes[k] = None
+    print("releasing: obs err max %.2e, reward err max %.2e over %d env steps" % (max(oerr), max(rerr), len(oerr)))
+    assert max(oerr) < 2e-4 and max(rerr) < 1e-4
+    env.close()
+    # carrying
+    env = JacoBatchedEnv(num_envs=B, task="carrying", seed=4)
+    obs = env.reset().cpu().numpy()
+    assert np.isfinite(obs).all() and env.action_space.shape == (7,)
+    o, r, d, _ = env.step(torch.zeros(B, 7))
+    assert d.all() and ((r == 0) | (r == -1)).all() and not env.successes().any()
+    obs2 = env.reset(d)
+    assert torch.isfinite(obs2).all() and (env.task_state()[:, 3] == 0).all()
+    env.close()
+    # pushing, reset inside jaco_step
+    env = JacoBatchedEnv(num_envs=B, task="pushing", seed=4, auto_reset=True)
+    assert env.action_space.shape == (6,) and env.auto_reset
+    first = env.reset().clone()
+    o, r, d, _ = env.step(torch.zeros(B, 6))
+    assert d.all() and ((r == 0) | (r == -1)).all()
+    assert torch.isfinite(o).all() and not torch.equal(o, first) and (env.task_state()[:, 1] == 0).all()   # a new episode's first observation
+    env.close()
+
+
+def test_small_action_regime_flag_census_and_parity_of_unflagged_envs(tmp_path):
+    """Action scale 0.1: the EE's axis sticks lie on the "hand" marker's sticks, most envs run in the medium / heavy / huge tiers, and the
+    last tier (512 rows / 128 contacts) has nobody to hand an overflow to -- contacts / rows beyond it are dropped and FLAGGED
+    (physics_kernel.h, TIER == 3).  (A) census: 16 384 envs x 60 steps, finished envs reset inside jaco_step, error flags counted and
+    cleared after every step: the flagged share of env steps must stay below 1e-5 (measured on MI355X: see the printed line).
+    (B) parity of what is not flagged: 96 envs x 6 steps against the fp64 oracle env on the same actions / noise; every env without an
+    error flag is compared (MAX over them), done flags exact."""
+    import os, subprocess, sys
+    from mujoco_jaco_amd.env import JacoBatchedEnv
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import env_drift
+    # (B) first: its oracle pool forks in a fresh process
+    B, nstep, scale = 96, 6, 0.1
+    ref_path, gpu_path = str(tmp_path / "ref.npz"), str(tmp_path / "gpu.npz")
+    subprocess.run([sys.executable, os.path.join(root, "tools", "env_drift.py"), "oracle", ref_path, str(B), str(nstep), str(scale)], check=True, timeout=900)
+    env_drift.gpu_leg(gpu_path, B, nstep, scale=scale)
+    g, r = dict(np.load(gpu_path)), dict(np.load(ref_path))
+    ok = (g["flags"] & 31) == 0
+    bigger = int(((g["flags"] & 32) != 0).sum())
+    assert ok.sum() >= B - 1 and bigger > B // 4, (int(ok.sum()), bigger)       # the bigger tiers really carried the regime
+    assert np.array_equal(g["done"].astype(bool)[:, ok], r["done"].astype(bool)[:, ok])
+    live = (~np.cumsum(r["done"].astype(bool), 0).astype(bool) | r["done"].astype(bool)) & ok[None, :]
+    eq = np.abs(g["qpos"].astype(np.float64) - r["qpos"]).max(2)
+    eo = np.abs(g["obs"].astype(np.float64) - r["obs"]).max(2)
+    print("scale 0.1, %d unflagged envs x %d steps (%d of them stepped by a bigger tier): qpos err median %.2e p99 %.2e max %.2e | obs err max %.2e" % (
+        int(ok.sum()), nstep, bigger, np.median(eq[live]), np.percentile(eq[live], 99), eq[live].max(), eo[live].max()))
+    # bounds = 3x measured on MI355X (qpos median 4.3e-7, p99 1.95e-4, max 8.6e-4; obs max 2.9e-4): the stick-on-stick contacts of this regime
+    # amplify rounding differences faster than the headline regime's (there: max 5.9e-5 after 10 steps)
+    assert np.median(eq[live]) <= 1.3e-6 and np.percentile(eq[live], 99) <= 6e-4 and eq[live].max() <= 2.6e-3 and eo[live].max() <= 9e-4
+    # (A)
+    B, nstep = 16384, 60
+    env = JacoBatchedEnv(num_envs=B, task="picking", seed=21, auto_reset=True)
+    env.reset()
+    gen = torch.Generator(device=env.device); gen.manual_seed(4)
+    nfl = torch.zeros((), dtype=torch.int64, device=env.device)
+    kinds = torch.zeros(5, dtype=torch.int64, device=env.device)
+    for s in range(nstep):
+        env.step((torch.rand(B, 7, device=env.device, generator=gen) * 2 - 1) * 0.1)
+        f = env.sim.flags()
+        nfl += ((f & 31) != 0).sum()
+        kinds += torch.stack([((f & (1 << b)) != 0).sum() for b in range(5)])
+        env.sim.clear_flags()
+    share = float(nfl.item()) / (B * nstep)
+    print("scale 0.1 census: %d of %d env steps flagged (share %.2e); contacts / rows / candidates dropped, non-finite, solver cap: %s" % (
+        int(nfl.item()), B * nstep, share, kinds.tolist()))
+    assert share <= 1e-5 and int(kinds[3]) == 0
+    env.close()

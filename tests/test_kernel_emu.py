@@ -178,3 +178,22 @@ def test_jaco2_torque_model_on_the_d12_build_matches_oracle():
         assert np.abs(e.qpos[0] - o.get("qpos")).max() < 2e-6 and np.abs(e.qvel[0] - o.get("qvel")).max() < 2e-4, k
     assert rows >= 1                                                # the scenario really exercised limit rows
     assert np.abs(o.get("qfrc_passive")[6:]).max() > 0.005           # ... and the springs / dampers are at work at the end
+
+
+def test_contact_free_kernel_with_joint_limit_rows():
+    """The contact-free instantiation's Newton solve (stage_newton_limits: every row a joint-limit row held by its dof's lane) against
+    the oracle: arm-only model driven into the limits of joints 1 and 2 (range [0.87, 5.41] / [0.33, 5.95]) and of the finger joints
+    (servo command beyond their range), single steps re-synchronised with the oracle, row counts equal."""
+    o = Oracle("jaco2_reaching_torque"); o.option("disable_contact", 1)
+    e = EmuEnv("jaco2_reaching_torque")
+    q = e.M["qpos0"].copy(); q[:6] = [1.5, 0.88, 5.94, 2.0, 2.0, 1.5]; q[6:9] = [1.5, 0.01, 0.7]
+    v = np.zeros(9); v[1] = -3.0; v[2] = 2.5; v[6] = 4.0; v[7] = -5.0
+    o.set("qpos", q); o.set("qvel", v)
+    ctrl = np.array([5.0, -30.0, 30.0, 3.0, -2.0, 1.0, 1.6, -0.2, 0.7])
+    rows, worst_q, worst_v = 0, 0.0, 0.0
+    for i in range(40):
+        eq, ev = _sync_step(o, e, ctrl, disable_contact=True)
+        assert e.stats[0, 1] == o.nefc and e.stats[0, 0] == 0, (i, e.stats[0], o.nefc)
+        rows = max(rows, o.nefc); worst_q = max(worst_q, eq); worst_v = max(worst_v, ev)
+    assert rows >= 3 and e.flags[0] == 0
+    assert worst_q < 1e-6 and worst_v < 2e-3, (worst_q, worst_v)

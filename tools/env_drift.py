@@ -24,21 +24,21 @@ MODEL = "jaco2_curtain_torque"
 MARKS = (2, 6, 20)   # env steps = 100 / 300 / 1 000 substeps at frame_skip 50
 
 
-def inputs(B, nstep, seed=71):
+def inputs(B, nstep, seed=71, scale=1.0):
     from mujoco_jaco_amd import workload
     from mujoco_jaco_amd.modelc import blob
     M = blob.load(os.path.join(ROOT, "mujoco_jaco_amd", "assets", MODEL + ".jacomdl"))
     q0 = workload.reset_states(M["qpos0"], B, seed=seed, f32_draws=True)
     rng = np.random.default_rng(seed + 1)
-    act = rng.uniform(-1, 1, (nstep, B, 7)).astype(np.float32)
+    act = (rng.uniform(-1, 1, (nstep, B, 7)) * scale).astype(np.float32)
     noise = rng.uniform(size=(nstep + 1, B, 12)).astype(np.float32)
     return q0, act, noise
 
 
-def gpu_leg(out_path, B, nstep, compensated=1, task="picking"):
+def gpu_leg(out_path, B, nstep, compensated=1, task="picking", scale=1.0):
     import torch
     from mujoco_jaco_amd.env import JacoBatchedEnv
-    q0, act, noise = inputs(B, nstep)
+    q0, act, noise = inputs(B, nstep, scale=scale)
     env = JacoBatchedEnv(num_envs=B, task=task)
     env.sim.set_option("compensated", compensated)
     dev = env.device
@@ -80,16 +80,16 @@ def _oracle_one(k):
     return np.array(qs), np.array(obs_all), np.array(dones), np.array(rews)
 
 
-def oracle_leg(B, nstep, nproc=None):
+def oracle_leg(B, nstep, nproc=None, scale=1.0):
     """(before anything in this process has touched the GPU: the pool forks)"""
     import multiprocessing as mp
-    q0, act, noise = inputs(B, nstep)
+    q0, act, noise = inputs(B, nstep, scale=scale)
     names = {}
     for line in open(os.path.join(ROOT, "mujoco_jaco_amd", "assets", MODEL + ".names.txt")):
         k, v = line.strip().split(": ", 1)
         names[k] = v.split()
     _W.update(q0=q0, act=act, noise=noise, names=names, nstep=nstep)
-    nproc = nproc or min(B, os.cpu_count() or 1)
+    nproc = nproc or int(os.environ.get("JACO_DRIFT_NPROC", "0")) or min(B, os.cpu_count() or 1)
     os.environ.setdefault("OMP_NUM_THREADS", "1")
     with mp.get_context("fork").Pool(nproc) as pool:
         res = pool.map(_oracle_one, range(B), chunksize=max(1, B // (4 * nproc)))
@@ -116,10 +116,10 @@ if __name__ == "__main__":
     import json
     import subprocess
     if len(sys.argv) > 1 and sys.argv[1] == "gpu":
-        gpu_leg(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]) if len(sys.argv) > 5 else 1)
+        gpu_leg(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]) if len(sys.argv) > 5 else 1, scale=float(sys.argv[6]) if len(sys.argv) > 6 else 1.0)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "oracle":   # the oracle leg alone -> .npz (a fresh process: its pool forks before any GPU use)
-        np.savez(sys.argv[2], **oracle_leg(int(sys.argv[3]), int(sys.argv[4])))
+        np.savez(sys.argv[2], **oracle_leg(int(sys.argv[3]), int(sys.argv[4]), scale=float(sys.argv[5]) if len(sys.argv) > 5 else 1.0))
         sys.exit(0)
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     nstep = int(sys.argv[2]) if len(sys.argv) > 2 else 20

@@ -38,6 +38,17 @@ if envlevel:
     env._chk(env.L.jaco_stage_profile(env.h, prof.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), 1))
     env.clear_flags()
     t = time.time(); genv.step(acts[presteps % 4]); torch.cuda.synchronize(); dt = time.time() - t
+elif "--arm" in sys.argv:   # BASELINE config 2: arm-only model, contacts off (the contact-free kernel), fresh random torques per launch
+    env = BatchedMujoco(B, robot_file="jaco2_reaching_torque")
+    env.set_option("disable_contact", 1)
+    Ma = blob.load(os.path.join(ROOT, "mujoco_jaco_amd", "assets", "jaco2_reaching_torque.jacomdl"))
+    q = torch.tensor(workload.reset_states(Ma["qpos0"], B), dtype=torch.float32, device=env.device)
+    env.set_state(q, None, None)
+    cs = [torch.tensor(workload.random_ctrl(B, seed=k, scale=0.2)[:, :env.nu].copy(), dtype=torch.float32, device=env.device) for k in range(8)]
+    for k in range(6): env.send_forces(cs[k], nsub=nsub)
+    torch.cuda.synchronize()
+    env._chk(env.L.jaco_stage_profile(env.h, prof.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), 1))
+    t = time.time(); env.send_forces(cs[6], nsub=nsub); torch.cuda.synchronize(); dt = time.time() - t
 else:
     env = BatchedMujoco(B)
     q = torch.tensor(workload.reset_states(M["qpos0"], B), dtype=torch.float32, device=env.device)

@@ -1,0 +1,44 @@
+"""CPU diagnostic: how many support queries the oracle's MPR spends per call under the reference's shipped picking policy
+(the regime in which the hull narrowphase dominates the substep), split into penetrating / non-penetrating calls.
+Single process (the oracle's counters are plain statics).   python tools/mpr_query_stats.py [episodes] [max_steps]"""
+import ctypes, os, sys
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+from mujoco_jaco_amd import workload
+from mujoco_jaco_amd.modelc import blob
+from mujoco_jaco_amd.policy import HPCPolicy
+from oracle_env import OracleEnv
+import oracle_binding
+
+neps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+maxsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+M = blob.load(os.path.join(ROOT, "mujoco_jaco_amd", "assets", "jaco2_curtain_torque.jacomdl"))
+names = {}
+for line in open(os.path.join(ROOT, "mujoco_jaco_amd", "assets", "jaco2_curtain_torque.names.txt")):
+    k, v = line.strip().split(": ", 1); names[k] = v.split()
+pol = HPCPolicy.load(os.path.join(ROOT, "tests", "golden", "policy_picking.npz"), device=torch.device("cpu"))
+L = oracle_binding.Oracle().L if hasattr(oracle_binding.Oracle(), "L") else None
+lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "libjaco_oracle.so"))
+lib.orc_debug_counter.restype = ctypes.c_long; lib.orc_debug_counter.argtypes = [ctypes.c_int, ctypes.c_int]
+rng = np.random.default_rng(0)
+q0 = workload.reset_states(M["qpos0"], neps, seed=5, f32_draws=True)
+tot = np.zeros(4)
+for ep in range(neps):
+    oe = OracleEnv(names)
+    oe.obj_goal = q0[ep, 9:12].copy(); oe.dest_goal = np.array([q0[ep, 16], q0[ep, 17], 0.3468])
+    oe.set_state(q0[ep])
+    obs = oe.observe(rng.uniform(size=6))[0]
+    for i in range(4): lib.orc_debug_counter(i, 1)
+    for s in range(maxsteps):
+        a, _ = pol.predict(torch.tensor(obs[None], dtype=torch.float32))
+        obs, r, d, succ = oe.step(a[0].numpy().astype(np.float64), rng.uniform(size=12))
+        if d:
+            break
+    c = np.array([lib.orc_debug_counter(i, 1) for i in range(4)], float)
+    tot += c
+    print("episode %d: %d steps, done %s succ %s | MPR calls %d (%.2f per substep), hits %d, queries per hit %.1f, per miss %.1f" % (
+        ep, s + 1, d, succ, c[0], c[0] / ((s + 1) * 50), c[1], c[2] / max(c[1], 1), c[3] / max(c[0] - c[1], 1)), flush=True)
+print("total: calls %d, hit share %.2f, queries per hit %.2f, per miss %.2f, share of all queries spent in hits %.2f" % (
+    tot[0], tot[1] / tot[0], tot[2] / max(tot[1], 1), tot[3] / max(tot[0] - tot[1], 1), tot[2] / (tot[2] + tot[3])))
