@@ -402,6 +402,8 @@ def main():
         scale = [float(args.action_scale)]
         nact = genv.action_space.shape[0]
 
+        abuf = torch.empty(B, nact, device=dev)
+        done_each = torch.zeros(B, dtype=torch.int32, device=dev)
         pol, cur_obs = None, [None]
         if args.policy:
             from mujoco_jaco_amd.policy import HPCPolicy
@@ -413,9 +415,9 @@ def main():
             if pol is not None:
                 a, _ = pol.predict(cur_obs[0])
             else:
-                a = (torch.rand(B, nact, device=dev, generator=gen) * 2 - 1) * scale[0]
+                a = abuf.uniform_(-scale[0], scale[0], generator=gen)   # one launch: U(-1, 1)^nact x action scale
             o, r, d, _ = genv.step(a)
-            done_count.add_(d.sum())
+            done_each.add_(d)   # (one elementwise launch; summed after the timed window)
             if not args.no_reset and not genv.auto_reset:
                 o = genv.reset(d)  # masked jaco_reset of the finished envs: no host sync; their obs rows become the new episode's first
             # (default: option auto_reset -- the same reset, done inside jaco_step by the wave that finished the episode)
@@ -475,6 +477,8 @@ def main():
     for _ in range((args.preroll if args.level == "env" else 0) + args.warmup):
         step()
     done_count.zero_()
+    if args.level == "env":
+        done_each.zero_()
     env.launch_count()   # (reset the kernel-launch counter)
     env.enable_timing(True)
     if world > 1 and args.level == "env":
@@ -484,6 +488,8 @@ def main():
     step_ms = env.step_time_ms()
     kern_ms, launches = env.kernel_time_ms()
     env.enable_timing(False)
+    if args.level == "env":
+        done_count.add_(done_each.sum())
     done_fraction = float(done_count.item()) / (B * args.steps)
     launches_per_step = env.launch_count() / float(args.steps)
     flags = int(np.bitwise_or.reduce(env.flags().cpu().numpy().astype(np.uint32)))   # OR over the batch (a max would let a big informational bit hide a small error bit)

@@ -97,11 +97,11 @@ JDEV v3 support_geom(const JacoStepArgs& A, const JacoModelDev* m, const L& s, i
 
 // ---------------------------------------------------------------- plane narrowphase
 template <class L>
-JDEV void collide_plane_box(const JacoModelDev* m, L& s, int g1, int g2, int pair, int lane, int& ncon, unsigned& flags) {
+JDEV void collide_plane_box(v3 size, L& s, int g1, int g2, int pair, int lane, int& ncon, unsigned& flags) {
   GeomPose P = geom_pose(s, g1), B = geom_pose(s, g2);
   v3 n = col(P.R, 2);
   int i = lane & 7;
-  v3 l = mk3((i & 1) ? m->g_size[g2][0] : -m->g_size[g2][0], (i & 2) ? m->g_size[g2][1] : -m->g_size[g2][1], (i & 4) ? m->g_size[g2][2] : -m->g_size[g2][2]);
+  v3 l = mk3((i & 1) ? size.x : -size.x, (i & 2) ? size.y : -size.y, (i & 4) ? size.z : -size.z);
   v3 c = B.p + mul(B.R, l);
   float dist = dot(c - P.p, n);
   push_contacts(s, lane < 8 && !(dist > 0.f), dist, c - n * (0.5f * dist), n, pair, ncon, flags, 4);
@@ -130,7 +130,7 @@ JDEV void collide_plane_convex(const JacoStepArgs& A, const JacoModelDev* m, L& 
 // Row r handles candidate cbase + r of the list; lane c of the A-arrays holds candidate c's pair index, code and contact bookkeeping.
 template <class L>
 JDEV void collide_box_box4(const JacoModelDev* m, L& s, int cbase, int nrows, int pkA, int codeA, unsigned m1A, unsigned m2A, int obA, int dimA,
-                           int lane, int& ncon, unsigned& flags) {
+                           v3 saA, v3 sbA, int lane, int& ncon, unsigned& flags) {
   constexpr int MAXCON = L::Caps::MAXCON;
   const int g = lane >> 4, a = lane & 15, rb = lane & 48;
   const bool slot = g < nrows;
@@ -140,7 +140,10 @@ JDEV void collide_box_box4(const JacoModelDev* m, L& s, int cbase, int nrows, in
   const int pob = wave_shfl_i(obA, src), pdim = wave_shfl_i(dimA, src);
   const int g1 = code & 255, g2 = (code >> 8) & 255;
   GeomPose P1 = geom_pose(s, g1), P2 = geom_pose(s, g2);
-  float s1[3] = {m->g_size[g1][0], m->g_size[g1][1], m->g_size[g1][2]}, s2[3] = {m->g_size[g2][0], m->g_size[g2][1], m->g_size[g2][2]};
+  // box half sizes: from the pair record lane `src` fetched with the candidate (one L2 round trip for the whole candidate chunk
+  // instead of a dependent g_size load per pass)
+  float s1[3] = {wave_shfl(saA.x, src), wave_shfl(saA.y, src), wave_shfl(saA.z, src)}, s2[3] = {wave_shfl(sbA.x, src), wave_shfl(sbA.y, src), wave_shfl(sbA.z, src)};
+  (void)m;
   v3 Aa[3] = {col(P1.R, 0), col(P1.R, 1), col(P1.R, 2)}, Ba[3] = {col(P2.R, 0), col(P2.R, 1), col(P2.R, 2)};
   v3 pp = P2.p - P1.p;
   const int ai = a < 15 ? a : 0;
@@ -438,17 +441,18 @@ JDEV v3 mpr_find_pos(const Sup& p0, const Sup& p1, const Sup& p2, const Sup& p3)
   return (a1 + a2) * (0.5f / sum);
 }
 // returns true on penetration
-template <class L>
-JDEV bool mpr_penetration(const JacoStepArgs& A, const JacoModelDev* m, const L& s, int g1, int t1, int g2, int t2, int lane,
-                          float* depth, v3* dirout, v3* pos) {
+// On a miss that ended on a support test (the support of G1 - G2 along `dr` does not reach past the origin) *sep = dr: a separating
+// direction, which the caller caches for the pair (stage_collision, "separating directions").
+JDEV bool mpr_penetration(const JacoStepArgs& A, const JacoModelDev* m, const MprGeom& G1, const MprGeom& G2, int lane,
+                          float* depth, v3* dirout, v3* pos, v3* sep, bool* sepvalid) {
   Sup p0, p1, p2, p3, v4;
   float tol = m->mpr_tolerance;
-  const MprGeom G1 = mpr_geom(m, s, g1, t1), G2 = mpr_geom(m, s, g2, t2);
+  *sepvalid = false;
   p0.v1 = G1.P.p; p0.v2 = G2.P.p; p0.v = p0.v1 - p0.v2;
   if (norm(p0.v) < 1e-9f) p0.v.x = 1e-5f;
   v3 dr = normalized(-p0.v);
   p1 = mpr_support(A, G1, G2, dr, lane);
-  if (dot(p1.v, dr) <= 0.f) return false;
+  if (dot(p1.v, dr) <= 0.f) { *sep = dr; *sepvalid = true; return false; }
   dr = cross(p0.v, p1.v);
   if (norm(dr) < 1e-9f) {
     *depth = norm(p1.v); *dirout = normalized(p1.v); *pos = (p1.v1 + p1.v2) * 0.5f;
@@ -456,13 +460,13 @@ JDEV bool mpr_penetration(const JacoStepArgs& A, const JacoModelDev* m, const L&
   }
   dr = normalized(dr);
   p2 = mpr_support(A, G1, G2, dr, lane);
-  if (dot(p2.v, dr) <= 0.f) return false;
+  if (dot(p2.v, dr) <= 0.f) { *sep = dr; *sepvalid = true; return false; }
   dr = normalized(cross(p1.v - p0.v, p2.v - p0.v));
   if (dot(dr, p0.v) > 0.f) { Sup t = p1; p1 = p2; p2 = t; dr = -dr; }
   for (int it = 0;; it++) {
     if (it > 100) return false;
     p3 = mpr_support(A, G1, G2, dr, lane);
-    if (dot(p3.v, dr) <= 0.f) return false;
+    if (dot(p3.v, dr) <= 0.f) { *sep = dr; *sepvalid = true; return false; }
     bool cont = false;
     if (dot(cross(p1.v, p3.v), p0.v) < -1e-11f) { p2 = p3; cont = true; }
     if (!cont && dot(cross(p3.v, p2.v), p0.v) < -1e-11f) { p1 = p3; cont = true; }
@@ -473,7 +477,8 @@ JDEV bool mpr_penetration(const JacoStepArgs& A, const JacoModelDev* m, const L&
     dr = portal_dir(p1, p2, p3);
     if (dot(dr, p1.v) >= 0.f) break;
     v4 = mpr_support(A, G1, G2, dr, lane);
-    if (dot(v4.v, dr) < 0.f || reach_tol(p1, p2, p3, v4, dr, tol) || it > m->mpr_iterations) return false;
+    if (dot(v4.v, dr) < 0.f) { *sep = dr; *sepvalid = true; return false; }
+    if (reach_tol(p1, p2, p3, v4, dr, tol) || it > m->mpr_iterations) return false;
     expand_portal(p0, p1, p2, p3, v4);
   }
   for (int it = 0;; it++) {
@@ -576,7 +581,7 @@ JDEV void list_chunk(L& s, unsigned ent, bool valid, int& n1) {
 }
 
 template <class L>
-JDEV void stage_collision(const JacoStepArgs& A, const JacoModelDev* m, L& s, int lane, unsigned& flags, JProfCtx& pc, PairList<typename L::Caps>& pl) {
+JDEV void stage_collision(const JacoStepArgs& A, const JacoModelDev* m, L& s, int env, int lane, unsigned& flags, JProfCtx& pc, PairList<typename L::Caps>& pl) {
   (void)pc;
   typedef PairList<typename L::Caps> PL;
   // phase 1: bounding spheres.  How far has any geom centre moved since the list was built?
@@ -655,17 +660,28 @@ JDEV void stage_collision(const JacoStepArgs& A, const JacoModelDev* m, L& s, in
   for (int cb = 0; cb < ncand; cb += 64) {
     const int nhere = ncand - cb < 64 ? ncand - cb : 64;
     const int pkA = s.cand[lane < nhere ? cb + lane : cb];
-    const int codeA = m->pair_code[pkA];
+    // the pair's 32-byte record: code + the two geoms' box half sizes (what box-box and plane-box need next)
+    const v4 rec0 = ld4(reinterpret_cast<const float*>(&m->pair_obb[pkA])), rec1 = ld4(reinterpret_cast<const float*>(&m->pair_obb[pkA]) + 4);
+    const int codeA = __builtin_bit_cast(int, rec0.x);
+    const v3 saA = mk3(rec0.y, rec0.z, rec0.w), sbA = mk3(rec1.x, rec1.y, rec1.z);
     const unsigned m1A = m->pair[pkA].m1, m2A = m->pair[pkA].m2;
     const int obA = m->pair[pkA].ob, dimA = m->pair[pkA].condim;
     const unsigned long long boxes = wave_ballot(lane < nhere && ((codeA >> 16) & 255) == (JG_BOX | (JG_BOX << 4)));
+    // Separating directions (hull pairs).  A pair that MPR found apart ended on a direction d with  max over (G1 - G2) of x . d <= 0; as
+    // long as one support query along the cached d still gives < -10 um the geoms are provably apart and MPR -- which would say the same
+    // after ~5 queries -- is not run.  Per (env, pair) one float4 in global memory (w = 1: valid), fetched here with the pair records; any
+    // stale or foreign value is harmless (it is re-validated by that one query), so the cache needs no hand-off discipline and cannot
+    // change a result: only misses are skipped.
+    v4 sepA; sepA.x = sepA.y = sepA.z = sepA.w = 0.f;
+    float* const seprow = A.sepdir ? A.sepdir + (size_t)env * (4 * JMAXPAIR) : nullptr;
+    if (seprow && lane < nhere && ((codeA >> 16) & 15) != JG_PLANE && ((codeA >> 16) & 255) != (JG_BOX | (JG_BOX << 4))) sepA = ld4(seprow + 4 * pkA);
     for (int c = 0; c < nhere;) {
       lane = wave_opaque_i(lane);   // (lane-id predicates of the narrowphase routines stay inside the loop: physics_kernel.h stage_newton)
       // contact buffer full and a bigger tier to hand the env to: the rest of the narrowphase would be thrown away with the substep
       if (L::Caps::MAXEFC < JacoHuge::MAXEFC && (wave_uniform_i((int)flags) & (int)JFLAG_CON_OVERFLOW)) break;
       if ((boxes >> c) & 1ull) {   // a run of up to four box-box pairs, one 16-lane row each
         const int run = ffs64(~(boxes >> c) | 16ull);
-        collide_box_box4(m, s, c, run, pkA, codeA, m1A, m2A, obA, dimA, lane, ncon, flags);
+        collide_box_box4(m, s, c, run, pkA, codeA, m1A, m2A, obA, dimA, saA, sbA, lane, ncon, flags);
         c += run;
         continue;
       }
@@ -675,7 +691,7 @@ JDEV void stage_collision(const JacoStepArgs& A, const JacoModelDev* m, L& s, in
       const int g1 = code & 255, g2 = (code >> 8) & 255, t1 = (code >> 16) & 15, t2 = (code >> 20) & 15;
       const int before = ncon;
       if (t1 == JG_PLANE) {
-        if (t2 == JG_BOX) collide_plane_box(m, s, g1, g2, pk, lane, ncon, flags);
+        if (t2 == JG_BOX) collide_plane_box(mk3(wave_bcast(sbA.x, c), wave_bcast(sbA.y, c), wave_bcast(sbA.z, c)), s, g1, g2, pk, lane, ncon, flags);
         else if (t2 == JG_SPHERE) collide_plane_sphere(m, s, g1, g2, pk, lane, ncon, flags);
         else if (t2 == JG_MESH) collide_plane_convex(A, m, s, g1, g2, t2, pk, lane, ncon, flags);
       } else {
@@ -684,7 +700,22 @@ JDEV void stage_collision(const JacoStepArgs& A, const JacoModelDev* m, L& s, in
 #ifdef JACO_EMULATED
         const long q0_ = emu_counter[7];
 #endif
-        bool hit = mpr_penetration(A, m, s, g1, t1, g2, t2, lane, &depth, &dir, &pos);
+        const MprGeom G1 = mpr_geom(m, s, g1, t1), G2 = mpr_geom(m, s, g2, t2);
+        const float sw = wave_bcast(sepA.w, c);
+        bool hit = false, apart = false, sepvalid = false;
+        v3 sep = mk3(0.f, 0.f, 0.f);
+        if (sw != 0.f) {   // (wave-uniform)
+          const v3 d = mk3(wave_bcast(sepA.x, c), wave_bcast(sepA.y, c), wave_bcast(sepA.z, c));
+          const Sup q = mpr_support(A, G1, G2, d, lane);
+          apart = dot(q.v, d) < -1e-5f && fabsf(dot(d, d) - 1.f) < 1e-3f;
+        }
+        if (!apart) {
+          hit = mpr_penetration(A, m, G1, G2, lane, &depth, &dir, &pos, &sep, &sepvalid);
+          if (seprow && lane == 0 && (sepvalid || sw != 0.f)) {
+            v4 o; o.x = sep.x; o.y = sep.y; o.z = sep.z; o.w = sepvalid ? 1.f : 0.f;
+            *reinterpret_cast<v4*>(seprow + 4 * pk) = o;
+          }
+        }
 #ifdef JACO_EMULATED
         if (lane == 0) { emu_counter[3]++; emu_counter[4] += hit; emu_counter[hit ? 5 : 6] += emu_counter[7] - q0_; }   // (CPU diagnostics: tools/mpr_query_stats.py)
 #endif

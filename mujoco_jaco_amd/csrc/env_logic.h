@@ -630,13 +630,17 @@ JDEV void stage_osc(const JacoModelDev* m, L& s, int lane, unsigned& flags) { st
 
 // ---------------------------------------------------------------- a2: action -> target / gripper ramp (env_mujoco_util.py:602-646)
 template <class L>
-JDEV void take_action(const JacoModelDev* m, L& s, const float* act, int nact, int lane) {
+JDEV void take_action(const JacoModelDev* m, L& s, const float* act_in, int nact, int lane) {
   v3 pe; m3 Re;
   ee_frame(m, s, &pe, &Re);
   float eul[3];
   mat_to_euler_rxyz(Re, eul);
   if (lane == 0) {
     float* t = s.task;
+    // np.clip(action, act_min, act_max) with act_max = -act_min = 1 (env_mujoco.py:117; a NaN stays a NaN, as under np.clip)
+    float a_[7];
+    for (int k = 0; k < 7; k++) { const float x = k < nact ? act_in[k] : 0.f; a_[k] = x > 1.f ? 1.f : (x < -1.f ? -1.f : x); }
+    const float* act = a_;
     t[JT_TARGET + 0] = pe.x + act[0] / 25.f; t[JT_TARGET + 1] = pe.y + act[1] / 25.f; t[JT_TARGET + 2] = pe.z + act[2] / 25.f;
     t[JT_TARGET + 3] = eul[0] + act[3] / 5.f; t[JT_TARGET + 4] = eul[1] + act[4] / 5.f;
     float yaw = eul[2] + act[5] / 5.f;

@@ -66,6 +66,8 @@ struct JacoHandle {
   hipStream_t side[3] = {nullptr, nullptr, nullptr};   // the tiers' resident workers run here, concurrently with the light grid
   hipEvent_t ev_pre = nullptr, ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
   int pair_list = 1;   // option "pair_list"
+  float* sepdir = nullptr;   // [num_envs][JMAXPAIR][4] separating-direction cache of the hull narrowphase (collision.h)
+  int sep_cache = 1;         // option "sep_cache"
   int concurrent = 1, workers = 1024, workers_heavy = 256, workers_huge = 32, tier_return = 1, use_hints = 2, handdown = 1;   // options "concurrent_heavy", "heavy_workers", "hints"
   float *task_rows = nullptr, *cache = nullptr;
   float* marker = nullptr;    // [num_envs][2][12] poses of the "hand" / "subgoal_reach" markers (mocap bodies the task layer moves)
@@ -160,6 +162,10 @@ extern "C" int jaco_create(const JacoConfig* cfg, JacoHandle** out) {
   CREATECHK(hipMalloc(&h->qlist, 6 * B * sizeof(int)));   // (per tier 2 B slots: an env can come by twice, see the second drain round)
   CREATECHK(hipMalloc(&h->qctl, JQ_WORDS * sizeof(int)));
   CREATECHK(hipMemset(h->qctl, 0, JQ_WORDS * sizeof(int)));
+  if (m.npair > 0) {
+    CREATECHK(hipMalloc(&h->sepdir, B * JMAXPAIR * 4 * sizeof(float)));
+    CREATECHK(hipMemset(h->sepdir, 0, B * JMAXPAIR * 4 * sizeof(float)));
+  }
   CREATECHK(hipMalloc(&h->hint, B * sizeof(int)));
   CREATECHK(hipMemset(h->hint, 0, B * sizeof(int)));
   CREATECHK(hipMalloc(&h->routed_mark, B * sizeof(int)));
@@ -228,7 +234,7 @@ extern "C" int jaco_destroy(JacoHandle* h) {
   }
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_pre) (void)hipEventDestroy(h->ev_pre);
-  void* ptrs[] = {h->model_dev, h->hull_dev, h->qpos, h->qvel, h->qacc_ws, h->qpos_lo, h->qvel_lo, h->sensordata, h->flags, h->stats, h->dbg, h->prof, h->remaining, h->qlist, h->qctl, h->hint, h->routed_mark, h->task_rows, h->cache, h->cost, h->order, h->marker, h->order_ctl, h->qpos0_dev};
+  void* ptrs[] = {h->model_dev, h->hull_dev, h->qpos, h->qvel, h->qacc_ws, h->qpos_lo, h->qvel_lo, h->sensordata, h->flags, h->stats, h->dbg, h->prof, h->remaining, h->qlist, h->qctl, h->hint, h->routed_mark, h->task_rows, h->cache, h->cost, h->order, h->marker, h->order_ctl, h->qpos0_dev, h->sepdir};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   delete h;
   return JACO_OK;
@@ -450,7 +456,7 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
   A.model = h->model_dev; A.hull = h->hull_dev; A.qpos = h->qpos; A.qvel = h->qvel; A.qacc_ws = h->qacc_ws; A.qpos_lo = h->qpos_lo; A.qvel_lo = h->qvel_lo;
   A.ctrl = ctrl ? ctrl : h->qvel;   // env modes compute ctrl in-kernel; the pointer only has to be readable
   A.sensordata = h->sensordata; A.flags = h->flags; A.stats = h->stats; A.nenv = h->num_envs; A.nsub = nsub;
-  A.disable_contact = h->disable_contact; A.no_pairlist = !h->pair_list; A.no_tier_return = !h->tier_return; A.dbg = dbg; A.dbg_env = dbg_env; A.prof = h->prof;
+  A.disable_contact = h->disable_contact; A.no_pairlist = !h->pair_list; A.sepdir = h->sep_cache ? h->sepdir : nullptr; A.no_tier_return = !h->tier_return; A.dbg = dbg; A.dbg_env = dbg_env; A.prof = h->prof;
   A.remaining = h->remaining; A.light_left = h->qctl + JQ_LIGHT; A.hint = h->use_hints ? h->hint : nullptr; A.hint_mode = h->use_hints;
   for (int t = 0; t < 3; t++) { A.q[t].list = h->qlist + (size_t)t * 2 * h->num_envs; A.q[t].count = h->qctl + JQ_COUNT + t; A.q[t].taken = h->qctl + JQ_TAKEN + t; A.q[t].limit = h->qctl + JQ_LIMIT + t; A.q[t].reserve = h->qctl + JQ_RESERVE + t; }
   A.routed_mark = nullptr; A.launch_id = ++h->launch_id;
@@ -737,6 +743,7 @@ extern "C" int jaco_set_option(JacoHandle* h, const char* name, double v) {
   JacoModelDev& m = h->model_host;
   if (!strcmp(name, "disable_contact")) { h->disable_contact = v != 0; return JACO_OK; }
   if (!strcmp(name, "pair_list")) { h->pair_list = v != 0; return JACO_OK; }
+  if (!strcmp(name, "sep_cache")) { h->sep_cache = v != 0; return JACO_OK; }
   if (!strcmp(name, "schedule")) { h->schedule = v != 0; return JACO_OK; }
   if (!strcmp(name, "concurrent_heavy")) { h->concurrent = v != 0; return JACO_OK; }
   if (!strcmp(name, "tier_return")) { h->tier_return = v != 0; return JACO_OK; }

@@ -110,6 +110,7 @@ struct JacoStepArgs {
   int* hint;           // [nenv] highest tier (0..3) the env's last step really needed, or nullptr: where its next step starts
   int nenv, nsub, disable_contact;
   int no_pairlist;     // 1: the bounding-sphere phase tests every pair in every substep (option "pair_list" = 0: comparison runs)
+  float* sepdir;       // [nenv][JMAXPAIR][4] cached separating direction of every hull pair (collision.h), or nullptr (option "sep_cache" = 0)
   int handdown;        // 1: a heavy-tier workgroup (4 per CU) passes an env that has calmed down on to the medium queue instead of running the
                        //    medium / light code itself for the rest of the step (first heavy drain only: a second medium drain follows it)
   int hint_mode;       // 1: an env's next step starts in the biggest tier this step really needed; 2: in the tier its last substep needed
@@ -1687,7 +1688,7 @@ again:
     // which are dead once the contact list exists.  (Actuation touches neither: no synchronisation of its own.)
     unsigned cflags = 0;
     if (C::CONTACT && !A.disable_contact) {
-      stage_collision(A, m, s, lane, cflags, pc, pl);
+      stage_collision(A, m, s, env, lane, cflags, pc, pl);
       wave_sync();
       JSTAMP(4);
       stage_limit_rows(m, s, lane, pf);

@@ -154,13 +154,14 @@ class JacoBatchedEnv:
         return m.reshape(self.num_envs).to(torch.uint8).contiguous()
 
     def _action(self, action):
-        """Validated, clipped [num_envs, nact] fp32 device tensor (the kernel reads nact floats per env unconditionally)."""
+        """Validated [num_envs, nact] fp32 device tensor (the kernel reads nact floats per env unconditionally).  The np.clip of
+        env_mujoco.py:117 happens inside the kernel (env_logic.h take_action): no elementwise launch per step for a tensor that is
+        already on the device in the right layout."""
         a = torch.as_tensor(action, dtype=torch.float32, device=self.device)
         nact = self.action_space.shape[0]
         if a.numel() != self.num_envs * nact or (a.dim() > 1 and a.shape[-1] != nact):
             raise ValueError("action must have shape (%d, %d), got %s" % (self.num_envs, nact, tuple(a.shape)))
-        a = a.reshape(self.num_envs, nact)
-        return torch.clamp(a, self._amin, self._amax).contiguous()                    # np.clip (env_mujoco.py:117)
+        return a.reshape(self.num_envs, nact).contiguous()
 
     def take_action(self, a, weight=None, subgoal=None, id=None):
         """env_mujoco.py:158-159 -> _take_action (env_mujoco_util.py:602-646): EE target, gripper command, marker poses; no physics."""
@@ -199,7 +200,7 @@ class JacoBatchedEnv:
         self.current_steps += 1
         obs, rew, done = self._out(self._obs, self._rew, self._done)
         if self.num_envs != 1:
-            done = done.bool()
+            done = done.view(torch.bool)   # (the kernel writes 0 / 1: a reinterpreting view of the same buffer, no launch)
         return obs, rew, done, {0: 0}
 
     def make_observation(self):

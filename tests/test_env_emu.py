@@ -520,3 +520,16 @@ def test_reset_draws_of_releasing_and_carrying_stay_in_the_references_ranges(mod
             assert np.all(e.qpos[:, 6:9] == np.float32(0.6))
         else:
             assert np.all(e.qpos[:, 6:9] == np.float32(model_arrays["qpos0"][6:9]))   # fingers stay at the joint reference (mujoco.py:342-343)
+
+
+def test_action_is_clipped_inside_the_kernel(names, model_arrays):
+    """np.clip(action, act_min, act_max) of env_mujoco.py:117 happens in take_action (env_logic.h): an action beyond [-1, 1] gives the
+    target, gripper command and state of its clipped twin, bit for bit."""
+    outs = []
+    for a in (np.array([2.5, -3.0, 0.4, 1.5, -0.2, -9.0, 7.0], np.float32), np.array([1.0, -1.0, 0.4, 1.0, -0.2, -1.0, 1.0], np.float32)):
+        e, _ = _pair(names, model_arrays, 4, 3)
+        e.forward()
+        e.env_step(a, np.full((1, 12), 0.5, np.float32))
+        outs.append((e.task[0].copy(), e.qpos[0].copy(), e.obs[0].copy()))
+    for x, y in zip(*outs):
+        assert np.array_equal(x, y)
