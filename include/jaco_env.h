@@ -148,6 +148,11 @@ int jaco_set_subgoal(JacoHandle* h, const float* subgoal_dev);
 int jaco_get_task_state(JacoHandle* h, float* out_dev, void* stream);
 int jaco_set_task_state(JacoHandle* h, const float* in_dev, void* stream);
 int jaco_task_row_floats(void);
+/* What the most recent TERMINAL step of every env returned besides (reward, done): out_dev [num_envs][2] f32 = (success flag, wb) -- the
+ * `succ` and `wb` of terminal_inspection (env_mujoco.py:125,144-150), latched by the step that ended the episode.  Needed with option
+ * "auto_reset", where the task row already belongs to the new episode when jaco_step returns (the reference's accum_succ bookkeeping,
+ * env_mujoco.py:129-136, reads succ in the terminal step).  Rows of envs that have not finished an episode yet are (0, 0). */
+int jaco_get_last_terminal(JacoHandle* h, float* out_dev, void* stream);
 /* Marker poses [num_envs][2][12] f32: {"hand", "subgoal_reach"} x {position, rotation matrix row-major} -- the two mocap bodies
  * _take_action moves every env step (set_mocap_xyz / set_mocap_orientation, mujoco.py:248-256, env_mujoco_util.py:613-615,
  * 644-646).  Their contype-8 geoms collide with the EE axis sticks; jaco_step updates them in-kernel, jaco_reset* park

@@ -819,9 +819,18 @@ JDEV void stage_contact_rows(const JacoModelDev* m, L& s, int lane, unsigned& fl
     // JSIDE_ROWS rows and no other contact reaches into that block (every tier counts them: "would the light tier cope?" needs the number)
     const unsigned mm = cm1 | cm2;
     bool sidec = false;
-    int end = rowbase + wave_scan_incl(nrow, lane);
+    // inclusive prefix sum of the row counts.  A contact has 1, 4 or 10 rows (condim 1 / 3 / 6): three ballots and their prefix counts
+    // instead of a six-step shuffle scan (each step an LDS-crossbar round trip)
+    const unsigned long long upto = lane >= 63 ? ~0ull : ((2ull << lane) - 1ull);   // lanes <= mine
+    const unsigned long long r1m = wave_ballot(nrow == 1), r4m = wave_ballot(nrow == 4), r10m = wave_ballot(nrow == 10);
+    const bool rows_std = wave_ballot(nrow != 0 && nrow != 1 && nrow != 4 && nrow != 10) == 0ull;
+    int end = rowbase + (rows_std ? popc64(r1m & upto) + 4 * popc64(r4m & upto) + 10 * popc64(r10m & upto) : wave_scan_incl(nrow, lane));
     // (only looked for when the rows exceed the light tier's buffer: nobody asks for the number otherwise)
+#ifdef JACO_SIDE_ALWAYS   // A/B build (tools/build_variant.sh sidealways -DJACO_SIDE_ALWAYS): the pedestal's rows go to the side solve whenever they are separable
+    if (JNV - JB1 == 6 && cb == 0) {
+#else
     if (JNV - JB1 == 6 && cb == 0 && wave_bcast_i(end, nhere - 1) > JSIDE_BASE) {
+#endif
       const bool only2 = lane < nhere && mm != 0u && (mm & ((1u << JB1) - 1u)) == 0u && nrow <= 4;
       const bool reach2 = lane < nhere && !only2 && (mm >> JB1) != 0u;
       const unsigned long long o2 = wave_ballot(only2);
@@ -833,7 +842,11 @@ JDEV void stage_contact_rows(const JacoModelDev* m, L& s, int lane, unsigned& fl
     }
     bool split = false;
     int r0s = 0;
+#ifdef JACO_SIDE_ALWAYS
+    if (SIDE && side_cand > 0 && wave_bcast_i(end, nhere - 1) - side_cand <= MAXEFC) {
+#else
     if (SIDE && side_cand > 0 && wave_bcast_i(end, nhere - 1) > MAXEFC && wave_bcast_i(end, nhere - 1) - side_cand <= MAXEFC) {
+#endif
       // the rows do not fit the main buffer, and they do without the pedestal's: split
       split = true;
       end = rowbase + wave_scan_incl(sidec ? 0 : nrow, lane);

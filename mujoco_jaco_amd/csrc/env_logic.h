@@ -18,7 +18,10 @@
 #define JT_TARGET 10     // [6] EE target pose (xyz + euler rxyz)
 #define JT_GRIP_PREV 16
 #define JT_SUB 17        // substep index inside the current env step (tier hand-off)
-#define JT_RNG 18        // draw counter (bit pattern of an unsigned)
+#define JT_RNG 18        // draw counter (bit pattern of an unsigned).  NOTE: small counts are fp32 DENORMAL patterns and the library is built with
+                         // -fgpu-flush-denormals-to-zero: the slot must only ever be moved (loads, stores, v_readlane, __float_as_uint), never
+                         // pass through a floating-point operation (a select via fmul, a canonicalising min / max, `task * mask` on the host side)
+                         // -- that would zero the counter and restart the env's RNG stream.  tests/test_gpu_env.py pins the round trip.
 #define JT_PENDING 19    // 1: JT_CTRL holds the ctrl of the interrupted substep
 #define JT_CTRL 20       // [9]
 #define JT_SUCC 29       // success flag of the last terminal step

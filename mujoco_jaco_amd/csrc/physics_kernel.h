@@ -136,6 +136,7 @@ struct JacoStepArgs {
   float* obs;                // [nenv][26]
   float* reward;             // [nenv]
   unsigned char* done;       // [nenv]
+  float* terminal;           // [nenv][2] (success flag, wb) of the env's most recent terminal step (jaco_get_last_terminal), or nullptr
   unsigned* cost;            // [nenv] shader-clock ticks (>> 4) the env's last step took (launch-order heuristic), or nullptr
   const int* order;          // light tier, optional: workgroup -> env permutation (expensive envs first), else identity
   const int* nslots;         // light tier, optional: [1] number of valid entries of `order` (masked resets launch a small grid over the list of reset envs), else nenv
@@ -1932,6 +1933,7 @@ again:
           s.task[JT_SUCC] = (float)succ; s.task[JT_WB] = wb; s.task[JT_SUB] = 0.f; s.task[JT_PENDING] = 0.f; s.task[JT_PICKED] = picked;
           A.reward[env] = rew + bonus;
           A.done[env] = done ? 1 : 0;
+          if (done && A.terminal) { A.terminal[2 * (size_t)env] = (float)succ; A.terminal[2 * (size_t)env + 1] = wb; }   // (survives the in-kernel reset)
         }
         reset_now = emode == 1 && A.auto_reset != 0 && wave_ballot(done) != 0ull;
       }

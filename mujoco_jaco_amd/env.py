@@ -236,6 +236,15 @@ class JacoBatchedEnv:
     def successes(self):
         return self.task_state()[:, 29] > 0.5
 
+    def last_terminal(self):
+        """(success [num_envs] bool, wb [num_envs] f32) of every env's most recent terminal step -- `succ` and `wb` of
+        terminal_inspection (env_mujoco.py:125,144-150), latched by the step that ended the episode.  With auto_reset the task row
+        (successes(), get_wb()) already belongs to the new episode when step() returns; this is what the reference's success-rate
+        bookkeeping (env_mujoco.py:129-136) reads."""
+        t = torch.empty(self.num_envs, 2, device=self.device)
+        self.sim._chk(self.L.jaco_get_last_terminal(self.h, self._p(t), self.sim._stream()))
+        return t[:, 0] > 0.5, t[:, 1]
+
     def seed(self, seed):
         pass  # the reference's seed() is a no-op too (env_mujoco.py:163-164); pass `seed=` to the constructor instead
 

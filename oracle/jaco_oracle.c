@@ -1328,9 +1328,16 @@ void orc_step(const OrcModel* m, OrcData* d) {
      * sees its fp32 rounding -- the ceiling for an fp32 engine that carries its state compensated (hi + lo floats): rounding
      * then perturbs each evaluation but never accumulates in the state */
     double q[64], v[64];
+    if (m->nq > 64 || m->nv > 64) { fprintf(stderr, "orc_step: round_state >= 2 supports at most 64 coordinates (model has nq %d nv %d)\n", m->nq, m->nv); abort(); }
+    /* variant 3 exempts the height of the LAST free body (the destination pedestal of jaco2_curtain_torque: qpos 18); a model without a
+     * free joint has nothing to exempt */
+    int exempt = -1;
+    for (int b = 0; b < m->nbody; b++)
+      for (int j = m->body_jntadr[b]; j >= 0 && j < m->body_jntadr[b] + m->body_jntnum[b]; j++)
+        if (m->jnt_type[j] == J_FREE) exempt = m->jnt_qposadr[j] + 2;
     memcpy(q, d->qpos, sizeof(double) * m->nq);
     memcpy(v, d->qvel, sizeof(double) * m->nv);
-    for (int i = 0; i < m->nq; i++) if (!(m->round_state == 3 && i == 18)) d->qpos[i] = (double)(float)d->qpos[i];   /* (3: the pedestal's height keeps its exact value -- its bottom face starts exactly on the floor plane, see tools/drift_control.py variant D) */
+    for (int i = 0; i < m->nq; i++) if (!(m->round_state == 3 && i == exempt)) d->qpos[i] = (double)(float)d->qpos[i];   /* (3: the pedestal's height keeps its exact value -- its bottom face starts exactly on the floor plane, see tools/drift_control.py variant D) */
     for (int i = 0; i < m->nv; i++) d->qvel[i] = (double)(float)d->qvel[i];
     orc_forward(m, d);
     memcpy(d->qpos, q, sizeof(double) * m->nq);

@@ -28,6 +28,8 @@ extern "C" void emu_set_hints(int on) { g_use_hints = on; }
 long emu_counter[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 extern "C" long emu_get_counter(int i, int reset) { long v = emu_counter[i & 7]; if (reset) emu_counter[i & 7] = 0; return v; }
 static int g_no_pairlist = 0;
+static std::vector<float> g_terminal;
+extern "C" const float* emu_last_terminal() { return g_terminal.data(); }   // [nenv][2] (success, wb) latched by terminal steps
 static int g_sep_cache = 1;
 static std::vector<float> g_sepdir;
 extern "C" void emu_set_sep_cache(int on) { g_sep_cache = on; g_sepdir.clear(); }   // 0: every hull pair goes through MPR (option "sep_cache" = 0); either call empties the cache
@@ -40,6 +42,8 @@ static int emu_launch(JacoStepArgs A, int* heavy_envs) {
   A.no_pairlist = g_no_pairlist;
   if (g_sepdir.size() != (size_t)A.nenv * JMAXPAIR * 4) g_sepdir.assign((size_t)A.nenv * JMAXPAIR * 4, 0.f);
   A.sepdir = g_sep_cache ? g_sepdir.data() : nullptr;
+  if (g_terminal.size() != (size_t)A.nenv * 2) g_terminal.assign((size_t)A.nenv * 2, 0.f);
+  A.terminal = g_terminal.data();
   A.obs_mode = g_obs_mode;
   std::vector<int> remaining(A.nenv, 0), lists(6 * (size_t)A.nenv, -1);
   int count[3] = {0, 0, 0}, taken[3] = {0, 0, 0}, light_left = A.nenv;

@@ -282,6 +282,11 @@ def test_kernel_terminal_inspection_against_the_references_own_outputs(model_arr
             else:
                 assert e.task[0, 29] == float(bool(rd) and rb > 100)     # success flag (the 4th value the reference's tuple lacks)
             assert e.task[0, 2] == GG["g_nsteps"][k] + 1 and e.task[0, 1] == 1
+            if rd:   # the terminal step latches (success, wb) for jaco_get_last_terminal (what survives an in-kernel reset)
+                import ctypes
+                e.L.emu_last_terminal.restype = ctypes.POINTER(ctypes.c_float)
+                lt = e.L.emu_last_terminal()
+                assert lt[0] == e.task[0, 29] and abs(lt[1] - rwb) < 1e-5
 
 
 def test_grasping_prereach_and_steps_match_oracle_env(names, model_arrays):

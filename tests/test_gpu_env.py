@@ -790,3 +790,45 @@ def test_small_action_regime_flag_census_and_parity_of_unflagged_envs(tmp_path):
         int(nfl.item()), B * nstep, share, kinds.tolist()))
     assert share <= 1e-5 and int(kinds[3]) == 0
     env.close()
+
+
+def test_last_terminal_survives_the_in_kernel_reset():
+    """jaco_get_last_terminal: (success, wb) of the step that ended an episode, latched before the auto-reset clears the task row.
+    Half of the envs are sent into the 700-step time-out (success 0, wb 0 as the reference returns there, env_mujoco.py:148-150); the
+    same steps without auto_reset give the task row's JT_SUCC / JT_WB to compare with."""
+    from mujoco_jaco_amd.env import JacoBatchedEnv
+    B = 64
+    outs = []
+    for auto in (True, False):
+        env = JacoBatchedEnv(num_envs=B, task="picking", seed=12, frame_skip=4, auto_reset=auto)
+        env.reset()
+        t = env.task_state(); t[: B // 2, 1] = 699; env.set_task_state(t)
+        o, r, d, _ = env.step(torch.zeros(B, 7))
+        succ, wb = env.last_terminal()
+        assert d[: B // 2].all() and not d[B // 2:].any()
+        outs.append((succ.clone(), wb.clone(), env.successes().clone(), env.get_wb().clone(), env.task_state()[:, 1].clone()))
+        env.close()
+    (sa, wa, _, _, steps_a), (sb, wb_, succ_row, wb_row, steps_b) = outs
+    assert torch.equal(sa, sb) and torch.equal(wa, wb_)                       # the latch does not depend on who resets
+    assert torch.equal(sb[: B // 2], succ_row[: B // 2]) and torch.equal(wb_[: B // 2], wb_row[: B // 2])   # = the terminal step's task row
+    assert (steps_a[: B // 2] == 0).all() and (steps_b[: B // 2] == 700).all()   # auto_reset: the row already belongs to the new episode
+    assert not sa.any() and (wa[B // 2:] == 0).all()
+
+
+def test_task_row_round_trip_keeps_the_draw_counter_bits():
+    """The task row's draw counter (JT_RNG, slot 18) is an unsigned stored as a float bit pattern -- a denormal for small counts, in a
+    library built with denormals flushed.  get -> set -> step must leave the RNG stream where an untouched twin has it."""
+    from mujoco_jaco_amd.env import JacoBatchedEnv
+    B = 32
+    a, b = JacoBatchedEnv(num_envs=B, task="picking", seed=5, frame_skip=2), JacoBatchedEnv(num_envs=B, task="picking", seed=5, frame_skip=2)
+    a.reset(); b.reset()
+    ts = b.task_state()
+    cnt = ts[:, 18].view(torch.int32)
+    assert (cnt > 0).all() and (cnt < 1000).all()          # a live counter: these ARE denormal bit patterns
+    b.set_task_state(ts.clone())
+    assert torch.equal(b.task_state().view(torch.int32), ts.view(torch.int32))
+    z = torch.zeros(B, 7)
+    for _ in range(2):
+        oa, _, _, _ = a.step(z); ob, _, _, _ = b.step(z)
+    assert torch.equal(oa, ob) and torch.equal(a.task_state().view(torch.int32), b.task_state().view(torch.int32))
+    a.close(); b.close()
