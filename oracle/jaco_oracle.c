@@ -744,10 +744,10 @@ static void collide_box_box(const OrcModel* m, OrcData* d, int g1, int g2) {
 
 /* ---- MPR (Minkowski Portal Refinement) penetration query; Minkowski difference = geom1 - geom2 */
 typedef struct { double v[3], v1[3], v2[3]; } Sup;
-static long g_mpr_queries_now;
+static _Thread_local long g_mpr_queries_now;   /* (thread-local: orc_step_batch runs envs on all cores) */
 static void mpr_support(const OrcModel* m, const OrcData* d, int g1, int g2, const double* dir, Sup* s) {
   double nd[3] = {-dir[0], -dir[1], -dir[2]};
-  g_mpr_queries_now++;   /* (diagnostic; not thread-safe: read it from single-threaded runs only) */
+  g_mpr_queries_now++;   /* (diagnostic) */
   support_geom(m, d, g1, dir, s->v1);
   support_geom(m, d, g2, nd, s->v2);
   sub3(s->v, s->v1, s->v2);
@@ -819,7 +819,7 @@ static void mpr_find_pos(const Sup* p, double* pos) {
   scl3(pos, pos, 0.5 * inv);
 }
 /* diagnostic counters (tools/mpr_query_stats.py): [0] MPR calls, [1] hits, [2] support queries of the hit calls, [3] of the miss calls */
-static long g_orc_counter[4];
+static _Thread_local long g_orc_counter[4];   /* (per thread: read them from the thread that stepped, tools/mpr_query_stats.py is single-threaded) */
 long orc_debug_counter(int i, int reset) { long v = g_orc_counter[i & 3]; if (reset) g_orc_counter[i & 3] = 0; return v; }
 static int mpr_penetration_impl(const OrcModel* m, const OrcData* d, int g1, int g2, double* depth, double* dir, double* pos);
 /* returns 0 on penetration (depth, dir = from geom1 toward geom2, pos), -1 otherwise */

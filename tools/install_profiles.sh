@@ -1,11 +1,13 @@
 #!/bin/bash
-# Copy the outputs of tools/gpu_profile_all.sh from gpurun_out/ into profiles/ under the round's prefix (default r03).
+# Copy the outputs of tools/gpu_profile_all.sh from gpurun_out/ into profiles/ under the round's prefix (default r04).
 # The PMC file gets the layout bench.py replays (commit = HEAD: commit the sources the libraries were built from first).
 set -e
 cd "$(dirname "$0")/.."
-P=${1:-r03}
+P=${1:-r04}
 grep -v amdgpu.ids gpurun_out/stage_profile.txt > profiles/${P}_stage_profile.txt
 grep -v amdgpu.ids gpurun_out/stage_profile_policy.txt > profiles/${P}_stage_profile_policy.txt
+grep -v amdgpu.ids gpurun_out/stage_profile_arm.txt > profiles/${P}_stage_profile_arm.txt
+grep -v amdgpu.ids gpurun_out/soak_curve.txt > profiles/${P}_soak_curve.txt
 cp gpurun_out/bench_kernel_stats.csv profiles/${P}_bench_kernel_stats.csv
 cp gpurun_out/bench_kernel_window.txt profiles/${P}_bench_kernel_window.txt
 tail -1 gpurun_out/bench_final.json > profiles/${P}_bench_env_level.json
