@@ -194,6 +194,8 @@ class JacoBatchedEnv:
         self.sim._chk(self.L.jaco_set_subgoal(self.h, self._p(sg)))
 
     def step(self, action, weight=None, subgoal=None, id=None):
+        """env_mujoco.py:116-139.  With num_envs > 1 the returned obs / reward / done tensors are the handle's own output buffers (done: a
+        bool view of the kernel's byte flags): valid until the next step() / reset() call, `.clone()` what has to outlive it."""
         a = self._action(action)
         self._set_subgoal(subgoal)
         self.sim._chk(self.L.jaco_step(self.h, self._p(a), self._p(self._obs), self._p(self._rew), self._p(self._done), self.sim._stream()))
