@@ -64,7 +64,8 @@ _libs = {}
 
 
 def load(variant=""):
-    """variant "": the default layout (11 fused bodies, 21 dofs in blocks 9 + 6 + 6); "_d12": the build for jaco2_torque.xml."""
+    """variant "": the default layout (11 fused bodies, 21 dofs in blocks 9 + 6 + 6); "_d12": the build for jaco2_torque.xml;
+    "_d30": the build for jaco2_dual_torque.xml."""
     if variant not in _libs:
         path = LIB_PATH if not variant else os.path.join(_HERE, "libjaco_env%s.so" % variant)
         if not os.path.exists(path):
@@ -83,6 +84,8 @@ def variant_for(blob_bytes):
     """Which build of the library steps this model: the loader of each build rejects models outside its compiled layout."""
     from .modelc import blob as blobmod
     M = blobmod.loads(blob_bytes)
+    if int(M["nv"][0]) > 21 or int(M["f_nbody"][0]) > 12:
+        return "_d30"   # jaco2_dual_torque.xml: two arms + two objects (30 dofs, 20 fused bodies); sim-interface (ctrl) level only
     return "_d12" if (int(M["nv"][0]) == 12 and int(M["f_nbody"][0]) == 12) else ""
 
 

@@ -519,12 +519,14 @@ JDEV bool mpr_penetration(const JacoStepArgs& A, const JacoModelDev* m, const Mp
 template <class C>
 struct PairList {
   static constexpr int NV = C::MAXCAND > 256 ? 8 : 4;   // registers per lane, 64 entries each
-  unsigned e[NV];        // pair index | g1 << 10 | g2 << 16 | (g1 is a plane) << 22
-  float px, py, pz;      // lane = geom: its position when the list was built
+  unsigned e[NV];        // pair index | g1 << JPL_KBITS | g2 << (JPL_KBITS + JPL_GBITS) | (g1 is a plane) << (JPL_KBITS + 2 JPL_GBITS)
+  float px[JGEOM_PASSES], py[JGEOM_PASSES], pz[JGEOM_PASSES];   // geom 64 p + lane: its position when the list was built
   int n;                 // entries (wave-uniform); -1: no list (first substep of a launch, or more near pairs than the registers hold)
   unsigned planes;       // bit j: entries 64 j .. 64 j + 63 hold a plane pair
 };
-static_assert(JMAXPAIR <= 1024 && JMAXGEOM <= 64, "pair-list entry packing");
+#define JPL_KBITS (JMAXPAIR <= 1024 ? 10 : 12)
+#define JPL_GBITS (JMAXGEOM <= 64 ? 6 : 7)
+static_assert(JMAXPAIR <= (1 << JPL_KBITS) && JMAXGEOM <= (1 << JPL_GBITS) && JPL_KBITS + 2 * JPL_GBITS + 1 <= 32, "pair-list entry packing");
 // the exact bounding test of one pair: fixed fma chains, so that the all-pairs pass and the list pass round identically
 JDEV bool sphere_test(const v4& pa, const v4& pb, const v3& nrm, bool plane, float slack) {
   const float dx = pb.x - pa.x, dy = pb.y - pa.y, dz = pb.z - pa.z;
@@ -533,8 +535,8 @@ JDEV bool sphere_test(const v4& pa, const v4& pb, const v3& nrm, bool plane, flo
   return !((plane ? dn : dd) > (plane ? rp : r * r));
 }
 // all-pairs pass over the chunks 4 G .. 4 G + 3 (lane = pair): survivors are appended to s.cand in pair order, near pairs to `tmp`
-template <int G, bool PLANES, class L>
-JDEV void sphere_group(L& s, const JacoModelDev* m, int npair, int lane, int& n1, int& nl, unsigned* tmp, int tmpcap) {
+template <bool PLANES, class L>
+JDEV void sphere_group(L& s, const JacoModelDev* m, int G, int npair, int lane, int& n1, int& nl, unsigned* tmp, int tmpcap) {
   v4 pa[4], pb[4];
   v3 nrm[4];
   int codes[4];
@@ -561,7 +563,7 @@ JDEV void sphere_group(L& s, const JacoModelDev* m, int npair, int lane, int& n1
     const unsigned long long mask = wave_ballot(pass), nmask = wave_ballot(near);
     const int idx = n1 + wave_prefix_count(mask), nidx = nl + wave_prefix_count(nmask);
     if (pass && idx < L::Caps::MAXCAND) s.cand[idx] = k;
-    if (near && nidx < tmpcap) tmp[nidx] = (unsigned)k | ((unsigned)g1 << 10) | ((unsigned)g2 << 16) | (plane ? 1u << 22 : 0u);
+    if (near && nidx < tmpcap) tmp[nidx] = (unsigned)k | ((unsigned)g1 << JPL_KBITS) | ((unsigned)g2 << (JPL_KBITS + JPL_GBITS)) | (plane ? 1u << (JPL_KBITS + 2 * JPL_GBITS) : 0u);
     n1 += popc64(mask);
     nl += popc64(nmask);
   }
@@ -569,11 +571,11 @@ JDEV void sphere_group(L& s, const JacoModelDev* m, int npair, int lane, int& n1
 // list pass over entries 64 j .. 64 j + 63
 template <bool PLANES, class L>
 JDEV void list_chunk(L& s, unsigned ent, bool valid, int& n1) {
-  const int k = (int)(ent & 1023u), g1 = (int)((ent >> 10) & 63u), g2 = (int)((ent >> 16) & 63u);
+  const int k = (int)(ent & ((1u << JPL_KBITS) - 1u)), g1 = (int)((ent >> JPL_KBITS) & ((1u << JPL_GBITS) - 1u)), g2 = (int)((ent >> (JPL_KBITS + JPL_GBITS)) & ((1u << JPL_GBITS) - 1u));
   const v4 pa = ld4(s.gpos[g1]), pb = ld4(s.gpos[g2]);
   v3 nrm = mk3(0.f, 0.f, 0.f);
   if (PLANES) nrm = mk3(s.gmat[g1][2], s.gmat[g1][5], s.gmat[g1][8]);
-  const bool pass = sphere_test(pa, pb, nrm, PLANES && ((ent >> 22) & 1u) != 0u, 0.f) & valid;
+  const bool pass = sphere_test(pa, pb, nrm, PLANES && ((ent >> (JPL_KBITS + 2 * JPL_GBITS)) & 1u) != 0u, 0.f) & valid;
   const unsigned long long mask = wave_ballot(pass);
   const int idx = n1 + wave_prefix_count(mask);
   if (pass && idx < L::Caps::MAXCAND) s.cand[idx] = k;
@@ -587,13 +589,21 @@ JDEV void stage_collision(const JacoStepArgs& A, const JacoModelDev* m, L& s, in
   // phase 1: bounding spheres.  How far has any geom centre moved since the list was built?
   int n1 = 0;
   const int npair = m->npair, plane_chunks = m->plane_chunks;
-  static_assert(JMAXPAIR == 768, "three groups of four 64-pair chunks");
-  const bool isg = lane < m->ngeom;
-  const v3 gp = isg ? ld3(s.gpos[isg ? lane : 0]) : mk3(0.f, 0.f, 0.f);
+  static_assert(JMAXPAIR % 256 == 0, "groups of four 64-pair chunks");
+  v3 gp[JGEOM_PASSES];
   bool rebuild = pl.n < 0 || A.no_pairlist;
+  float d2 = 0.f;
+#pragma unroll
+  for (int p = 0; p < JGEOM_PASSES; p++) {
+    const bool isg = 64 * p + lane < m->ngeom;
+    gp[p] = isg ? ld3(s.gpos[isg ? 64 * p + lane : 0]) : mk3(0.f, 0.f, 0.f);
+    if (!rebuild) {
+      const float dx = gp[p].x - pl.px[p], dy = gp[p].y - pl.py[p], dz = gp[p].z - pl.pz[p];
+      const float dd = isg ? fmaf(dz, dz, fmaf(dy, dy, dx * dx)) : 0.f;
+      d2 = dd > d2 || !(dd == dd) ? dd : d2;   // (keeps a NaN)
+    }
+  }
   if (!rebuild) {
-    const float dx = gp.x - pl.px, dy = gp.y - pl.py, dz = gp.z - pl.pz;
-    const float d2 = isg ? fmaf(dz, dz, fmaf(dy, dy, dx * dx)) : 0.f;
     const float lim = 0.45f * JACO_PAIRLIST_SLACK;
     rebuild = wave_ballot(!(d2 < lim * lim)) != 0ull;   // (a non-finite position rebuilds, too)
   }
@@ -607,9 +617,15 @@ JDEV void stage_collision(const JacoStepArgs& A, const JacoModelDev* m, L& s, in
     unsigned* tmp = reinterpret_cast<unsigned*>(s.early_scratch);
     static_assert(PL::NV * 64 <= JSCRATCH, "pair-list staging area");
     int nl = 0;
-    if (0 < plane_chunks) sphere_group<0, true>(s, m, npair, lane, n1, nl, tmp, PL::NV * 64); else sphere_group<0, false>(s, m, npair, lane, n1, nl, tmp, PL::NV * 64);
-    if (256 < npair) { if (4 < plane_chunks) sphere_group<1, true>(s, m, npair, lane, n1, nl, tmp, PL::NV * 64); else sphere_group<1, false>(s, m, npair, lane, n1, nl, tmp, PL::NV * 64); }
-    if (512 < npair) { if (8 < plane_chunks) sphere_group<2, true>(s, m, npair, lane, n1, nl, tmp, PL::NV * 64); else sphere_group<2, false>(s, m, npair, lane, n1, nl, tmp, PL::NV * 64); }
+#if JMAXPAIR == 768
+    if (0 < plane_chunks) sphere_group<true>(s, m, 0, npair, lane, n1, nl, tmp, PL::NV * 64); else sphere_group<false>(s, m, 0, npair, lane, n1, nl, tmp, PL::NV * 64);
+    if (256 < npair) { if (4 < plane_chunks) sphere_group<true>(s, m, 1, npair, lane, n1, nl, tmp, PL::NV * 64); else sphere_group<false>(s, m, 1, npair, lane, n1, nl, tmp, PL::NV * 64); }
+    if (512 < npair) { if (8 < plane_chunks) sphere_group<true>(s, m, 2, npair, lane, n1, nl, tmp, PL::NV * 64); else sphere_group<false>(s, m, 2, npair, lane, n1, nl, tmp, PL::NV * 64); }
+#else   // (bigger pair tables: a loop over the groups)
+    for (int G = 0; 256 * G < npair; G++) {
+      if (4 * G < plane_chunks) sphere_group<true>(s, m, G, npair, lane, n1, nl, tmp, PL::NV * 64); else sphere_group<false>(s, m, G, npair, lane, n1, nl, tmp, PL::NV * 64);
+    }
+#endif
     wave_sync();
     // ... and dealt out to the lanes' registers
     pl.n = nl <= PL::NV * 64 ? nl : -1;
@@ -620,7 +636,8 @@ JDEV void stage_collision(const JacoStepArgs& A, const JacoModelDev* m, L& s, in
       pl.e[j] = have ? tmp[have ? j * 64 + lane : 0] : 0u;
       pl.planes |= wave_ballot(have && ((pl.e[j] >> 22) & 1u) != 0u) ? 1u << j : 0u;
     }
-    pl.px = gp.x; pl.py = gp.y; pl.pz = gp.z;
+#pragma unroll
+    for (int p = 0; p < JGEOM_PASSES; p++) { pl.px[p] = gp[p].x; pl.py[p] = gp[p].y; pl.pz[p] = gp[p].z; }
   } else {
 #pragma unroll
     for (int j = 0; j < PL::NV; j++) {
@@ -790,8 +807,9 @@ JDEV void stage_contact_rows(const JacoModelDev* m, L& s, int lane, unsigned& fl
   float* sd = side_buf(s);
   int rowbase = nlim, kept_total = 0, nside = 0, side_cand = 0;
   // Jacobian rows: lane = (contact slot 0..2, dof); the slot's contact data is fetched from its owner lane
+  constexpr int CPP = JNV <= 21 ? 3 : 64 / JNV;   // contacts per Jacobian pass (lane = contact slot x dof)
   const int cl = lane / JNV, k = lane - cl * JNV;
-  const bool dofok = cl < 3 && k < nv;
+  const bool dofok = cl < CPP && k < nv;
   const sv S = ldsv(s.cdof[dofok ? k : 0]);
   for (int cb = 0; cb < ncon; cb += 64) {   // lane = contact, 64 at a time (one pass unless the tier holds more than 64 contacts)
     const int ci = cb + lane, nhere = ncon - cb < 64 ? ncon - cb : 64;
@@ -889,8 +907,8 @@ JDEV void stage_contact_rows(const JacoModelDev* m, L& s, int lane, unsigned& fl
         for (int e = 0; e < 4; e++) if (e < nrow) { sd[JSIDE_AREF + r0 - JSIDE_BASE + e] = aside[e]; sd[JSIDE_D + r0 - JSIDE_BASE + e] = dinv; }
       }
     }
-    for (int c0 = 0; c0 < kept; c0 += 3) {
-      int c = c0 + (cl < 3 ? cl : 0);
+    for (int c0 = 0; c0 < kept; c0 += CPP) {
+      int c = c0 + (cl < CPP ? cl : 0);
       int src = c < 64 ? c : 0;
       int cdim = wave_shfl_i(dim, src), cr0 = wave_shfl_i(r0, src);
       float f0 = wave_shfl(mu0, src), f1 = wave_shfl(mu1, src), f2 = wave_shfl(mu2, src);
@@ -974,9 +992,17 @@ template <class L>
 JDEV void stage_touch(const JacoModelDev* m, L& s, int lane, float* sens) {
   int ncon = wave_uniform_i(s.ncon);
   {   // no contact on a body that carries a touch site (the common case: only object/pedestal/floor contacts): all zero
-    const unsigned long long sb = ((unsigned long long)m->sens_bodymask[1] << 32) | m->sens_bodymask[0];
+    const unsigned sb0 = m->sens_bodymask[0], sb1 = m->sens_bodymask[1], sb2 = m->sens_bodymask[2], sb3 = m->sens_bodymask[3];
     bool mine = false;
-    for (int ci = lane; ci < ncon; ci += 64) { int obs = s.c_ob[ci]; mine = mine || (((sb >> (obs & 0xFF)) | (sb >> ((obs >> 16) & 0xFF))) & 1ull) != 0ull; }
+    for (int ci = lane; ci < ncon; ci += 64) {
+      const int obs = s.c_ob[ci];
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int ob = (obs >> (16 * h)) & 0xFF;
+        const unsigned w = (ob >> 5) == 0 ? sb0 : ((ob >> 5) == 1 ? sb1 : ((ob >> 5) == 2 ? sb2 : sb3));
+        mine = mine || ((w >> (ob & 31)) & 1u) != 0u;
+      }
+    }
     if (!wave_ballot(mine)) { *sens = 0.f; return; }
   }
   for (int ci = lane; ci < ncon; ci += 64) {

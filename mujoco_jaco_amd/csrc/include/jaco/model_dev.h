@@ -16,10 +16,22 @@
 #define JB0 9         // dof blocks of the mass matrix (one per kinematic tree): [0,JB0) arm + fingers, [JB0,JB1) object, [JB1,JNV) pedestal
 #define JB1 15
 #endif
+// A third build, -DJNB=20 -DJNV=30 -DJNQ=32 -DJB0=18 -DJB1=24 -DJNU=18 -DJNSENS=40 -DJMAXGEOM=128 -DJMAXPAIR=3584 -DJMAXINNER=12 -DJMAXMPAIR=192
+// (libjaco_env_d30.so), serves jaco2_dual_torque.xml at the sim-interface (ctrl) level: two 9-dof arm trees side by side in dof block
+// [0, 18) (block diagonal inside it: the factorisations treat it as one block), then the two free objects; 106 collidable geoms and
+// 3 332 whitelisted pairs, so the frame, geom and pair stages run in two or more 64-lane passes there.
+#ifndef JNU
 #define JNU 9         // actuators: 6 motors + 3 finger position servos (xml:341-349)
+#endif
+#ifndef JNSENS
 #define JNSENS 20     // touch sensors (xml:352-374)
+#endif
+#ifndef JMAXGEOM
 #define JMAXGEOM 64   // collidable geoms
+#endif
+#ifndef JMAXPAIR
 #define JMAXPAIR 768  // geom pairs passing the static collision filter
+#endif
 #ifndef JMAXINNER
 #define JMAXINNER 6   // bodies that have children (link1..link6)
 #endif
@@ -29,7 +41,9 @@
 #ifndef JMAXDESC
 #define JMAXDESC 9    // bodies of one subtree: the arm's links and fingers
 #endif
+#ifndef JMAXMPAIR
 #define JMAXMPAIR 128 // structurally non-zero lower-triangle mass-matrix entries (84 for this model)
+#endif
 #define JNMOCAP 16
 
 enum { JG_PLANE = 0, JG_SPHERE = 2, JG_CYLINDER = 5, JG_BOX = 6, JG_MESH = 7 };
@@ -109,7 +123,7 @@ struct JacoModelDev {
   // touch sites, one per sensor, in sensordata order
   int s_body[JNSENS], s_type[JNSENS], s_origbody[JNSENS];
   float s_pos[JNSENS][3], s_mat[JNSENS][9], s_size[JNSENS][3];
-  unsigned sens_bodymask[2];   // bit b (of 64): original body b carries a touch site (contacts elsewhere cannot reach a sensor)
+  unsigned sens_bodymask[4];   // bit b (of 128): original body b carries a touch site (contacts elsewhere cannot reach a sensor)
 
   // named frames the task layer reads: body id + local pos + local rotation
   int ee_body, eeobj_body;

@@ -454,6 +454,12 @@ __global__ void jaco_prepare_kernel(int* ctl, int* lists, int n, int wm, int wh,
 
 static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t st, float* dbg, int dbg_env, const EnvIO& io = EnvIO()) {
   if ((!ctrl && io.mode == 0) || nsub <= 0) { h->err = "jaco_physics_step: bad arguments"; return JACO_EINVAL; }
+#if JNV > 21
+  // the two-arm layout serves the sim-interface tier (jaco_physics_step and the state accessors).  The env tier is one arm's task layer; the
+  // reference's own env loop is single-robot too (_step_simulation stacks ONE gripper command onto the controller output,
+  // env_mujoco_util.py:73-83: 15 values for the dual model's 18 controls)
+  if (io.mode != 0) { h->err = "this build of the library (two-arm layout) steps models at the ctrl level only: jaco_physics_step / jaco_get_state / jaco_set_state"; return JACO_EINVAL; }
+#endif
   ENTER(h);
   JacoStepArgs A{};
   A.model = h->model_dev; A.hull = h->hull_dev; A.qpos = h->qpos; A.qvel = h->qvel; A.qacc_ws = h->qacc_ws; A.qpos_lo = h->qpos_lo; A.qvel_lo = h->qvel_lo;

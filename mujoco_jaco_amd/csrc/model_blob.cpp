@@ -235,7 +235,7 @@ int jaco_model_from_blob(const void* buf, size_t size, JacoModelDev* m, std::vec
   if (!sb || !sty || !sob || !sp || !sq || !ssz) FAIL(B.err);
   for (int s = 0; s < ns; s++) {
     m->s_body[s] = sb[s]; m->s_type[s] = sty[s]; m->s_origbody[s] = sob[s];
-    if (sob[s] < 0 || sob[s] >= 64) FAIL("touch site on a body id outside [0, 64)");
+    if (sob[s] < 0 || sob[s] >= 128) FAIL("touch site on a body id outside [0, 128)");
     m->sens_bodymask[sob[s] >> 5] |= 1u << (sob[s] & 31);
     cp3(m->s_pos[s], sp + 3 * s); quat2mat(sq + 4 * s, m->s_mat[s]); cp3(m->s_size[s], ssz + 3 * s);
   }

@@ -26,13 +26,13 @@
 template <int MAXEFC_, int MAXCON_, int MAXCAND_, bool CONTACT_ = true>
 struct JacoCaps {
   static_assert(MAXEFC_ % 64 == 0, "rows are dealt out 64 at a time (one per lane): the row capacity must be a multiple of 64");
-  static_assert(MAXCAND_ <= MAXEFC_ * 25 - 520 - 256 - 576, "the candidate list must fit behind the geom poses in the constraint-row area");
+  static_assert(JMAXGEOM != 64 || JNV != 21 || MAXCAND_ <= MAXEFC_ * 25 - 520 - 256 - 576, "default layout: the candidate list must fit behind the geom poses in the constraint-row area");
   static constexpr int MAXEFC = MAXEFC_, MAXCON = MAXCON_, MAXCAND = MAXCAND_, NR = MAXEFC_ / 64;
   // CONTACT = false: the contact-free instantiation (arm-only models, option disable_contact): no geom poses, no contact list, and
   // Jacobian storage for the joint-limit rows only (at most one per body)
   static constexpr bool CONTACT = CONTACT_;
-  static constexpr int JROWS = CONTACT_ ? MAXEFC_ : 16, NGEOM = CONTACT_ ? JMAXGEOM : 1;
-  static_assert(CONTACT_ || JNB <= 16, "limit rows of the contact-free instantiation");
+  static constexpr int JROWS = CONTACT_ ? MAXEFC_ : (JNB <= 16 ? 16 : 32), NGEOM = CONTACT_ ? JMAXGEOM : 1;
+  static_assert(CONTACT_ || JNB <= 32, "limit rows of the contact-free instantiation");
 };
 // Candidates = bounding-sphere survivors (closed fingers alone contribute > 64; with the EE sticks on the marker's sticks 130-200): their
 // list shares LDS with the constraint rows, which are bigger, so its capacity costs nothing -- and it must not be what sends
@@ -184,7 +184,17 @@ JDEV const JacoStepArgs* args_view(const JacoStepArgs&) {
 JDEV int m_index(int d, int j) {   // (d, j in the same block)
   return d < JB0 ? d * JB0 + j : (d < JB1 ? JB0 * JB0 + (d - JB0) * (JB1 - JB0) + (j - JB0) : JB0 * JB0 + (JB1 - JB0) * (JB1 - JB0) + (d - JB1) * (JNV - JB1) + (j - JB1));
 }
-#define JSCRATCH 520   // floats of the constraint-row area that the early stages of a substep use as scratch (stage_walk, stage_mass_bias, stage_osc)
+// Floats of the constraint-row area that the early stages of a substep use as scratch (stage_walk, stage_mass_bias, stage_osc): S_d qvel_d and
+// S_d-dot qvel_d ([JNV][6] each) from its start, the frame records of the tree walk ([JNB + 2][16]) from JTB_OFF.
+#define JTB_OFF (12 * JNV > 256 ? 12 * JNV : 256)
+#define JSCRATCH (JTB_OFF + 16 * (JNB + 2) > 520 ? JTB_OFF + 16 * (JNB + 2) : 520)
+// state rows in LDS (sizes of the default layout are the floor: 24 / 24 / 12)
+#define JQ_LDS (JNQ + 1 > 24 ? JNQ + 1 : 24)
+#define JV_LDS (JNV + 3 > 24 ? JNV + 3 : 24)
+#define JU_LDS (JNU + 3 > 12 ? JNU + 3 : 12)
+// 64-lane passes of the frame-column lanes (4 per body + the two markers) and of the geom lanes
+#define JFRAME_PASSES ((4 * (JNB + 2) + 63) / 64)
+#define JGEOM_PASSES (JMAXGEOM / 64)
 
 // Per-env working state.  LDS is what caps the number of resident envs per CU (160 KB / sizeof), so arrays whose lifetimes inside
 // a substep do not overlap share storage:
@@ -195,13 +205,13 @@ JDEV int m_index(int d, int j) {   // (d, j in the same block)
 template <class C>
 struct JacoLDS {
   typedef C Caps;
-  float qpos[24], qvel[24], qacc_ws[24], ctrl[12];
-  float qpos_lo[24], qvel_lo[24];               // compensated state: what every stage reads is the fp32 rounding (qpos, qvel) of hi + lo
+  float qpos[JQ_LDS], qvel[JV_LDS], qacc_ws[JV_LDS], ctrl[JU_LDS];
+  float qpos_lo[JQ_LDS], qvel_lo[JV_LDS];       // compensated state: what every stage reads is the fp32 rounding (qpos, qvel) of hi + lo
   float xpos[JNB][3], xmat[JNB][9];
   float cdof[JNV][6];
   float cvel[JNB][6];
   float M[JMBLK];
-  float bias[24], smooth[72];                   // smooth[0..nv); the light tier also stages its <= 64 row residuals here (MFMA pass)
+  float bias[JV_LDS], smooth[72];               // smooth[0..nv); the light tier also stages its <= 64 row residuals here (MFMA pass)
   float mk[24];                                 // poses of the two task-layer markers ("hand", "subgoal_reach") during this launch
   union {
     struct {                                    // tree walk .. mass matrix
@@ -246,9 +256,8 @@ struct JacoLDS {
     int q_dof[JNQ + 1];                         // dof that advances position coordinate q linearly (hinge angle, free-body translation), -1: quaternion component
   } mc;
 };
-static_assert(6 * JMAXINNER <= 64, "subtree force sums: one lane per (inner body, component)");
-static_assert((JB1 - JB0 == 6 || JB1 == JB0) && (JNV - JB1 == 6 || JNV == JB1) && JB0 >= 6 && JNV <= 21 && JNV - JB0 <= 15,
-              "dof blocks: one arm tree of at least the six arm joints, then zero, one or two free bodies");
+static_assert((JB1 - JB0 == 6 || JB1 == JB0) && (JNV - JB1 == 6 || JNV == JB1) && JB0 >= 6 && JNV <= 31 && JNV - JB0 <= 15 && JNV <= 64,
+              "dof blocks: the arm tree(s) of at least the six arm joints, then zero, one or two free bodies; dofs + the residual column fit the 32-column matrix-core tile");
 
 template <class L>
 JDEV void stage_model(const JacoModelDev* m, L& s, int lane) {
@@ -578,7 +587,8 @@ JDEV v3 chain_sum3(const float* T, unsigned mask) {   // one half (3 components)
   for (int k = 0; k < JMAXCHAIN; k++) if (on[k]) v = v + t[k];
   return v;
 }
-static_assert(4 * (JNB + 2) <= 64 && 256 + 16 * (JNB + 2) <= JSCRATCH && 16 * JNB <= 20 * JNB, "frame records: one lane per column, scratch sizes");
+static_assert(JTB_OFF % 4 == 0 && JTB_OFF + 16 * (JNB + 2) <= JSCRATCH && 16 * JNB <= 20 * JNB && JNB <= 64, "frame records: scratch sizes, one lane per body");
+// (every per-slot loop below runs JFRAME_PASSES / JGEOM_PASSES times: once in the default layout -- slot = lane -- where it unrolls to straight-line code)
 template <class L>
 JDEV void stage_walk(const JacoModelDev* m, L& s, int lane, bool markers, JProfCtx* wpc = nullptr) {
 #ifdef JACO_WALK_PROFILE   // diagnostic: split this stage over profile slots 9..14 (their usual owners are wrong in such a build)
@@ -589,130 +599,178 @@ JDEV void stage_walk(const JacoModelDev* m, L& s, int lane, bool markers, JProfC
   (void)wpc;
   const int nb = m->nbody, nv = m->nv;
   float* TA = &s.cinert[0][0];   // [JNB][16] frame records, ping  (cinert+crb are contiguous: 2 * JNB * 10 floats)
-  float* TB = s.J + 256;         // [JNB + 2][16] frame records, pong  (the first JSCRATCH floats of the constraint-row area are free at this point)
+  float* TB = s.J + JTB_OFF;     // [JNB + 2][16] frame records, pong  (the first JSCRATCH floats of the constraint-row area are free at this point)
   float* Sq = s.J;               // [JNV][6] S_d * qvel_d
   float* Sq2 = s.J + JNV * 6;    // [JNV][6] S_d-dot * qvel_d
-  const int fb = lane >> 2, fc = lane & 3;
-  const bool isf = fb < nb;                            // frame lane: column fc of body fb
-  const bool ismk = markers && fb >= nb && fb < nb + 2;   // ... of marker fb - nb
-  const int b = isf ? fb : 0;
   const bool isb = lane < nb;
-  const int jt = s.mc.b_jtype[b], qa = s.mc.b_qadr[b];
-  const int a1 = s.mc.b_anc[b][0], a2 = s.mc.b_anc[b][1], a4 = s.mc.b_anc[b][2];
-  const unsigned chain = isf ? m->b_chainmask[b] : 0u;             // dofs that move body fb
-  const unsigned chainb = isb ? m->b_chainmask[isb ? lane : 0] : 0u;   // ... body `lane`
-  const float q0lo = m->b_qpos0_lo[b];
-  // Model constants of the later phases, issued now: their L2 latency overlaps the frame composition below instead of being paid
-  // right before their use (nothing may cross the wave_sync fences on its own).
-  float Imod[6];
-#pragma unroll
-  for (int k = 0; k < 6; k++) Imod[k] = m->b_inertia[b][k];
-  const float mass = m->b_mass[b];
+  const unsigned chainb = isb ? m->b_chainmask[isb ? lane : 0] : 0u;   // dofs that move body `lane`
   constexpr bool GEOMS = L::Caps::CONTACT;   // (the contact-free instantiation has no use for geom poses)
-  const bool isg = GEOMS && lane < m->ngeom;
-  const int gl = isg ? lane : 0;
-  int gb = -1, km = -1;
-  float grb = 0.f;
-  v3 gp0 = mk3(0.f, 0.f, 0.f);
-  m3 gR0;
-  if (GEOMS) {
-    gb = m->g_body[gl]; km = markers ? m->g_marker[gl] : -1;
-    grb = m->g_rbound[gl];
-    const bool onmk = km >= 0 && gb < 0;
-    gp0 = ld3(onmk ? m->g_lpos[gl] : m->g_pos[gl]);
-    gR0 = ldm(onmk ? m->g_lmat[gl] : m->g_mat[gl]);
+  // per frame slot (pass p: slot 64 p + lane = column fc of body fb)
+  int fbA[JFRAME_PASSES], fcA[JFRAME_PASSES], bA[JFRAME_PASSES], jtA[JFRAME_PASSES], qaA[JFRAME_PASSES], a1A[JFRAME_PASSES], a2A[JFRAME_PASSES], a4A[JFRAME_PASSES];
+  bool isfA[JFRAME_PASSES], ismkA[JFRAME_PASSES];
+  unsigned chainA[JFRAME_PASSES];
+  float q0loA[JFRAME_PASSES], massA[JFRAME_PASSES], ImodA[JFRAME_PASSES][6];
+  v3 vA[JFRAME_PASSES];   // my column
+#pragma unroll
+  for (int p = 0; p < JFRAME_PASSES; p++) {
+    const int slot = 64 * p + lane;
+    const int fb = slot >> 2, fc = slot & 3;
+    const bool isf = fb < nb;                            // frame lane: column fc of body fb
+    const bool ismk = markers && fb >= nb && fb < nb + 2;   // ... of marker fb - nb
+    const int b = isf ? fb : 0;
+    fbA[p] = fb; fcA[p] = fc; isfA[p] = isf; ismkA[p] = ismk; bA[p] = b;
+    jtA[p] = s.mc.b_jtype[b]; qaA[p] = s.mc.b_qadr[b];
+    a1A[p] = s.mc.b_anc[b][0]; a2A[p] = s.mc.b_anc[b][1]; a4A[p] = s.mc.b_anc[b][2];
+    chainA[p] = isf ? m->b_chainmask[b] : 0u;             // dofs that move body fb
+    q0loA[p] = m->b_qpos0_lo[b];
+    // Model constants of the later phases, issued now: their L2 latency overlaps the frame composition below instead of being paid
+    // right before their use (nothing may cross the wave_sync fences on its own).
+#pragma unroll
+    for (int k = 0; k < 6; k++) ImodA[p][k] = m->b_inertia[b][k];
+    massA[p] = m->b_mass[b];
+    vA[p] = mk3(0.f, 0.f, 0.f);
   }
-  v3 v = mk3(0.f, 0.f, 0.f);   // my column
-  if (isf) {
-    if (jt == JJ_HINGE) {
-      // joint angle relative to the reference, from the compensated state: hi part q - q0 with its exact rounding error (two-sum),
-      // low part = state's low part - reference's low part (ref 3.14: 1.05e-7 off its float) + that error
-      const float q = s.qpos[qa], q0 = s.mc.b_qpos0[b];
-      const float ah = q - q0, bb = ah - q;
-      const float al = ((q - (ah - bb)) + (-q0 - bb)) + (s.qpos_lo[qa] - q0lo);
-      const m3 Rj = axis_rot(ld3(s.mc.b_axis[b]), ah, al);
-      const v3 rc = fc == 0 ? col(Rj, 0) : (fc == 1 ? col(Rj, 1) : col(Rj, 2));
-      v = fc == 3 ? ld3(s.mc.b_pos[b]) : mul(ldm(s.mc.b_mat[b]), rc);
-    } else {
-      float w = s.qpos[qa + 3], x = s.qpos[qa + 4], y = s.qpos[qa + 5], z = s.qpos[qa + 6];
-      float n = sqrtf(w * w + x * x + y * y + z * z);
-      if (n < JMINVAL) { w = 1.f; x = y = z = 0.f; } else { float in = 1.f / n; w *= in; x *= in; y *= in; z *= in; }
-      const m3 R = quat2mat(w, x, y, z);
-      v = fc == 0 ? col(R, 0) : (fc == 1 ? col(R, 1) : (fc == 2 ? col(R, 2) : ld3(&s.qpos[qa])));
+  // per geom slot
+  bool isgA[JGEOM_PASSES];
+  int gbA[JGEOM_PASSES], kmA[JGEOM_PASSES];
+  float grbA[JGEOM_PASSES];
+  v3 gp0A[JGEOM_PASSES];
+  m3 gR0A[JGEOM_PASSES];
+#pragma unroll
+  for (int p = 0; p < JGEOM_PASSES; p++) {
+    const int g = 64 * p + lane;
+    isgA[p] = GEOMS && g < m->ngeom;
+    const int gl = isgA[p] ? g : 0;
+    gbA[p] = -1; kmA[p] = -1; grbA[p] = 0.f; gp0A[p] = mk3(0.f, 0.f, 0.f);
+    if (GEOMS) {
+      gbA[p] = m->g_body[gl]; kmA[p] = markers ? m->g_marker[gl] : -1;
+      grbA[p] = m->g_rbound[gl];
+      const bool onmk = kmA[p] >= 0 && gbA[p] < 0;
+      gp0A[p] = ld3(onmk ? m->g_lpos[gl] : m->g_pos[gl]);
+      gR0A[p] = ldm(onmk ? m->g_lmat[gl] : m->g_mat[gl]);
     }
-    st_col(TA + 4 * lane, v);
+  }
+#pragma unroll
+  for (int p = 0; p < JFRAME_PASSES; p++) {
+    if (isfA[p]) {
+      const int b = bA[p], fc = fcA[p], qa = qaA[p];
+      v3 v;
+      if (jtA[p] == JJ_HINGE) {
+        // joint angle relative to the reference, from the compensated state: hi part q - q0 with its exact rounding error (two-sum),
+        // low part = state's low part - reference's low part (ref 3.14: 1.05e-7 off its float) + that error
+        const float q = s.qpos[qa], q0 = s.mc.b_qpos0[b];
+        const float ah = q - q0, bb = ah - q;
+        const float al = ((q - (ah - bb)) + (-q0 - bb)) + (s.qpos_lo[qa] - q0loA[p]);
+        const m3 Rj = axis_rot(ld3(s.mc.b_axis[b]), ah, al);
+        const v3 rc = fc == 0 ? col(Rj, 0) : (fc == 1 ? col(Rj, 1) : col(Rj, 2));
+        v = fc == 3 ? ld3(s.mc.b_pos[b]) : mul(ldm(s.mc.b_mat[b]), rc);
+      } else {
+        float w = s.qpos[qa + 3], x = s.qpos[qa + 4], y = s.qpos[qa + 5], z = s.qpos[qa + 6];
+        float n = sqrtf(w * w + x * x + y * y + z * z);
+        if (n < JMINVAL) { w = 1.f; x = y = z = 0.f; } else { float in = 1.f / n; w *= in; x *= in; y *= in; z *= in; }
+        const m3 R = quat2mat(w, x, y, z);
+        v = fc == 0 ? col(R, 0) : (fc == 1 ? col(R, 1) : (fc == 2 ? col(R, 2) : ld3(&s.qpos[qa])));
+      }
+      vA[p] = v;
+      st_col(TA + 4 * (64 * p + lane), v);
+    }
   }
   wave_sync();
   JWSTAMP(9);
-  if (isf) {
-    if (a1 >= 0) { v3 c0, c1, c2, pp; ld_cols(TA + 16 * a1, c0, c1, c2, pp); v = mul_cols(c0, c1, c2, v); if (fc == 3) v = pp + v; }
-    st_col(TB + 4 * lane, v);
+#pragma unroll
+  for (int p = 0; p < JFRAME_PASSES; p++) {
+    if (isfA[p]) {
+      v3 v = vA[p];
+      if (a1A[p] >= 0) { v3 c0, c1, c2, pp; ld_cols(TA + 16 * a1A[p], c0, c1, c2, pp); v = mul_cols(c0, c1, c2, v); if (fcA[p] == 3) v = pp + v; }
+      vA[p] = v;
+      st_col(TB + 4 * (64 * p + lane), v);
+    }
   }
   wave_sync();
-  if (isf) {
-    if (a2 >= 0) { v3 c0, c1, c2, pp; ld_cols(TB + 16 * a2, c0, c1, c2, pp); v = mul_cols(c0, c1, c2, v); if (fc == 3) v = pp + v; }
-    st_col(TA + 4 * lane, v);
+#pragma unroll
+  for (int p = 0; p < JFRAME_PASSES; p++) {
+    if (isfA[p]) {
+      v3 v = vA[p];
+      if (a2A[p] >= 0) { v3 c0, c1, c2, pp; ld_cols(TB + 16 * a2A[p], c0, c1, c2, pp); v = mul_cols(c0, c1, c2, v); if (fcA[p] == 3) v = pp + v; }
+      vA[p] = v;
+      st_col(TA + 4 * (64 * p + lane), v);
+    }
   }
   wave_sync();
-  if (isf) {
-    if (a4 >= 0) { v3 c0, c1, c2, pp; ld_cols(TA + 16 * a4, c0, c1, c2, pp); v = mul_cols(c0, c1, c2, v); if (fc == 3) v = pp + v; }
-    st_col(TB + 4 * lane, v);
-    if (fc == 3) st3(s.xpos[b], v);
-    else { s.xmat[b][fc] = v.x; s.xmat[b][3 + fc] = v.y; s.xmat[b][6 + fc] = v.z; }
-  } else if (ismk) {   // marker frames as records nb, nb + 1 (set_mocap_xyz / set_mocap_orientation between env steps): one path for the geoms below
-    const float* P = s.mk + 12 * (fb - nb);
-    st_col(TB + 4 * lane, fc == 3 ? ld3(P) : mk3(P[3 + fc], P[6 + fc], P[9 + fc]));
+#pragma unroll
+  for (int p = 0; p < JFRAME_PASSES; p++) {
+    if (isfA[p]) {
+      const int b = bA[p], fc = fcA[p];
+      v3 v = vA[p];
+      if (a4A[p] >= 0) { v3 c0, c1, c2, pp; ld_cols(TA + 16 * a4A[p], c0, c1, c2, pp); v = mul_cols(c0, c1, c2, v); if (fc == 3) v = pp + v; }
+      st_col(TB + 4 * (64 * p + lane), v);
+      if (fc == 3) st3(s.xpos[b], v);
+      else { s.xmat[b][fc] = v.x; s.xmat[b][3 + fc] = v.y; s.xmat[b][6 + fc] = v.z; }
+    } else if (ismkA[p]) {   // marker frames as records nb, nb + 1 (set_mocap_xyz / set_mocap_orientation between env steps): one path for the geoms below
+      const float* P = s.mk + 12 * (fbA[p] - nb);
+      const int fc = fcA[p];
+      st_col(TB + 4 * (64 * p + lane), fc == 3 ? ld3(P) : mk3(P[3 + fc], P[6 + fc], P[9 + fc]));
+    }
   }
   wave_sync();   // the frame scratch TA (= cinert / crb) is dead from here on; TB holds the world frames
   JWSTAMP(10);
   // one interval for everything that only needs the body frames: inertias, moving geom poses, S_d
-  if (isf) {
-    v3 c0, c1, c2, pos;
-    ld_cols(TB + 16 * b, c0, c1, c2, pos);
-    const v3 c = pos + mul_cols(c0, c1, c2, ld3(s.mc.b_com[b]));
-    if (fc == 3) {   // [m, m c]
-      s.cinert[b][0] = mass; s.crb[b][0] = mass;
-      const v3 mc_ = mk3(mass * c.x, mass * c.y, mass * c.z);
-      st3(&s.cinert[b][1], mc_); st3(&s.crb[b][1], mc_);
-    } else {
-      // row i = fc of I_w = R I R^T (T = R I first, as a matrix product would), shifted to the world origin
-      const float* I = Imod;
-      const v3 Ri = fc == 0 ? mk3(c0.x, c1.x, c2.x) : (fc == 1 ? mk3(c0.y, c1.y, c2.y) : mk3(c0.z, c1.z, c2.z));
-      const v3 Ti = mk3(Ri.x * I[0] + Ri.y * I[3] + Ri.z * I[4], Ri.x * I[3] + Ri.y * I[1] + Ri.z * I[5], Ri.x * I[4] + Ri.y * I[5] + Ri.z * I[2]);
-      const float w0 = Ti.x * c0.x + Ti.y * c1.x + Ti.z * c2.x;   // I_w[i][0]
-      const float w1 = Ti.x * c0.y + Ti.y * c1.y + Ti.z * c2.y;   // I_w[i][1]
-      const float w2 = Ti.x * c0.z + Ti.y * c1.z + Ti.z * c2.z;   // I_w[i][2]
-      const float cc = dot(c, c);
-      if (fc == 0) {
-        const float d = w0 + mass * (cc - c.x * c.x), o1 = w1 - mass * c.x * c.y, o2 = w2 - mass * c.x * c.z;
-        s.cinert[b][4] = d; s.cinert[b][7] = o1; s.cinert[b][8] = o2;
-        s.crb[b][4] = d; s.crb[b][7] = o1; s.crb[b][8] = o2;
-      } else if (fc == 1) {
-        const float d = w1 + mass * (cc - c.y * c.y), o = w2 - mass * c.y * c.z;
-        s.cinert[b][5] = d; s.cinert[b][9] = o;
-        s.crb[b][5] = d; s.crb[b][9] = o;
+#pragma unroll
+  for (int p = 0; p < JFRAME_PASSES; p++) {
+    if (isfA[p]) {
+      const int b = bA[p], fc = fcA[p];
+      const float mass = massA[p];
+      v3 c0, c1, c2, pos;
+      ld_cols(TB + 16 * b, c0, c1, c2, pos);
+      const v3 c = pos + mul_cols(c0, c1, c2, ld3(s.mc.b_com[b]));
+      if (fc == 3) {   // [m, m c]
+        s.cinert[b][0] = mass; s.crb[b][0] = mass;
+        const v3 mc_ = mk3(mass * c.x, mass * c.y, mass * c.z);
+        st3(&s.cinert[b][1], mc_); st3(&s.crb[b][1], mc_);
       } else {
-        const float d = w2 + mass * (cc - c.z * c.z);
-        s.cinert[b][6] = d; s.crb[b][6] = d;
+        // row i = fc of I_w = R I R^T (T = R I first, as a matrix product would), shifted to the world origin
+        const float* I = ImodA[p];
+        const v3 Ri = fc == 0 ? mk3(c0.x, c1.x, c2.x) : (fc == 1 ? mk3(c0.y, c1.y, c2.y) : mk3(c0.z, c1.z, c2.z));
+        const v3 Ti = mk3(Ri.x * I[0] + Ri.y * I[3] + Ri.z * I[4], Ri.x * I[3] + Ri.y * I[1] + Ri.z * I[5], Ri.x * I[4] + Ri.y * I[5] + Ri.z * I[2]);
+        const float w0 = Ti.x * c0.x + Ti.y * c1.x + Ti.z * c2.x;   // I_w[i][0]
+        const float w1 = Ti.x * c0.y + Ti.y * c1.y + Ti.z * c2.y;   // I_w[i][1]
+        const float w2 = Ti.x * c0.z + Ti.y * c1.z + Ti.z * c2.z;   // I_w[i][2]
+        const float cc = dot(c, c);
+        if (fc == 0) {
+          const float d = w0 + mass * (cc - c.x * c.x), o1 = w1 - mass * c.x * c.y, o2 = w2 - mass * c.x * c.z;
+          s.cinert[b][4] = d; s.cinert[b][7] = o1; s.cinert[b][8] = o2;
+          s.crb[b][4] = d; s.crb[b][7] = o1; s.crb[b][8] = o2;
+        } else if (fc == 1) {
+          const float d = w1 + mass * (cc - c.y * c.y), o = w2 - mass * c.y * c.z;
+          s.cinert[b][5] = d; s.cinert[b][9] = o;
+          s.crb[b][5] = d; s.crb[b][9] = o;
+        } else {
+          const float d = w2 + mass * (cc - c.z * c.z);
+          s.cinert[b][6] = d; s.crb[b][6] = d;
+        }
       }
     }
   }
-  if (GEOMS && isg) {   // geom poses (they share LDS with the constraint rows: every substep writes all of them)
-    v3 gp = gp0; m3 gR = gR0;   // static: world pose from the model
-    const int src = gb >= 0 ? gb : (km >= 0 ? nb + km : -1);   // rides on a moving body / on one of the two task-layer markers
-    if (src >= 0) {
-      v3 c0, c1, c2, pos;
-      ld_cols(TB + 16 * src, c0, c1, c2, pos);
-      gp = pos + mul_cols(c0, c1, c2, gp0);
 #pragma unroll
-      for (int j = 0; j < 3; j++) {
-        const v3 gc = mul_cols(c0, c1, c2, col(gR0, j));
-        gR.m[j] = gc.x; gR.m[3 + j] = gc.y; gR.m[6 + j] = gc.z;
+  for (int p = 0; p < JGEOM_PASSES; p++) {
+    if (GEOMS && isgA[p]) {   // geom poses (they share LDS with the constraint rows: every substep writes all of them)
+      const int g = 64 * p + lane;
+      v3 gp = gp0A[p]; m3 gR = gR0A[p];   // static: world pose from the model
+      const int src = gbA[p] >= 0 ? gbA[p] : (kmA[p] >= 0 ? nb + kmA[p] : -1);   // rides on a moving body / on one of the two task-layer markers
+      if (src >= 0) {
+        v3 c0, c1, c2, pos;
+        ld_cols(TB + 16 * src, c0, c1, c2, pos);
+        gp = pos + mul_cols(c0, c1, c2, gp0A[p]);
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+          const v3 gc = mul_cols(c0, c1, c2, col(gR0A[p], j));
+          gR.m[j] = gc.x; gR.m[3 + j] = gc.y; gR.m[6 + j] = gc.z;
+        }
       }
+      st3(s.gpos[g], gp);
+      s.gpos[g][3] = grbA[p];
+      stm(s.gmat[g], gR);
     }
-    st3(s.gpos[lane], gp);
-    s.gpos[lane][3] = grb;
-    stm(s.gmat[lane], gR);
   }
   if (lane < nv) {   // S_d: hinge -> world axis through the body origin; free joint -> 3 world translations, 3 body-frame rotations
     const int d = lane, bd = s.mc.d_body[d], k = d - s.mc.b_dadr[bd];
@@ -729,8 +787,11 @@ JDEV void stage_walk(const JacoModelDev* m, L& s, int lane, bool markers, JProfC
   }
   wave_sync();
   JWSTAMP(11);
-  if (isf && fc < 2) {   // body velocity: sum of S_d qvel_d over the dofs that move the body (own + all ancestors'), straight from the mask
-    st3(s.cvel[b] + 3 * fc, chain_sum3(Sq + 3 * fc, chain));
+#pragma unroll
+  for (int p = 0; p < JFRAME_PASSES; p++) {
+    if (isfA[p] && fcA[p] < 2) {   // body velocity: sum of S_d qvel_d over the dofs that move the body (own + all ancestors'), straight from the mask
+      st3(s.cvel[bA[p]] + 3 * fcA[p], chain_sum3(Sq + 3 * fcA[p], chainA[p]));
+    }
   }
   wave_sync();
   JWSTAMP(12);
@@ -792,23 +853,28 @@ JDEV void stage_accumulate(const JacoModelDev* m, L& s, int lane) {
       s.crb[a][c] = subtree_sum(&s.cinert[0][0] + c, 10, s.mc.b_descmask[a]);
     }
   }
-  if (lane < 6 * ni) {   // (6 x JMAXINNER <= 64 in every layout)
-    const int a = s.mc.inner_body[lane / 6], c = lane % 6;
-    s.cacc[a][c] = subtree_sum(&s.cfrc[0][0] + c, 6, s.mc.b_descmask[a]);
+#pragma unroll
+  for (int base = 0; base < 6 * JMAXINNER; base += 64) {   // (one pass in the default layout: 6 x 6 <= 64)
+    const int i = base + lane;
+    if (i < 6 * ni) {
+      const int a = s.mc.inner_body[i / 6], c = i % 6;
+      s.cacc[a][c] = subtree_sum(&s.cfrc[0][0] + c, 6, s.mc.b_descmask[a]);
+    }
   }
 }
 
 // Per-lane model constants of the stages after the tree walk, fetched in one go right after it: their L2 round trip is hidden
 // behind the subtree sums and the mass matrix instead of being paid, one dependent load at a time, in front of every stage.
 struct StagePrefetch {
-  int mp0, mp1;               // stage M: this lane's mass-matrix entries
+  int mp[JMAXMPAIR / 64];     // stage M: this lane's mass-matrix entries
   float damping;              // joint damping of dof `lane`
   float stiffness, springref; int sqadr;   // joint spring of dof `lane` (models that have any)
   int limited; float lo, hi;  // joint limit of body `lane`
 };
 JDEV StagePrefetch stage_prefetch(const JacoModelDev* m, int lane) {
   StagePrefetch P;
-  P.mp0 = m->mpair[lane]; P.mp1 = m->mpair[64 + lane];                                     // (zero-padded to JMAXMPAIR)
+#pragma unroll
+  for (int h = 0; h < JMAXMPAIR / 64; h++) P.mp[h] = m->mpair[64 * h + lane];             // (zero-padded to JMAXMPAIR)
   P.damping = m->d_damping[lane < JNV ? lane : 0];
   P.stiffness = 0.f; P.springref = 0.f; P.sqadr = 0;
   if (m->has_springs) { P.stiffness = m->d_stiffness[lane < JNV ? lane : 0]; P.springref = m->d_springref[lane < JNV ? lane : 0]; P.sqadr = m->d_qadr[lane < JNV ? lane : 0]; }
@@ -823,7 +889,6 @@ template <class L>
 JDEV void stage_mass_bias(const JacoModelDev* m, L& s, int lane, const StagePrefetch& pf) {
   float* Fd = s.J;   // [JNV][6]
   const int nmp = m->nmpair;
-  int code0 = pf.mp0, code1 = pf.mp1;
   if (lane < m->nv) {
     int d = lane, b = s.mc.d_body[d];
     sv S = ldsv(s.cdof[d]);
@@ -837,7 +902,7 @@ JDEV void stage_mass_bias(const JacoModelDev* m, L& s, int lane, const StagePref
   wave_sync();
 #pragma unroll
   for (int h = 0; h < JMAXMPAIR / 64; h++) {
-    int code = h == 0 ? code0 : code1;
+    int code = pf.mp[h];
     if (h * 64 + lane < nmp) {
       int d = code & 255, j = code >> 8;
       float v = dot(ldsv(s.cdof[j]), ldsv(Fd + 6 * d));

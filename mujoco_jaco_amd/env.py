@@ -52,13 +52,19 @@ class JacoBatchedEnv:
             raise NotImplementedError("subgoal_obs=True: the reference's own observation assert (23 != 26 entries) rejects this branch")
         self.rulebased_subgoal = bool(kwargs.get("rulebased_subgoal", True))
         self.n_robots = kwargs.get("n_robots", 1)
-        if self.n_robots != 1:
-            raise NotImplementedError("n_robots != 1")
-        robot_file = kwargs.get("robot_file", "jaco2_curtain_torque") or "jaco2_curtain_torque"
+        if self.n_robots not in (1, 2):
+            raise NotImplementedError("n_robots = %r: the reference ships models for one and two arms" % (self.n_robots,))
+        # robot_file=None picks 'jaco2' + ['', '_dual', '_tri'][n_robots - 1] in the reference (env_mujoco_util.py:19-28), files its assets
+        # directory does not hold; the shipped two-arm model is jaco2_dual_torque.xml
+        robot_file = kwargs.get("robot_file", None) or ("jaco2_curtain_torque" if self.n_robots == 1 else "jaco2_dual_torque")
         self.num_envs = int(num_envs)
         self.sim = BatchedMujoco(self.num_envs, robot_file=robot_file, device=device, frame_skip=frame_skip,
                                  task=TASK_IDS[self.task], seed=int(seed))
         self.L, self.h, self.device = self.sim.L, self.sim.h, self.sim.device
+        # Two arms: the sim tier (self.sim: send_forces / get_state / set_state on the two-arm build of the library) is what exists.  The
+        # reference's env loop is single-robot as well -- _step_simulation stacks one gripper command onto the controller output
+        # (env_mujoco_util.py:73-83: 15 values for the dual model's 18 controls) -- so reset() / step() have no working reference to follow.
+        self.sim_tier_only = self.n_robots != 1
         if not self.rulebased_subgoal:
             self.sim.set_option("obs_mode", 1)
         # auto_reset=True (batched rollouts): an env whose step ends its episode is reset inside that very jaco_step call -- sim.reset(),
@@ -79,13 +85,13 @@ class JacoBatchedEnv:
         self.max_steps = 2500
         self.task_max_steps = 700 if self.task in ("picking", "placing") else (1200 if self.task == "pickAndplace" else 500)   # env_mujoco.py:18-23
         self.skip_frames = int(frame_skip)
-        obs_max = np.hstack([[3], [1] * 25]).astype(np.float32)
+        obs_max = np.hstack([[3], [1] * 25]).astype(np.float32).repeat(self.n_robots)   # (.repeat(n_robots), env_mujoco.py:57-58)
         self.observation_space = Box(-obs_max, obs_max, dtype=np.float32)
         self.state_shape = self.observation_space.shape[0]
         self.pose_action_space_max = 1
         nact = 6 if self.task in ("reaching", "pushing") else 7   # env_mujoco.py:79-89
-        self.act_max = np.ones(nact)
-        self.act_min = -np.ones(nact)
+        self.act_max = np.ones(nact).repeat(self.n_robots)      # env_mujoco.py:86-88
+        self.act_min = -np.ones(nact).repeat(self.n_robots)
         self.action_space = Box(self.act_min, self.act_max, dtype=np.float32)
         self.wb = 0
         self.metadata = None
@@ -117,7 +123,13 @@ class JacoBatchedEnv:
             self.sim._chk(self.L.jaco_set_noise(self.h, self._p(self._noise)))
 
     # ---- reference surface
+    def _env_tier(self):
+        if self.sim_tier_only:
+            raise NotImplementedError("n_robots = 2: the two-arm model is stepped at the sim-interface tier (env.sim.send_forces / get_state / "
+                                      "set_state); the reference's env loop (env_mujoco_util.py:73-83) drives one arm")
+
     def reset(self, mask=None):
+        self._env_tier()
         self.current_steps = 0
         m = self._mask(mask)
         self.sim._chk(self.L.jaco_reset(self.h, self._p(m) if m is not None else None, self._p(self._obs), self.sim._stream()))
@@ -196,6 +208,7 @@ class JacoBatchedEnv:
     def step(self, action, weight=None, subgoal=None, id=None):
         """env_mujoco.py:116-139.  With num_envs > 1 the returned obs / reward / done tensors are the handle's own output buffers (done: a
         bool view of the kernel's byte flags): valid until the next step() / reset() call, `.clone()` what has to outlive it."""
+        self._env_tier()
         a = self._action(action)
         self._set_subgoal(subgoal)
         self.sim._chk(self.L.jaco_step(self.h, self._p(a), self._p(self._obs), self._p(self._rew), self._p(self._done), self.sim._stream()))

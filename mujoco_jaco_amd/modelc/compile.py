@@ -317,8 +317,9 @@ def compile_model(xml_name, timestep=0.001):
 
 def main():
     os.makedirs(OUT_DIR, exist_ok=True)
-    # jaco2_torque: 6 arm + 6 finger hinges (sprung distal joints), no free bodies -- stepped by the d12 build of the library
-    for xml_name in ("jaco2_curtain_torque", "jaco2_reaching_torque", "jaco2_torque"):
+    # jaco2_torque: 6 arm + 6 finger hinges (sprung distal joints), no free bodies -- stepped by the d12 build of the library;
+    # jaco2_dual_torque: two arms + two objects (30 dofs, 106 geoms, 3 332 pairs) -- stepped by the d30 build (ctrl level)
+    for xml_name in ("jaco2_curtain_torque", "jaco2_reaching_torque", "jaco2_torque", "jaco2_dual_torque"):
         M, names = compile_model(xml_name)
         path = os.path.join(OUT_DIR, xml_name + ".jacomdl")
         blob.save(path, M)

@@ -20,7 +20,8 @@ _libs = {}
 
 
 def lib(layout=""):
-    """layout "": the default build (11 bodies / 21 dofs in blocks 9 + 6 + 6); "_d12": the build for jaco2_torque.xml (12 hinge dofs, one tree)."""
+    """layout "": the default build (11 bodies / 21 dofs in blocks 9 + 6 + 6); "_d12": the build for jaco2_torque.xml (12 hinge dofs, one tree);
+    "_d30": the build for jaco2_dual_torque.xml (two arms + two objects, 30 dofs; ctrl level)."""
     if layout not in _libs:
         subprocess.check_call(["make", "-s", "-C", EMU_DIR])
         L = ctypes.CDLL(os.path.join(EMU_DIR, "libjaco_emu%s.so" % layout))
@@ -42,7 +43,7 @@ class EmuEnv:
         self.blob = open(os.path.join(ASSETS, model + ".jacomdl"), "rb").read()
         from mujoco_jaco_amd.modelc import blob as blobmod
         M = blobmod.loads(self.blob)
-        self.L = lib("" if (int(M["f_nbody"][0]) <= 11 and int(M["nv"][0]) != 12) else "_d12")
+        self.L = lib("_d30" if int(M["nv"][0]) > 21 else ("" if (int(M["f_nbody"][0]) <= 11 and int(M["nv"][0]) != 12) else "_d12"))
         self.M = M
         self.nq, self.nv, self.nu, self.ns = int(M["nq"][0]), int(M["nv"][0]), int(M["nu"][0]), int(M["nsensor"][0])
         self.nenv = nenv

@@ -24,7 +24,9 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_lib.SYMBOLS) == names, "ctypes table and header disagree"
     _lib.load()
     _lib.load("_d12")          # the build for the layout of jaco2_torque.xml exports the same ABI
+    _lib.load("_d30")          # ... and the build for the two-arm layout of jaco2_dual_torque.xml
     assert _lib.variant_for(open(_lib.model_path("jaco2_torque"), "rb").read()) == "_d12"
+    assert _lib.variant_for(open(_lib.model_path("jaco2_dual_torque"), "rb").read()) == "_d30"
     assert _lib.variant_for(open(_lib.model_path("jaco2_curtain_torque"), "rb").read()) == "" and _lib.variant_for(open(_lib.model_path("jaco2_reaching_torque"), "rb").read()) == ""
 
 

@@ -286,3 +286,66 @@ def test_jaco2_torque_sibling_model_on_the_d12_build():
     print("jaco2_torque, %d substeps: qpos err median %.2e max %.2e, qvel err max %.2e; oracle max rows %d, max contacts %d" % (nsub, np.median(eq), eq.max(), ev.max(), st[:, 1].max(), st[:, 0].max()))
     assert (env.flags().cpu().numpy() & 15).max() == 0 and st[:, 1].max() >= 1
     assert np.median(eq) < 4e-7 and eq.max() < 1.2e-5 and ev.max() < 2e-4   # 3x measured (1.2e-7 / 4.0e-6 / 5.8e-5; up to 11 limit rows, 1 contact)
+
+
+def test_dual_arm_model_on_the_d30_build():
+    """jaco2_dual_torque.xml (xml:48-49: two arms included side by side; 30 dofs, 106 geoms, 3 332 pairs, 18 actuators) stepped
+    by libjaco_env_d30.so -- the same kernel sources compiled for that layout -- at the sim-interface (ctrl) level, against the fp64 oracle.
+    (A) 128 envs, objects on their holders, random arm poses, 100 substeps of random motor torques and finger commands (free run);
+    (B) the arm-on-arm poses of tests/golden/dual_cross_poses.npz, one substep from identical state: contact and row counts as the oracle's.
+    JacoBatchedEnv(n_robots=2) picks the model and the build and exposes that tier."""
+    import os
+    from mujoco_jaco_amd import _lib
+    from mujoco_jaco_amd.env import JacoBatchedEnv
+    from mujoco_jaco_amd.modelc import blob
+    from oracle_binding import Oracle
+    M = blob.load(_lib.model_path("jaco2_dual_torque"))
+    B, nsub = 128, 100
+    rng = np.random.default_rng(78)
+    lo, hi = np.array([0.7, 3.8, 1.0, 1.8, 1.0, 0.8]), np.array([2.5, 4.0, 1.7, 2.5, 2.5, 2.3])
+    q = np.tile(M["qpos0"], (B, 1))
+    q[:, 0:6] = rng.uniform(lo, hi, (B, 6)); q[:, 9:15] = rng.uniform(lo, hi, (B, 6))
+    q[:, 18:21] = [-0.5, 0.6, 0.2001]; q[:, 25:28] = [0.5, 0.6, 0.2001]
+    q = q.astype(np.float32).astype(np.float64)
+    tq = np.array([30, 30, 30, 15, 15, 15]) * 0.2
+    c = np.concatenate([rng.uniform(-1, 1, (B, 6)) * tq, rng.uniform(0.6, 1.0, (B, 3)), rng.uniform(-1, 1, (B, 6)) * tq, rng.uniform(0.6, 1.0, (B, 3))], 1)
+    c = c.astype(np.float32).astype(np.float64)
+    genv = JacoBatchedEnv(num_envs=B, n_robots=2)
+    assert genv.observation_space.shape == (52,) and genv.action_space.shape == (14,) and genv.sim_tier_only
+    with pytest.raises(NotImplementedError):
+        genv.reset()
+    env = genv.sim
+    assert (env.nq, env.nv, env.nu, env.nsensor) == (32, 30, 18, 40)
+    env.set_state(_t(q, env.device), None, None)
+    env.send_forces(_t(c, env.device), nsub=nsub)
+    gq, gv, _ = [t.cpu().numpy().astype(np.float64) for t in env.get_state()]
+    o = Oracle("jaco2_dual_torque")
+    qo, vo, wo = q.copy(), np.zeros((B, 30)), np.zeros((B, 30))
+    st = np.zeros((B, 4), np.int32)
+    o.step_batch(qo, vo, wo, np.ascontiguousarray(c), nsub=nsub, nthreads=16, stats=st)
+    eq, ev = np.abs(gq - qo).max(1), np.abs(gv - vo).max(1)
+    gst = env.stats().cpu().numpy()
+    print("dual arm, %d substeps free run: qpos err median %.2e p90 %.2e max %.2e, qvel err median %.2e max %.2e; oracle rows %d..%d, contacts up to %d; same final row count in %d of %d envs" % (
+        nsub, np.median(eq), np.percentile(eq, 90), eq.max(), np.median(ev), ev.max(), st[:, 1].min(), st[:, 1].max(), st[:, 0].max(), int((gst[:, 1] == st[:, 1]).sum()), B))
+    assert (env.flags().cpu().numpy() & 15).max() == 0 and st[:, 1].min() >= 48
+    # 3x measured on MI355X (qpos median 1.3e-7, p90 2.4e-7, max 6.2e-6; qvel max 3.7e-4; rows 48..280, up to 61 contacts; 120 of 128 envs end
+    # on the oracle's row count) -- jaco2_torque's bounds for the positions, a wider one for the velocities of a model with contacts
+    assert np.median(eq) < 4e-7 and np.percentile(eq, 90) < 7e-7 and eq.max() < 2e-5 and ev.max() < 1.1e-3
+    # (B) arm-on-arm poses, one substep
+    P = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dual_cross_poses.npz"))["qpos"]
+    n = len(P)
+    q2 = np.tile(M["qpos0"], (B, 1)); q2[:n] = P; q2[n:] = q[n:]
+    c2 = c.copy(); c2[:, :6] *= 0.5; c2[:, 9:15] *= 0.5
+    env.set_state(_t(q2, env.device), torch.zeros(B, 30, device=env.device), torch.zeros(B, 30, device=env.device))
+    env.clear_flags()
+    env.send_forces(_t(c2, env.device), nsub=1)
+    gq, gv, _ = [t.cpu().numpy().astype(np.float64) for t in env.get_state()]
+    gst = env.stats().cpu().numpy()
+    qo, vo, wo = q2.copy(), np.zeros((B, 30)), np.zeros((B, 30))
+    o.step_batch(qo, vo, wo, np.ascontiguousarray(c2), nsub=1, nthreads=16, stats=st)
+    eq = np.abs(gq - qo).max(1)[:n]
+    print("dual arm, %d arm-on-arm poses, one substep: contacts %s rows %s | qpos err median %.2e max %.2e" % (n, st[:n, 0].tolist(), st[:n, 1].tolist(), np.median(eq), eq.max()))
+    assert np.array_equal(gst[:n, :2], st[:n, :2])                       # same contact and row counts as the oracle
+    assert (env.flags().cpu().numpy()[:n] & 15).max() == 0 and st[:n, 1].max() > 128
+    assert np.median(eq) < 6e-7 and eq.max() < 1.6e-6                   # 3x measured (1.9e-7 / 5.2e-7)
+    genv.close()

@@ -236,3 +236,49 @@ def test_separating_direction_cache_does_not_change_results(model_arrays, names)
     (calls_on, q_on), (calls_off, q_off) = queries
     print("hull pairs: %d narrowphase calls; support queries %d with the cache, %d without" % (calls_on, q_on, q_off))
     assert calls_on == calls_off and q_on < q_off   # (this scenario is dominated by hits; the saving under the shipped policy is ~a quarter of all queries: tools/mpr_query_stats_emu.py)
+
+
+def test_dual_arm_model_on_the_d30_build_matches_oracle():
+    """Sibling MJCF jaco2_dual_torque.xml (xml:48-49 includes the two arms): 20 fused bodies, 30 dofs (two 9-dof arm trees in
+    one dof block + two free objects), 106 geoms, 3 332 pairs, 18 actuators, 40 touch sensors -- stepped by the d30 build of the same kernel
+    sources (frame, geom and pair stages in several 64-lane passes).  Single steps re-synchronised with the oracle: (A) free fall of the
+    objects and torque-driven arms, (B) objects resting on their holders (12 contacts / 48 rows) under random arm poses, (C) poses in which
+    the two arms touch each other (tests/golden/dual_cross_poses.npz: 13..47 contacts, up to ~340 rows incl. condim-6 hull contacts that
+    couple both arm trees; medium / heavy / huge tiers): same contact and row counts as the oracle in every step."""
+    import os
+    o = Oracle("jaco2_dual_torque"); e = EmuEnv("jaco2_dual_torque")
+    assert (e.nq, e.nv, e.nu, e.ns) == (32, 30, 18, 40)
+    rng = np.random.default_rng(1)
+
+    def run(q, nsteps, ctrl):
+        o.reset(); o.set("qpos", q); o.set("qvel", np.zeros(30)); o.set("qacc_warmstart", np.zeros(30))
+        e.flags[0] = 0
+        wq = wv = 0.0
+        maxrows = 0
+        for i in range(nsteps):
+            eq, ev = _sync_step(o, e, ctrl)
+            assert (e.stats[0, 0], e.stats[0, 1]) == (o.ncon, o.nefc), (i, e.stats[0], o.ncon, o.nefc)
+            wq, wv, maxrows = max(wq, eq), max(wv, ev), max(maxrows, o.nefc)
+        assert (e.flags[0] & 31) == 0
+        return wq, wv, maxrows
+
+    q0 = e.M["qpos0"].copy()
+    ctrl = np.concatenate([rng.uniform(-1, 1, 6) * 5, [0.6] * 3, rng.uniform(-1, 1, 6) * 5, [1.0] * 3])
+    wq, wv, _ = run(q0, 6, ctrl)                                            # (A)
+    assert wq < 1e-6 and wv < 2e-4
+    lo, hi = np.array([0.7, 3.8, 1.0, 1.8, 1.0, 0.8]), np.array([2.5, 4.0, 1.7, 2.5, 2.5, 2.3])
+    for k in range(2):                                                      # (B)
+        q = q0.copy(); q[18:21] = [-0.5, 0.6, 0.2001]; q[25:28] = [0.5, 0.6, 0.2001]
+        q[0:6] = rng.uniform(lo, hi); q[9:15] = rng.uniform(lo, hi)
+        wq, wv, rows = run(q, 8, np.concatenate([rng.uniform(-1, 1, 6) * 8, [0.8] * 3, rng.uniform(-1, 1, 6) * 8, [0.6] * 3]))
+        assert wq < 1e-6 and wv < 2e-4 and rows == 48
+    P = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dual_cross_poses.npz"))["qpos"]
+    errs, most = [], 0
+    for q in P[:6]:                                                         # (C)
+        wq, wv, rows = run(q, 6, np.concatenate([rng.uniform(-1, 1, 6) * 3, [0.7] * 3, rng.uniform(-1, 1, 6) * 3, [0.7] * 3]))
+        errs.append(wq); most = max(most, rows)
+    print("dual arm, arm-on-arm poses: single-step qpos error per pose", ["%.1e" % x for x in errs], "most rows", most)
+    # the geoms of these poses overlap by 1-7 cm (|qacc| ~ 5e3-2e4 rad/s^2): single-step errors of 2e-7 .. 2e-6, one pose / torque draw in
+    # a dozen an order above that (same contact set, fp32 solve of ~300 ill-conditioned rows)
+    assert np.median(errs) < 2e-6 and max(errs) < 1e-4
+    assert most > 128                                                       # the bigger tiers carried it
