@@ -426,8 +426,10 @@ def main():
                 gather.start(o)    # side stream: it overlaps the next step's launch set; the timed region ends on a full device sync)
     else:
         env = BatchedMujoco(B, robot_file=args.model, device=local_rank, frame_skip=fs, seed=rank)
-        q = torch.tensor(workload.reset_states(M["qpos0"], B, seed=1000 + rank), dtype=torch.float32, device=dev)
-        ctrl = torch.tensor(workload.random_ctrl(B, seed=2000 + rank, scale=0.2)[:, :env.nu].copy(), dtype=torch.float32, device=dev)
+        dual = env.nu == 18   # jaco2_dual_torque (two arms, two objects; the d30 build)
+        q = torch.tensor(workload.reset_states_dual(M["qpos0"], B, seed=1000 + rank) if dual else workload.reset_states(M["qpos0"], B, seed=1000 + rank),
+                         dtype=torch.float32, device=dev)
+        ctrl = torch.zeros(B, env.nu, dtype=torch.float32, device=dev)
         env.set_state(q, None, None)
         if args.no_contact:
             env.set_option("disable_contact", 1)
@@ -437,8 +439,9 @@ def main():
         # 0.6 -- the same distribution as workload.random_ctrl, drawn on the GPU.  (Constant torques for the whole run, as rounds 1-3 had it,
         # spin the limit-free arm joints up to hundreds of rad/s within the 11 000 substeps of the config-2 leg: a non-physical workload
         # that ended in the velocity quarantine for some envs.)
-        tq = torch.tensor([30, 30, 30, 15, 15, 15] + [0] * (env.nu - 6), dtype=torch.float32, device=dev)[:env.nu] * 0.2
-        hold = torch.tensor([0] * 6 + [0.6] * (env.nu - 6), dtype=torch.float32, device=dev)[:env.nu]
+        arm = [30, 30, 30, 15, 15, 15, 0, 0, 0]
+        tq = torch.tensor((arm * 2)[:env.nu], dtype=torch.float32, device=dev) * 0.2
+        hold = torch.tensor(([0] * 6 + [0.6] * 3) * 2, dtype=torch.float32, device=dev)[:env.nu]
         cgen = torch.Generator(device=dev); cgen.manual_seed(3000 + rank)
 
         def step():
@@ -531,7 +534,7 @@ def main():
                       "wait_frac": (pm["SQ_WAIT_ANY"] / pm["SQ_WAVE_CYCLES"]) if pm.get("SQ_WAIT_ANY") and pm.get("SQ_WAVE_CYCLES") else None}
         except Exception:
             pass
-        cfgname = "config2" if (args.no_contact and args.level == "ctrl") else ("config4" if (args.no_reset and fs == 4) else "config3")
+        cfgname = "config2" if (args.no_contact and args.level == "ctrl") else ("config4" if (args.no_reset and fs == 4) else ("two-arm model, sim tier" if env.nu == 18 else "config3"))
         if args.level != "env":
             workload_desc = "random motor ctrl, ctrl-level jaco_physics_step"
         else:

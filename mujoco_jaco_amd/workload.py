@@ -34,3 +34,14 @@ def random_ctrl(nenv, seed=1, scale=1.0, grip=0.6):
     c[:, :6] = rng.uniform(-1, 1, (nenv, 6)) * np.array([30, 30, 30, 15, 15, 15]) * scale
     c[:, 6:] = grip
     return c
+
+
+def reset_states_dual(qpos0, nenv, seed=0, f32_draws=True):
+    """jaco2_dual_torque.xml: both arms in the picking pose range (env_mujoco_util.py:177-180), both objects resting on their holders
+    (object_holder_1/2 at (-+0.5, 0.6): top at z = 0.17, object half height 0.03)."""
+    rng = np.random.default_rng(seed)
+    q = np.tile(np.asarray(qpos0, np.float64), (nenv, 1))
+    lo = np.array([0.7, 3.8, 1.0, 1.8, 1.0, 0.8]); hi = np.array([2.5, 4.0, 1.7, 2.5, 2.5, 2.3])
+    q[:, 0:6] = rng.uniform(lo, hi, (nenv, 6)); q[:, 9:15] = rng.uniform(lo, hi, (nenv, 6))
+    q[:, 18:21] = [-0.5, 0.6, 0.2001]; q[:, 25:28] = [0.5, 0.6, 0.2001]
+    return q.astype(np.float32).astype(np.float64) if f32_draws else q
