@@ -77,7 +77,8 @@ struct JacoHandle {
   unsigned* order_ctl = nullptr;   // histogram / cursors / cost sum / bucket reference of the ordering passes
   int schedule = 1;           // option "schedule": 0 = launch envs in index order
   int auto_reset = 0;         // option "auto_reset"
-  int min_nsub_sched = 2;     // option "min_nsub_sched": shortest step (substeps) that gets the cost-ordered launch and the resident tier workers
+  int min_nsub_sched = 2;     // option "min_nsub_sched": shortest step (substeps) that gets the resident tier workers
+  int min_nsub_order = 2;     // option "min_nsub_order": shortest step that gets the cost-ordered launch (three small launches in front of the light grid)
   const float* noise = nullptr;
   const float* subgoal = nullptr;   // obs_mode 1: the policy's sub-goal offsets for the "subgoal_reach" marker
   int obs_mode = 0;
@@ -476,7 +477,7 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
   // object for 150 substeps, grasping pre-reaches: those keep the explicit jaco_reset)
   A.auto_reset = h->auto_reset && io.mode == 1 && (h->task == JACO_TASK_PICKING || h->task == JACO_TASK_REACHING || h->task == JACO_TASK_PICKANDPLACE || h->task == JACO_TASK_PUSHING);
   A.qpos0 = h->qpos0_dev;
-  const bool reorder = io.mode == 1 && h->schedule && nsub >= h->min_nsub_sched && h->num_envs >= 4096;
+  const bool reorder = io.mode == 1 && h->schedule && nsub >= h->min_nsub_order && h->num_envs >= 4096;
   std::pair<hipEvent_t, hipEvent_t>*ev = nullptr, *kev = nullptr;
   if (h->timing && io.mode <= 1) {   // (the masked forward passes of resets are not the kernel being measured)
     if (h->events_used == h->events.size()) {
@@ -766,6 +767,7 @@ extern "C" int jaco_set_option(JacoHandle* h, const char* name, double v) {
   if (!strcmp(name, "handdown")) { h->handdown = v != 0; return JACO_OK; }
   if (!strcmp(name, "auto_reset")) { h->auto_reset = v != 0; return JACO_OK; }
   if (!strcmp(name, "min_nsub_sched")) { h->min_nsub_sched = v < 1 ? 1 : (int)v; return JACO_OK; }
+  if (!strcmp(name, "min_nsub_order")) { h->min_nsub_order = v < 1 ? 1 : (int)v; return JACO_OK; }
   if (!strcmp(name, "hints")) { h->use_hints = v < 0 ? 0 : (v > 2 ? 2 : (int)v); return JACO_OK; }   // 0 off, 1 biggest tier of the last step, 2 tier of its last substep
   if (!strcmp(name, "obs_mode")) { if (v != 0 && v != 1) { h->err = "jaco_set_option: obs_mode must be 0 or 1"; return JACO_EINVAL; } h->obs_mode = (int)v; return JACO_OK; }
   else if (!strcmp(name, "iterations")) m.iterations = (int)v;
