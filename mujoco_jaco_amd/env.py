@@ -51,6 +51,13 @@ class JacoBatchedEnv:
         if kwargs.get("subgoal_obs", False):
             raise NotImplementedError("subgoal_obs=True: the reference's own observation assert (23 != 26 entries) rejects this branch")
         self.rulebased_subgoal = bool(kwargs.get("rulebased_subgoal", True))
+        # kwargs of the reference that need host-side Python per env and have no batched counterpart here: said out loud instead of ignored
+        if kwargs.get("reward_method", None) is not None or kwargs.get("reward_module", None) is not None:
+            raise NotImplementedError("reward_method / reward_module (env_mujoco_util.py:69-70,442-443: a Python callable evaluated per step) are not "
+                                      "supported: the reward is computed inside the step kernel")
+        if kwargs.get("init_buffer", None) is not None:
+            raise NotImplementedError("init_buffer (reaching goals drawn from a recorded buffer, env_mujoco_util.py:46,208-212) is not supported: "
+                                      "goals are drawn by the in-kernel reset (:199-207)")
         self.n_robots = kwargs.get("n_robots", 1)
         if self.n_robots not in (1, 2):
             raise NotImplementedError("n_robots = %r: the reference ships models for one and two arms" % (self.n_robots,))
@@ -87,7 +94,10 @@ class JacoBatchedEnv:
         self.skip_frames = int(frame_skip)
         obs_max = np.hstack([[3], [1] * 25]).astype(np.float32).repeat(self.n_robots)   # (.repeat(n_robots), env_mujoco.py:57-58)
         self.observation_space = Box(-obs_max, obs_max, dtype=np.float32)
-        self.state_shape = self.observation_space.shape[0]
+        try:   # env_mujoco.py:64-67: a state generator may dictate the state shape
+            self.state_shape = kwargs["stateGen"].get_state_shape()
+        except Exception:
+            self.state_shape = self.observation_space.shape[0]
         self.pose_action_space_max = 1
         nact = 6 if self.task in ("reaching", "pushing") else 7   # env_mujoco.py:79-89
         self.act_max = np.ones(nact).repeat(self.n_robots)      # env_mujoco.py:86-88
