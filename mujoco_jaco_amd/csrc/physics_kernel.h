@@ -1937,8 +1937,14 @@ again:
   }
   Ap = args_view(A_);   // (the epilogue reads the argument block afresh: nothing of it was carried through the substep loop)
   bool reset_now = false;
+  // Write-through stores for everything another workgroup may read or REWRITE before this launch set is over: an env that is handed over
+  // (bailed), and -- option auto_reset -- every normal step's outputs, because a step that ends its episode is followed by the in-kernel
+  // reset, whose forward pass may overflow the tier and be finished by a resident worker on another XCD: that workgroup rewrites the
+  // observation, sensor, cache and state rows, and two XCDs holding dirty copies of one line write back in an undefined order (the
+  // GPU determinism test of the policy-driven regime caught this as one env in 8 192 differing from run to run).
+  const bool wt = bailed || (emode == 1 && A.auto_reset != 0 && !fwd);
   if (emode != 2) {
-    if (bailed) {   // handed over to another workgroup (possibly on another XCD): write-through stores
+    if (wt) {   // handed over to another workgroup (possibly on another XCD): write-through stores
       if (lane < nq) { st_wt(&A.qpos[(size_t)env * nq + lane], s.qpos[lane]); if (A.qpos_lo) st_wt(&A.qpos_lo[(size_t)env * nq + lane], s.qpos_lo[lane]); }
       if (lane < nv) { st_wt(&A.qvel[(size_t)env * nv + lane], s.qvel[lane]); st_wt(&A.qacc_ws[(size_t)env * nv + lane], s.qacc_ws[lane]); if (A.qvel_lo) st_wt(&A.qvel_lo[(size_t)env * nv + lane], s.qvel_lo[lane]); }
     } else {
@@ -1946,7 +1952,7 @@ again:
       if (lane < nv) { A.qvel[(size_t)env * nv + lane] = s.qvel[lane]; A.qacc_ws[(size_t)env * nv + lane] = s.qacc_ws[lane]; if (A.qvel_lo) A.qvel_lo[(size_t)env * nv + lane] = s.qvel_lo[lane]; }
     }
   }
-  if (left == 0 && lane < ns && A.sensordata && (emode < 4 || emode == 6)) A.sensordata[(size_t)env * ns + lane] = sens;
+  if (left == 0 && lane < ns && A.sensordata && (emode < 4 || emode == 6)) { if (wt) st_wt(&A.sensordata[(size_t)env * ns + lane], sens); else A.sensordata[(size_t)env * ns + lane] = sens; }
   if (emode == 6 && left == 0 && s.task[JT_PHASE] < 3.f) flags |= JFLAG_PREREACH_CAP;
   if (emode == 5) sens = (lane < ns && A.sensordata) ? A.sensordata[(size_t)env * ns + lane] : 0.f;   // touch of the last forward pass
   if (emode) {
@@ -1954,11 +1960,18 @@ again:
       // what the controller reads one substep late, for the next launch -- or, on a heavy -> light hand-back in the middle
       // of a step, for the light code's next substep
       float* CW = A.cache + (size_t)env * JCACHE_N;
-      if (lane < 36) { CW[JC_M + lane] = s.M[m_index(lane / 6, lane % 6)]; CW[JC_CDOF + lane] = s.cdof[lane / 6][lane % 6]; }
-      if (lane < 6) CW[JC_BIAS + lane] = s.bias[lane];
       int ob = m->obj_body >= 0 ? m->obj_body : 0;
-      if (lane < 3) { CW[JC_EEPOS + lane] = s.xpos[m->ee_body][lane]; CW[JC_OBJPOS + lane] = s.xpos[ob][lane]; }
-      if (lane < 9) CW[JC_EEMAT + lane] = s.xmat[m->ee_body][lane];
+      if (wt) {
+        if (lane < 36) { st_wt(&CW[JC_M + lane], s.M[m_index(lane / 6, lane % 6)]); st_wt(&CW[JC_CDOF + lane], s.cdof[lane / 6][lane % 6]); }
+        if (lane < 6) st_wt(&CW[JC_BIAS + lane], s.bias[lane]);
+        if (lane < 3) { st_wt(&CW[JC_EEPOS + lane], s.xpos[m->ee_body][lane]); st_wt(&CW[JC_OBJPOS + lane], s.xpos[ob][lane]); }
+        if (lane < 9) st_wt(&CW[JC_EEMAT + lane], s.xmat[m->ee_body][lane]);
+      } else {
+        if (lane < 36) { CW[JC_M + lane] = s.M[m_index(lane / 6, lane % 6)]; CW[JC_CDOF + lane] = s.cdof[lane / 6][lane % 6]; }
+        if (lane < 6) CW[JC_BIAS + lane] = s.bias[lane];
+        if (lane < 3) { CW[JC_EEPOS + lane] = s.xpos[m->ee_body][lane]; CW[JC_OBJPOS + lane] = s.xpos[ob][lane]; }
+        if (lane < 9) CW[JC_EEMAT + lane] = s.xmat[m->ee_body][lane];
+      }
     }
     if (left == 0 && emode != 3 && emode != 4) {
       // observation, reward, termination from the poses / sensors of the last forward pass (one substep stale, as in
@@ -2017,12 +2030,12 @@ again:
         else if (lane < 23) o = (A.obs_mode == 1 ? s.task[JT_REACHGOAL + lane - 17] : sori[lane - 20]) / PI;
         else o = lane == 24 ? PI / 2.f : 0.f;
         if (!(fabsf(o) <= 3.0e38f)) o = 0.f;   // (quarantined env: the observation row stays finite)
-        A.obs[(size_t)env * 26 + lane] = o;
+        if (wt) st_wt(&A.obs[(size_t)env * 26 + lane], o); else A.obs[(size_t)env * 26 + lane] = o;
       }
     }
     if (left == 0 && (emode == 3 || emode == 6) && lane == 0) { s.task[JT_SUB] = 0.f; s.task[JT_PENDING] = 0.f; }
     wave_sync();
-    if (lane < JTASK_N) { if (bailed) st_wt(&A.task[(size_t)env * JTASK_N + lane], s.task[lane]); else A.task[(size_t)env * JTASK_N + lane] = s.task[lane]; }
+    if (lane < JTASK_N) { if (wt) st_wt(&A.task[(size_t)env * JTASK_N + lane], s.task[lane]); else A.task[(size_t)env * JTASK_N + lane] = s.task[lane]; }
   }
   if (reset_now) {
     // auto-reset (option "auto_reset"; tasks whose reset is draws + sim.forward(): picking, reaching, pickAndplace): the episode has
