@@ -1,28 +1,36 @@
-"""Run-to-run determinism of the policy-driven regime (diagnostic): the same 8 192-env rollout under the shipped picking policy, three times per
-setting of the execution options; reports the first env / step at which two runs differ.  This is the tool that found the round-4 write-back
-race (auto_reset + resident tier workers: two XCDs holding dirty copies of one env's observation / cache rows; physics_kernel.h, epilogue `wt`).
-   python tools/gpu_determinism.py"""
+"""Run-to-run determinism of the batched env (diagnostic): the same rollout twice or three times per regime, comparing states, observations,
+rewards, done flags, sticky flags and statistics bit for bit; reports the first env / step at which two runs differ.  Regimes: the shipped
+picking / placing policies (grasp contacts, in-kernel or explicit resets), random actions at scale 1 and 0.1 (stick-on-stick contacts, bigger
+tiers), other tasks.  This is the tool that found the round-4 write-back race (auto_reset + resident tier workers: two XCDs holding dirty
+copies of one env's observation / cache rows; physics_kernel.h, epilogue `wt`).
+   python tools/gpu_determinism.py [envs]"""
 import os, sys, torch
-sys.path.insert(0, "/root/repo")
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
 from mujoco_jaco_amd.env import JacoBatchedEnv
 from mujoco_jaco_amd.policy import HPCPolicy
-root = "/root/repo"
-B = 8192
-def run(pl, sc, nsteps=12, policy=True, auto=True, opts=()):
-    env = JacoBatchedEnv(num_envs=B, task="picking", seed=33, auto_reset=auto)
-    env.sim.set_option("pair_list", pl); env.sim.set_option("sep_cache", sc)
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+
+
+def run(task, nsteps, policy, scale, auto, opts=()):
+    env = JacoBatchedEnv(num_envs=B, task=task, seed=33, auto_reset=auto)
     for k, v in opts: env.sim.set_option(k, v)
     obs = env.reset()
     gen = torch.Generator(device=env.device); gen.manual_seed(8)
-    pol = HPCPolicy.load(os.path.join(root, "tests", "golden", "policy_picking.npz"), device=env.device)
-    ts = env.task_state(); ts[:, 1] = torch.randint(0, 600, (B,), device=env.device, generator=gen).float(); env.set_task_state(ts)
+    pol = HPCPolicy.load(os.path.join(ROOT, "tests", "golden", "policy_%s.npz" % policy), device=env.device) if policy else None
+    ts = env.task_state(); ts[:, 1] = torch.randint(0, env.task_max_steps - 20, (B,), device=env.device, generator=gen).float(); env.set_task_state(ts)
+    nact = env.action_space.shape[0]
     hist = []
     for s in range(nsteps):
-        obs, rew, done, _ = env.step(pol.predict(obs)[0])
-        hist.append(env.sim.get_state()[0].clone())
-    out = (hist, obs.clone(), env.sim.flags().clone(), env.sim.stats().clone())
+        a = pol.predict(obs)[0] if pol is not None else (torch.rand(B, nact, device=env.device, generator=gen) * 2 - 1) * scale
+        obs, rew, done, _ = env.step(a)
+        hist.append(torch.cat([env.sim.get_state()[0], env.sim.get_state()[1], obs, rew[:, None], done[:, None].float()], 1).clone())
+        if not env.auto_reset and bool(done.any()):
+            obs = env.reset(done)
+    out = (hist, env.sim.flags().clone(), env.sim.stats()[:, :3].clone())
     env.close()
     return out
+
 
 def cmp(name, a, b):
     first = None
@@ -30,13 +38,21 @@ def cmp(name, a, b):
         if not torch.equal(x, y):
             first = st; break
     if first is None:
-        print(name, ": identical over all steps", flush=True); return
+        same = torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+        print("%-58s identical over %d steps%s" % (name, len(a[0]), "" if same else "  (flags / stats differ!)"), flush=True)
+        return
     d = (a[0][first] - b[0][first]).abs().max(1).values
     bad = torch.nonzero(d > 0).flatten()
-    print(name, ": first difference at step", first + 1, "envs differing", len(bad), "max diff %.3e" % d.max().item(), "env ids", bad[:8].tolist(),
-          "flags", [hex(int(a[2][i])) for i in bad[:4]], [hex(int(b[2][i])) for i in bad[:4]], flush=True)
-for name, opts, auto in (("defaults", (), True), ("auto_reset off", (), False), ("concurrent_heavy 0", (("concurrent_heavy", 0),), True), ("hints 0", (("hints", 0),), True),
-                         ("handdown 0", (("handdown", 0),), True), ("schedule 0", (("schedule", 0),), True), ("tier_return 0", (("tier_return", 0),), True),
-                         ("concurrent 0 + hints 0 + schedule 0", (("concurrent_heavy", 0), ("hints", 0), ("schedule", 0)), True)):
-    a = run(0, 0, opts=opts, auto=auto); b = run(0, 0, opts=opts, auto=auto); c = run(0, 0, opts=opts, auto=auto)
-    cmp(name + " run 1 vs 2", a, b); cmp(name + " run 1 vs 3", a, c)
+    print("%-58s FIRST DIFFERENCE at step %d: %d envs, max %.3e, env ids %s, flags %s" % (name, first + 1, len(bad), d.max().item(), bad[:6].tolist(),
+          [hex(int(a[1][i])) for i in bad[:4]]), flush=True)
+
+
+for name, kw in (("picking, shipped policy, reset inside jaco_step, 94 steps", dict(task="picking", nsteps=94, policy="picking", scale=1, auto=True)),
+                 ("picking, random actions x 0.1, reset inside jaco_step", dict(task="picking", nsteps=24, policy=None, scale=0.1, auto=True)),
+                 ("picking, random actions x 1, explicit reset chain", dict(task="picking", nsteps=24, policy=None, scale=1.0, auto=False)),
+                 ("placing, shipped policy, explicit reset chain (hold)", dict(task="placing", nsteps=60, policy="placing", scale=1, auto=False)),
+                 ("pickAndplace, random actions, reset inside jaco_step", dict(task="pickAndplace", nsteps=24, policy=None, scale=1.0, auto=True)),
+                 ("reaching, random actions, reset inside jaco_step", dict(task="reaching", nsteps=24, policy=None, scale=1.0, auto=True)),
+                 ("grasping, random actions, explicit reset chain (pre-reach)", dict(task="grasping", nsteps=12, policy=None, scale=1.0, auto=False))):
+    a = run(**kw); b = run(**kw)
+    cmp(name, a, b)
