@@ -868,3 +868,62 @@ def test_pair_list_and_separating_direction_cache_do_not_change_results_at_scale
                 assert torch.equal(x, y), regime
         print("%s: mean contacts %.1f rows %.1f, touch sensors active in %d envs" % (regime, outs[0][6][:, 0].float().mean().item(), outs[0][6][:, 1].float().mean().item(),
                                                                               int((outs[0][7] > 1e-3).any(1).sum())))
+
+
+def test_grasp_regime_parity_under_the_shipped_policy(names):
+    """Env-level parity where the physics is hardest: mid-grasp under the reference's shipped picking policy (hull contacts through MPR, condim-6
+    pad contacts, touch sensors active, most envs stepped by the medium / heavy tiers).  256 envs roll 100 policy-driven steps on the GPU; at
+    that point both sides take the SAME state: jaco_forward (= sim.forward(): the controller's one-substep-stale quantities are refreshed from
+    the current state) on the GPU, set_state + forward on the fp64 oracle env, for the envs whose fingers touch the object; then 3 more steps
+    with the policy's actions (computed from the GPU observations, given to both sides) and the same injected noise.  Touch class and done
+    flags exact, observation / reward within fp32-vs-fp64 bounds (MAX over the selected envs)."""
+    import os
+    from mujoco_jaco_amd.env import JacoBatchedEnv
+    from mujoco_jaco_amd.policy import HPCPolicy
+    from oracle_env import OracleEnv
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    B = 256
+    env = JacoBatchedEnv(num_envs=B, task="picking", seed=44)
+    pol = HPCPolicy.load(os.path.join(root, "tests", "golden", "policy_picking.npz"), device=env.device)
+    rng = np.random.default_rng(9)
+    obs = env.reset()
+    alive = torch.ones(B, dtype=torch.bool, device=env.device)
+    for s in range(100):
+        obs, rew, done, _ = env.step(pol.predict(obs)[0])
+        alive &= ~done
+    env.set_noise(torch.full((B, 12), 0.5)); obs = env.make_observation()          # sim.forward() + observation from the current state
+    touching = (obs[:, 0] > 0) & alive
+    sel = torch.nonzero(touching).flatten().cpu().numpy()[:24]
+    assert len(sel) >= 8, len(sel)                                                  # the policy has its fingers on the object in many envs by now
+    q, v, w = [t.cpu().numpy().astype(np.float64) for t in env.sim.get_state()]
+    ts = env.task_state().cpu().numpy().astype(np.float64)
+    bigger = int(((env.sim.flags()[torch.as_tensor(sel, device=env.device)] & 32) != 0).sum())
+    oes = {}
+    for k in sel:
+        oe = OracleEnv(names, task="picking")
+        oe.obj_goal, oe.dest_goal = ts[k, 4:7].copy(), ts[k, 7:10].copy()
+        oe.grip, oe.steps, oe.episodes = float(ts[k, 0]), int(ts[k, 1]), int(ts[k, 2])
+        oe.set_state(q[k], v[k], w[k])
+        oo = oe.observe(np.full(6, 0.5))[0]
+        assert oo[0] == obs[k, 0].item() and np.abs(oo - obs[k].cpu().numpy()).max() < 2e-6, (k, oo[0], obs[k, 0].item())
+        oes[k] = oe
+    oerr, rerr, ncmp = [], [], 0
+    for s in range(3):
+        a = pol.predict(obs)[0]
+        nz = rng.uniform(size=(B, 12)).astype(np.float32)
+        env.set_noise(torch.tensor(nz))
+        obs, rew, done, _ = env.step(a)
+        an, on, rn, dn = a.cpu().numpy(), obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()
+        for k in list(oes):
+            oo, orew, odone, _ = oes[k].step(an[k].astype(np.float64), nz[k].astype(np.float64))
+            assert bool(dn[k]) == odone and on[k, 0] == oo[0], (s, k, on[k, 0], oo[0])
+            oerr.append(np.abs(on[k] - oo).max()); rerr.append(abs(rn[k] - orew)); ncmp += 1
+            if odone:
+                del oes[k]
+    oerr, rerr = np.array(oerr), np.array(rerr)
+    print("grasp regime, %d envs with finger-object contact (%d stepped by a bigger tier), %d env steps compared: obs err median %.2e p90 %.2e max %.2e; reward err max %.2e" % (
+        len(sel), bigger, ncmp, np.median(oerr), np.percentile(oerr, 90), oerr.max(), rerr.max()))
+    # 3x measured on MI355X (obs median 8.6e-8, p90 2.5e-7, max 2.0e-6; reward 5.2e-6; 24 envs, 69 env steps)
+    assert np.median(oerr) < 2.6e-7 and np.percentile(oerr, 90) < 7.5e-7 and oerr.max() < 6e-6 and rerr.max() < 1.6e-5
+    env.close()
+
