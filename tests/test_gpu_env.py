@@ -927,3 +927,37 @@ def test_grasp_regime_parity_under_the_shipped_policy(names):
     assert np.median(oerr) < 2.6e-7 and np.percentile(oerr, 90) < 7.5e-7 and oerr.max() < 6e-6 and rerr.max() < 1.6e-5
     env.close()
 
+
+
+def test_in_kernel_reset_equals_the_explicit_chain_across_tasks():
+    """Option auto_reset (reset + sim.forward() + first observation by the wave that finished the episode, hand-offs to bigger tiers and
+    resident workers included) against step() + reset(done): observations, rewards, done flags, states and task rows BIT FOR BIT, for the
+    tasks whose reset is draws + forward pass -- pushing ends every episode in its first step (65 536 in-kernel resets in 8 steps), the
+    others run into their time-outs (step counters staggered over the episode length), one leg in the small-action regime."""
+    from mujoco_jaco_amd.env import JacoBatchedEnv
+    B = 8192
+
+    def run(task, auto, nsteps, scale):
+        env = JacoBatchedEnv(num_envs=B, task=task, seed=17, auto_reset=auto)
+        env.reset()
+        gen = torch.Generator(device=env.device); gen.manual_seed(3)
+        nact = env.action_space.shape[0]
+        ts = env.task_state(); ts[:, 1] = torch.randint(0, env.task_max_steps, (B,), device=env.device, generator=gen).float(); env.set_task_state(ts)
+        out, ends = [], 0
+        for s in range(nsteps):
+            obs, rew, done, _ = env.step((torch.rand(B, nact, device=env.device, generator=gen) * 2 - 1) * scale)
+            obs, rew, done = obs.clone(), rew.clone(), done.clone()
+            ends += int(done.sum())
+            if not env.auto_reset and bool(done.any()):
+                obs[done] = env.reset(done)[done]
+            out.append((obs, rew, done, env.sim.get_state()[0].clone(), env.task_state().clone()))
+        assert int((env.sim.flags() & 31).max()) == 0
+        env.close()
+        return out, ends
+
+    for task, n, scale in (("pushing", 8, 1.0), ("reaching", 30, 1.0), ("pickAndplace", 20, 1.0), ("picking", 16, 0.1)):
+        (a, ends), (b, _) = run(task, True, n, scale), run(task, False, n, scale)
+        assert ends > 100, (task, ends)
+        for s, (x, y) in enumerate(zip(a, b)):
+            for u, v in zip(x, y):
+                assert torch.equal(u, v), (task, s)
