@@ -68,6 +68,7 @@ struct JacoHandle {
   int pair_list = 1;   // option "pair_list"
   float* sepdir = nullptr;   // [num_envs][JMAXPAIR][4] separating-direction cache of the hull narrowphase (collision.h)
   int sep_cache = 1;         // option "sep_cache"
+  int arm_kernel = 1;        // option "arm_kernel": contact-free steps use the contact-free instantiation (0: the general kernel with its runtime flag, comparison)
   int concurrent = 1, workers = 1024, workers_heavy = 256, workers_huge = 32, tier_return = 1, use_hints = 2, handdown = 1;   // options "concurrent_heavy", "heavy_workers", "hints"
   float *task_rows = nullptr, *cache = nullptr;
   float* terminal = nullptr;   // [num_envs][2] (success flag, wb) latched by every terminal step
@@ -495,7 +496,7 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
   }
   // Contact-free step (option disable_contact, or a model without a collidable pair): its own lean kernel, alone -- no capacity can
   // overflow (at most one limit row per joint), so there is nothing to route, order, serve or drain.
-  if ((h->disable_contact || h->model_host.npair == 0) && io.mode <= 1) {
+  if (h->arm_kernel && (h->disable_contact || h->model_host.npair == 0) && io.mode <= 1) {
     A.disable_contact = 1; A.hint = nullptr;
     if (kev) HIPCHK(h, hipEventRecord(kev->first, st));
     JLAUNCHK(h, JK_ARM, (unsigned)h->num_envs, st, A);
@@ -760,6 +761,7 @@ extern "C" int jaco_set_option(JacoHandle* h, const char* name, double v) {
   if (!strcmp(name, "disable_contact")) { h->disable_contact = v != 0; return JACO_OK; }
   if (!strcmp(name, "pair_list")) { h->pair_list = v != 0; return JACO_OK; }
   if (!strcmp(name, "sep_cache")) { h->sep_cache = v != 0; return JACO_OK; }
+  if (!strcmp(name, "arm_kernel")) { h->arm_kernel = v != 0; return JACO_OK; }
   if (!strcmp(name, "schedule")) { h->schedule = v != 0; return JACO_OK; }
   if (!strcmp(name, "concurrent_heavy")) { h->concurrent = v != 0; return JACO_OK; }
   if (!strcmp(name, "tier_return")) { h->tier_return = v != 0; return JACO_OK; }

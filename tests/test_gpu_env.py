@@ -961,3 +961,30 @@ def test_in_kernel_reset_equals_the_explicit_chain_across_tasks():
         for s, (x, y) in enumerate(zip(a, b)):
             for u, v in zip(x, y):
                 assert torch.equal(u, v), (task, s)
+
+
+def test_contact_free_kernel_at_env_level_matches_the_general_kernel():
+    """The contact-free instantiation also serves env-level steps (task reaching on the arm-only model with contacts off: controller, 50
+    substeps, observation, reward, termination).  Against the general kernel with its runtime disable_contact flag (option arm_kernel = 0):
+    the two differ in how the joint-limit rows are solved (dof lanes vs matrix-core pass), so to fp32 rounding, done flags exactly."""
+    from mujoco_jaco_amd.env import JacoBatchedEnv
+    B = 512
+    outs = []
+    for arm in (1, 0):
+        env = JacoBatchedEnv(num_envs=B, task="reaching", robot_file="jaco2_reaching_torque", seed=5)
+        env.sim.set_option("disable_contact", 1); env.sim.set_option("arm_kernel", arm)
+        env.reset()
+        gen = torch.Generator(device=env.device); gen.manual_seed(2)
+        env.sim.launch_count()
+        for s in range(6):
+            obs, rew, done, _ = env.step(torch.rand(B, 6, device=env.device, generator=gen) * 2 - 1)
+        n = env.sim.launch_count()
+        assert (n == 6) == (arm == 1), n                      # one launch per step on the contact-free kernel
+        assert int((env.sim.flags() & 31).max()) == 0
+        outs.append((obs.clone(), rew.clone(), done.clone(), env.sim.get_state()[0].clone()))
+        env.close()
+    (oa, ra, da, qa), (ob, rb, db, qb) = outs
+    print("env-level reaching, contact-free vs general kernel after 6 steps: obs diff max %.2e, qpos diff max %.2e, reward diff max %.2e" % (
+        (oa - ob).abs().max().item(), (qa - qb).abs().max().item(), (ra - rb).abs().max().item()))
+    assert torch.equal(da, db) and torch.isfinite(oa).all()
+    assert (oa - ob).abs().max().item() < 1e-4 and (qa - qb).abs().max().item() < 1e-4
