@@ -297,7 +297,7 @@ JDEV void collide_box_box4(const JacoModelDev* m, L& s, int cbase, int nrows, in
 }
 
 // ---------------------------------------------------------------- MPR (all lanes run the same serial control flow)
-struct Sup { v3 v, v1, v2; };
+struct Sup { v3 v, v1; };   // a point of the Minkowski difference G1 - G2 and its witness on G1 (the one on G2 is v1 - v: not kept -- the routine is the kernel's register hot spot)
 // Everything a support query needs about one geom, fetched once per candidate pair.
 struct MprGeom { GeomPose P; v3 size; int type, adr, nvert, cellR, celladr; };
 template <class L>
@@ -387,8 +387,7 @@ JDEV Sup mpr_support(const JacoStepArgs& A, const MprGeom& G1, const MprGeom& G2
   } else sp2 = support_prim(G2, l2);
   Sup r;
   r.v1 = G1.P.p + mul(G1.P.R, sp1);
-  r.v2 = G2.P.p + mul(G2.P.R, sp2);
-  r.v = r.v1 - r.v2;
+  r.v = r.v1 - (G2.P.p + mul(G2.P.R, sp2));
   return r;
 }
 // The portal (p0 interior point, p1..p3 triangle) is kept in four named variables: an indexed array would live in scratch.
@@ -436,9 +435,10 @@ JDEV v3 mpr_find_pos(const Sup& p0, const Sup& p1, const Sup& p2, const Sup& p3)
     b1 = dot(cross(p2.v, p3.v), dir); b2 = dot(cross(p3.v, p1.v), dir); b3 = dot(cross(p1.v, p2.v), dir);
     sum = b1 + b2 + b3;
   }
+  // mid-point of the two witnesses: (a1 + a2) / 2 with a2 = a1 - sum_k b_k v_k
   v3 a1 = p0.v1 * b0 + p1.v1 * b1 + p2.v1 * b2 + p3.v1 * b3;
-  v3 a2 = p0.v2 * b0 + p1.v2 * b1 + p2.v2 * b2 + p3.v2 * b3;
-  return (a1 + a2) * (0.5f / sum);
+  v3 av = p0.v * b0 + p1.v * b1 + p2.v * b2 + p3.v * b3;
+  return (a1 - av * 0.5f) * (1.f / sum);
 }
 // returns true on penetration
 // On a miss that ended on a support test (the support of G1 - G2 along `dr` does not reach past the origin) *sep = dr: a separating
@@ -448,14 +448,14 @@ JDEV bool mpr_penetration(const JacoStepArgs& A, const JacoModelDev* m, const Mp
   Sup p0, p1, p2, p3, v4;
   float tol = m->mpr_tolerance;
   *sepvalid = false;
-  p0.v1 = G1.P.p; p0.v2 = G2.P.p; p0.v = p0.v1 - p0.v2;
+  p0.v1 = G1.P.p; p0.v = p0.v1 - G2.P.p;
   if (norm(p0.v) < 1e-9f) p0.v.x = 1e-5f;
   v3 dr = normalized(-p0.v);
   p1 = mpr_support(A, G1, G2, dr, lane);
   if (dot(p1.v, dr) <= 0.f) { *sep = dr; *sepvalid = true; return false; }
   dr = cross(p0.v, p1.v);
   if (norm(dr) < 1e-9f) {
-    *depth = norm(p1.v); *dirout = normalized(p1.v); *pos = (p1.v1 + p1.v2) * 0.5f;
+    *depth = norm(p1.v); *dirout = normalized(p1.v); *pos = p1.v1 - p1.v * 0.5f;
     return true;
   }
   dr = normalized(dr);
