@@ -153,6 +153,9 @@ int jaco_task_row_floats(void);
  * "auto_reset", where the task row already belongs to the new episode when jaco_step returns (the reference's accum_succ bookkeeping,
  * env_mujoco.py:129-136, reads succ in the terminal step).  Rows of envs that have not finished an episode yet are (0, 0). */
 int jaco_get_last_terminal(JacoHandle* h, float* out_dev, void* stream);
+/* ... and the observation of that terminal step, out_dev [num_envs][26] f32 (option "auto_reset": the env's obs_dev row already holds the new
+ * episode's first observation; a learner bootstrapping the value of a timed-out state needs the last one of the old episode). */
+int jaco_get_terminal_obs(JacoHandle* h, float* out_dev, void* stream);
 /* Marker poses [num_envs][2][12] f32: {"hand", "subgoal_reach"} x {position, rotation matrix row-major} -- the two mocap bodies
  * _take_action moves every env step (set_mocap_xyz / set_mocap_orientation, mujoco.py:248-256, env_mujoco_util.py:613-615,
  * 644-646).  Their contype-8 geoms collide with the EE axis sticks; jaco_step updates them in-kernel, jaco_reset* park

@@ -48,6 +48,7 @@ SYMBOLS = {
     "jaco_task_row_floats": (_ci, []),
     "jaco_get_markers": (_ci, [_vp, _vp, _vp]),
     "jaco_get_last_terminal": (_ci, [_vp, _vp, _vp]),
+    "jaco_get_terminal_obs": (_ci, [_vp, _vp, _vp]),
     "jaco_set_markers": (_ci, [_vp, _vp, _vp]),
     "jaco_set_frame_skip": (_ci, [_vp, _ci]),
     "jaco_physics_step_debug": (_ci, [_vp, _vp, _ci, _ci, ctypes.POINTER(ctypes.c_float), _ci]),

@@ -72,6 +72,7 @@ struct JacoHandle {
   int concurrent = 1, workers = 1024, workers_heavy = 256, workers_huge = 32, tier_return = 1, use_hints = 2, handdown = 1;   // options "concurrent_heavy", "heavy_workers", "hints"
   float *task_rows = nullptr, *cache = nullptr;
   float* terminal = nullptr;   // [num_envs][2] (success flag, wb) latched by every terminal step
+  float* terminal_obs = nullptr;   // [num_envs][26] observation of the terminal step (auto_reset)
   float* marker = nullptr;    // [num_envs][2][12] poses of the "hand" / "subgoal_reach" markers (mocap bodies the task layer moves)
   unsigned* cost = nullptr;   // per env: shader-clock ticks its last step took (>> 4)
   int* order = nullptr;       // launch order of the env-level light kernel: expensive envs first
@@ -194,6 +195,8 @@ extern "C" int jaco_create(const JacoConfig* cfg, JacoHandle** out) {
   CREATECHK(hipMalloc(&h->cache, B * JCACHE_N * sizeof(float)));
   CREATECHK(hipMalloc(&h->terminal, B * 2 * sizeof(float)));
   CREATECHK(hipMemset(h->terminal, 0, B * 2 * sizeof(float)));
+  CREATECHK(hipMalloc(&h->terminal_obs, B * 26 * sizeof(float)));
+  CREATECHK(hipMemset(h->terminal_obs, 0, B * 26 * sizeof(float)));
   CREATECHK(hipMemset(h->task_rows, 0, B * JTASK_N * sizeof(float)));
   CREATECHK(hipMemset(h->cache, 0, B * JCACHE_N * sizeof(float)));
   CREATECHK(hipMemcpy(h->model_dev, &h->model_host, sizeof(JacoModelDev), hipMemcpyHostToDevice));
@@ -239,7 +242,7 @@ extern "C" int jaco_destroy(JacoHandle* h) {
   }
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_pre) (void)hipEventDestroy(h->ev_pre);
-  void* ptrs[] = {h->model_dev, h->hull_dev, h->qpos, h->qvel, h->qacc_ws, h->qpos_lo, h->qvel_lo, h->sensordata, h->flags, h->stats, h->dbg, h->prof, h->remaining, h->qlist, h->qctl, h->hint, h->routed_mark, h->task_rows, h->cache, h->cost, h->order, h->marker, h->order_ctl, h->qpos0_dev, h->sepdir, h->terminal};
+  void* ptrs[] = {h->model_dev, h->hull_dev, h->qpos, h->qvel, h->qacc_ws, h->qpos_lo, h->qvel_lo, h->sensordata, h->flags, h->stats, h->dbg, h->prof, h->remaining, h->qlist, h->qctl, h->hint, h->routed_mark, h->task_rows, h->cache, h->cost, h->order, h->marker, h->order_ctl, h->qpos0_dev, h->sepdir, h->terminal, h->terminal_obs};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   delete h;
   return JACO_OK;
@@ -472,7 +475,7 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
   for (int t = 0; t < 3; t++) { A.q[t].list = h->qlist + (size_t)t * 2 * h->num_envs; A.q[t].count = h->qctl + JQ_COUNT + t; A.q[t].taken = h->qctl + JQ_TAKEN + t; A.q[t].limit = h->qctl + JQ_LIMIT + t; A.q[t].reserve = h->qctl + JQ_RESERVE + t; }
   A.routed_mark = nullptr; A.launch_id = ++h->launch_id;
   A.env_mode = io.mode; A.task_id = h->task; A.nact = (h->task == JACO_TASK_REACHING || h->task == JACO_TASK_PUSHING) ? 6 : 7; A.seed = h->seed;
-  A.task = h->task_rows; A.cache = h->cache; A.action = io.action; A.noise = h->noise; A.obs_mode = h->obs_mode; A.subgoal = h->subgoal; A.obs = io.obs; A.reward = io.reward; A.done = io.done; A.terminal = h->terminal; A.mask = io.mask; A.marker = h->marker;
+  A.task = h->task_rows; A.cache = h->cache; A.action = io.action; A.noise = h->noise; A.obs_mode = h->obs_mode; A.subgoal = h->subgoal; A.obs = io.obs; A.reward = io.reward; A.done = io.done; A.terminal = h->terminal; A.terminal_obs = h->terminal_obs; A.mask = io.mask; A.marker = h->marker;
   A.cost = h->cost;
   // auto-reset folds draws + sim.forward() + observation into the step wave: the tasks whose reset is nothing more (placing holds the
   // object for 150 substeps, grasping pre-reaches: those keep the explicit jaco_reset)
@@ -679,6 +682,12 @@ extern "C" int jaco_set_task_state(JacoHandle* h, const float* in_dev, void* str
   return JACO_OK;
 }
 extern "C" int jaco_task_row_floats(void) { return JTASK_N; }
+extern "C" int jaco_get_terminal_obs(JacoHandle* h, float* out_dev, void* stream) {
+  if (!h || !out_dev) return JACO_EINVAL;
+  ENTER(h);
+  HIPCHK(h, hipMemcpyAsync(out_dev, h->terminal_obs, (size_t)h->num_envs * 26 * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return JACO_OK;
+}
 extern "C" int jaco_get_last_terminal(JacoHandle* h, float* out_dev, void* stream) {
   if (!h || !out_dev) return JACO_EINVAL;
   ENTER(h);

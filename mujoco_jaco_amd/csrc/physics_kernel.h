@@ -137,6 +137,7 @@ struct JacoStepArgs {
   float* reward;             // [nenv]
   unsigned char* done;       // [nenv]
   float* terminal;           // [nenv][2] (success flag, wb) of the env's most recent terminal step (jaco_get_last_terminal), or nullptr
+  float* terminal_obs;       // [nenv][26] observation of that terminal step (auto_reset replaces the env's obs row with the new episode's first), or nullptr
   unsigned* cost;            // [nenv] shader-clock ticks (>> 4) the env's last step took (launch-order heuristic), or nullptr
   const int* order;          // light tier, optional: workgroup -> env permutation (expensive envs first), else identity
   const int* nslots;         // light tier, optional: [1] number of valid entries of `order` (masked resets launch a small grid over the list of reset envs), else nenv
@@ -2031,6 +2032,7 @@ again:
         else o = lane == 24 ? PI / 2.f : 0.f;
         if (!(fabsf(o) <= 3.0e38f)) o = 0.f;   // (quarantined env: the observation row stays finite)
         if (wt) st_wt(&A.obs[(size_t)env * 26 + lane], o); else A.obs[(size_t)env * 26 + lane] = o;
+        if (reset_now && A.terminal_obs) A.terminal_obs[(size_t)env * 26 + lane] = o;   // (what the learner's value bootstrap wants after a time-out)
       }
     }
     if (left == 0 && (emode == 3 || emode == 6) && lane == 0) { s.task[JT_SUB] = 0.f; s.task[JT_PENDING] = 0.f; }

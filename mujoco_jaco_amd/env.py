@@ -270,6 +270,12 @@ class JacoBatchedEnv:
         self.sim._chk(self.L.jaco_get_last_terminal(self.h, self._p(t), self.sim._stream()))
         return t[:, 0] > 0.5, t[:, 1]
 
+    def terminal_observation(self):
+        """[num_envs, 26]: the observation of every env's most recent terminal step under auto_reset (its obs row is the new episode's first)."""
+        t = torch.empty(self.num_envs, 26, device=self.device)
+        self.sim._chk(self.L.jaco_get_terminal_obs(self.h, self._p(t), self.sim._stream()))
+        return t
+
     def seed(self, seed):
         pass  # the reference's seed() is a no-op too (env_mujoco.py:163-164); pass `seed=` to the constructor instead
 

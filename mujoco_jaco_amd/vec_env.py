@@ -2,7 +2,8 @@
 drive (the reference trains through `model.learn(...)` on a single `JacoMujocoEnv`, main.py:172-178).
 
 `JacoVecEnv.step(actions)` returns `(obs [B,26], rewards [B], dones [B], infos)`; envs that finished are reset inside the
-call (masked `jaco_reset`), their returned observation is the first one of the new episode and the last observation of
+call (masked `jaco_reset`; with `auto_reset=True` -- tasks picking / reaching / pickAndplace / pushing -- inside `jaco_step` itself, no
+extra launches), their returned observation is the first one of the new episode and the last observation of
 the finished episode is kept in `infos["terminal_observation"]` rows, as SB's VecEnv does.  Everything stays on the GPU
 (`torch` tensors); `to_numpy=True` copies the four outputs to host arrays for learners that want numpy.
 """
@@ -39,7 +40,20 @@ class JacoVecEnv:
         obs, rew, done = obs.clone(), rew.clone(), done.clone()
         self.episode_returns += rew; self.episode_lengths += 1
         infos = {"terminal_observation": None, "episode_return": None, "episode_length": None, "is_success": None, "quarantined": 0}
-        if bool(done.any()):
+        if bool(done.any()) and self.env.auto_reset:
+            # the env was reset inside jaco_step (option auto_reset): obs already holds the new episodes' first observations; what the
+            # terminal step returned besides was latched by the kernel (jaco_get_terminal_obs / jaco_get_last_terminal)
+            bad = (self.env.sim.flags() & 8) != 0
+            if bool(bad.any()):
+                infos["quarantined"] = int((bad & done).sum().item())
+                self.quarantined_total += infos["quarantined"]
+                self.env.sim.clear_flags()
+            infos["terminal_observation"] = self.env.terminal_observation()[done]
+            infos["episode_return"] = self.episode_returns[done].clone()
+            infos["episode_length"] = self.episode_lengths[done].clone()
+            infos["is_success"] = self.env.last_terminal()[0][done]
+            self.episode_returns[done] = 0; self.episode_lengths[done] = 0
+        elif bool(done.any()):
             # envs whose state went non-finite end their episode inside jaco_step (reward 0, JACO_FLAG_NAN) and are reset here
             # with the others; the count is reported and their flag cleared (failure row)
             bad = (self.env.sim.flags() & 8) != 0

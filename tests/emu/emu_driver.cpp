@@ -44,6 +44,7 @@ static int emu_launch(JacoStepArgs A, int* heavy_envs) {
   A.sepdir = g_sep_cache ? g_sepdir.data() : nullptr;
   if (g_terminal.size() != (size_t)A.nenv * 2) g_terminal.assign((size_t)A.nenv * 2, 0.f);
   A.terminal = g_terminal.data();
+  A.terminal_obs = nullptr;
   A.obs_mode = g_obs_mode;
   std::vector<int> remaining(A.nenv, 0), lists(6 * (size_t)A.nenv, -1);
   int count[3] = {0, 0, 0}, taken[3] = {0, 0, 0}, light_left = A.nenv;

@@ -993,3 +993,32 @@ def test_contact_free_kernel_at_env_level_matches_the_general_kernel():
         (oa - ob).abs().max().item(), (qa - qb).abs().max().item(), (ra - rb).abs().max().item()))
     assert torch.equal(da, db) and torch.isfinite(oa).all()
     assert (oa - ob).abs().max().item() < 1e-4 and (qa - qb).abs().max().item() < 1e-4
+
+
+def test_vec_env_adapter_with_the_in_kernel_reset():
+    """JacoVecEnv(auto_reset=True): finished envs are reset inside jaco_step (no reset launch chain); the terminal observation and the success
+    flag come from the kernel's latches (jaco_get_terminal_obs / jaco_get_last_terminal).  Everything the adapter returns -- observations,
+    rewards, dones, terminal observations, success flags, episode lengths -- equals the explicit-reset adapter's, bit for bit."""
+    from mujoco_jaco_amd.vec_env import JacoVecEnv
+    B = 256
+    outs = []
+    for auto in (True, False):
+        venv = JacoVecEnv(B, task="picking", frame_skip=4, seed=9, auto_reset=auto)
+        assert venv.env.auto_reset == auto
+        venv.reset()
+        t = venv.env.task_state(); t[:64, 1] = 697; t[64:96, 1] = 698; venv.env.set_task_state(t)   # two groups of time-outs, one step apart
+        gen = torch.Generator(device=venv.env.device); gen.manual_seed(1)
+        rec = []
+        for s in range(4):
+            o, r, d, info = venv.step(torch.rand(B, 7, device=venv.env.device, generator=gen) * 2 - 1)
+            rec.append((o.clone(), r.clone(), d.clone(), info["terminal_observation"], info["is_success"], info["episode_length"]))
+        outs.append(rec)
+        venv.close()
+    ends = 0
+    for x, y in zip(*outs):
+        for u, v in zip(x, y):
+            assert (u is None) == (v is None)
+            if u is not None:
+                assert torch.equal(u, v)
+        ends += int(x[2].sum())
+    assert ends == 96
