@@ -508,13 +508,13 @@ JDEV bool mpr_penetration(const JacoStepArgs& A, const JacoModelDev* m, const Mp
 // ---------------------------------------------------------------- stage C
 // Pair list of the bounding-sphere phase (temporal coherence across the substeps of a launch).  Geoms move well under a
 // millimetre per 1 ms substep, yet the phase used to test all ~720 whitelisted pairs every substep.  A full pass now also lists,
-// in pair order, the pairs whose sphere gap is below JACO_PAIRLIST_SLACK (lane l keeps entries l, l + 64, ... in registers) and
+// in pair order, the pairs whose sphere gap is below JACO_PAIRLIST_SLACK (1.5 cm; lane l keeps entries l, l + 64, ... in registers) and
 // remembers where every geom was; a later substep runs the SAME exact test on the listed pairs only, as long as no geom centre has
 // moved further than 0.45 x slack since (an unlisted pair then still has a gap of a tenth of the slack: it would fail the exact test
 // by millimetres).  The survivors -- and through them every contact -- are identical to those of the all-pairs pass; the marker
 // geoms that _take_action moves and a reset trigger the rebuild through the same displacement test.
 #ifndef JACO_PAIRLIST_SLACK
-#define JACO_PAIRLIST_SLACK 0.03f
+#define JACO_PAIRLIST_SLACK 0.015f
 #endif
 template <class C>
 struct PairList {
