@@ -2,6 +2,7 @@
 # The round's whole profile set in one GPU call (run on the GPU box; every step bounded): stage profiles (headline, policy-driven and
 # contact-free regimes), the ms/step curve over a 1 000-step rollout, rocprofv3 kernel trace of the default bench command, PMC passes, and
 # the default bench line itself.  Outputs under gpurun_out/; tools/install_profiles.sh copies them into profiles/ with the round's prefix.
+# Needs the diagnostic twin of the library, built here first:  python __graft_entry__.py variant prof
 set -o pipefail
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
 timeout -k 10 200 python3 $R/tools/gpu_stage_profile.py 16384 50 --env > $O/stage_profile.txt 2>&1 || exit 1
