@@ -300,6 +300,14 @@ JDEV void collide_box_box4(const JacoModelDev* m, L& s, int cbase, int nrows, in
 struct Sup { v3 v, v1; };   // a point of the Minkowski difference G1 - G2 and its witness on G1 (the one on G2 is v1 - v: not kept -- the routine is the kernel's register hot spot)
 // Everything a support query needs about one geom, fetched once per candidate pair.
 struct MprGeom { GeomPose P; v3 size; int type, adr, nvert, cellR, celladr; };
+#ifdef JACO_ROW_REUSE   // A/B build: a hull's support-table row is kept while consecutive queries fall into the same cube-map cell
+struct HullRow { int cell; v4 e; };
+#define JROWARG , HullRow& H1, HullRow& H2
+#define JROWPASS , H1, H2
+#else
+#define JROWARG
+#define JROWPASS
+#endif
 template <class L>
 JDEV MprGeom mpr_geom(const JacoModelDev* m, const L& s, int g, int type) {
   MprGeom G;
@@ -334,7 +342,7 @@ JDEV v3 support_prim(const MprGeom& G, v3 l) {   // box / sphere, local frame
 // are scanned in one loop (64 lanes x float4 loads, both geoms' loads in flight together); every lane keeps the coordinates
 // of its own best vertex, so after the DPP argmax the winner is broadcast from its lane instead of being re-fetched from
 // memory.  Lowest vertex index wins ties (a serial first-max scan), as in support_geom.
-JDEV Sup mpr_support(const JacoStepArgs& A, const MprGeom& G1, const MprGeom& G2, v3 dir, int lane) {
+JDEV Sup mpr_support(const JacoStepArgs& A, const MprGeom& G1, const MprGeom& G2, v3 dir, int lane JROWARG) {
 #ifdef JACO_EMULATED
   if (lane == 0) emu_counter[7]++;
 #endif
@@ -347,12 +355,24 @@ JDEV Sup mpr_support(const JacoStepArgs& A, const MprGeom& G1, const MprGeom& G2
   int bi1 = 0x7fffffff, bi2 = 0x7fffffff;
   v3 c1 = mk3(0.f, 0.f, 0.f), c2 = mk3(0.f, 0.f, 0.f);
   if (tab1) {
+#ifdef JACO_ROW_REUSE
+    const int cell1 = wave_uniform_i(cube_cell(l1, G1.cellR));
+    if (cell1 != H1.cell) { H1.e = ld4(A.hull + 4 * ((size_t)G1.celladr + (size_t)cell1 * 64 + lane)); H1.cell = cell1; }
+    const v4 e = H1.e;
+#else
     const v4 e = ld4(A.hull + 4 * ((size_t)G1.celladr + (size_t)cube_cell(l1, G1.cellR) * 64 + lane));
+#endif
     const int id = __builtin_bit_cast(int, e.w);
     if (id >= 0) { best1 = e.x * l1.x + e.y * l1.y + e.z * l1.z; bi1 = id; c1 = mk3(e.x, e.y, e.z); }
   }
   if (tab2) {
+#ifdef JACO_ROW_REUSE
+    const int cell2 = wave_uniform_i(cube_cell(l2, G2.cellR));
+    if (cell2 != H2.cell) { H2.e = ld4(A.hull + 4 * ((size_t)G2.celladr + (size_t)cell2 * 64 + lane)); H2.cell = cell2; }
+    const v4 e = H2.e;
+#else
     const v4 e = ld4(A.hull + 4 * ((size_t)G2.celladr + (size_t)cube_cell(l2, G2.cellR) * 64 + lane));
+#endif
     const int id = __builtin_bit_cast(int, e.w);
     if (id >= 0) { best2 = e.x * l2.x + e.y * l2.y + e.z * l2.z; bi2 = id; c2 = mk3(e.x, e.y, e.z); }
   }
@@ -444,14 +464,14 @@ JDEV v3 mpr_find_pos(const Sup& p0, const Sup& p1, const Sup& p2, const Sup& p3)
 // On a miss that ended on a support test (the support of G1 - G2 along `dr` does not reach past the origin) *sep = dr: a separating
 // direction, which the caller caches for the pair (stage_collision, "separating directions").
 JDEV bool mpr_penetration(const JacoStepArgs& A, const JacoModelDev* m, const MprGeom& G1, const MprGeom& G2, int lane,
-                          float* depth, v3* dirout, v3* pos, v3* sep, bool* sepvalid) {
+                          float* depth, v3* dirout, v3* pos, v3* sep, bool* sepvalid JROWARG) {
   Sup p0, p1, p2, p3, v4;
   float tol = m->mpr_tolerance;
   *sepvalid = false;
   p0.v1 = G1.P.p; p0.v = p0.v1 - G2.P.p;
   if (norm(p0.v) < 1e-9f) p0.v.x = 1e-5f;
   v3 dr = normalized(-p0.v);
-  p1 = mpr_support(A, G1, G2, dr, lane);
+  p1 = mpr_support(A, G1, G2, dr, lane JROWPASS);
   if (dot(p1.v, dr) <= 0.f) { *sep = dr; *sepvalid = true; return false; }
   dr = cross(p0.v, p1.v);
   if (norm(dr) < 1e-9f) {
@@ -459,13 +479,13 @@ JDEV bool mpr_penetration(const JacoStepArgs& A, const JacoModelDev* m, const Mp
     return true;
   }
   dr = normalized(dr);
-  p2 = mpr_support(A, G1, G2, dr, lane);
+  p2 = mpr_support(A, G1, G2, dr, lane JROWPASS);
   if (dot(p2.v, dr) <= 0.f) { *sep = dr; *sepvalid = true; return false; }
   dr = normalized(cross(p1.v - p0.v, p2.v - p0.v));
   if (dot(dr, p0.v) > 0.f) { Sup t = p1; p1 = p2; p2 = t; dr = -dr; }
   for (int it = 0;; it++) {
     if (it > 100) return false;
-    p3 = mpr_support(A, G1, G2, dr, lane);
+    p3 = mpr_support(A, G1, G2, dr, lane JROWPASS);
     if (dot(p3.v, dr) <= 0.f) { *sep = dr; *sepvalid = true; return false; }
     bool cont = false;
     if (dot(cross(p1.v, p3.v), p0.v) < -1e-11f) { p2 = p3; cont = true; }
@@ -476,14 +496,14 @@ JDEV bool mpr_penetration(const JacoStepArgs& A, const JacoModelDev* m, const Mp
   for (int it = 0;; it++) {
     dr = portal_dir(p1, p2, p3);
     if (dot(dr, p1.v) >= 0.f) break;
-    v4 = mpr_support(A, G1, G2, dr, lane);
+    v4 = mpr_support(A, G1, G2, dr, lane JROWPASS);
     if (dot(v4.v, dr) < 0.f) { *sep = dr; *sepvalid = true; return false; }
     if (reach_tol(p1, p2, p3, v4, dr, tol) || it > m->mpr_iterations) return false;
     expand_portal(p0, p1, p2, p3, v4);
   }
   for (int it = 0;; it++) {
     dr = portal_dir(p1, p2, p3);
-    v4 = mpr_support(A, G1, G2, dr, lane);
+    v4 = mpr_support(A, G1, G2, dr, lane JROWPASS);
     if (reach_tol(p1, p2, p3, v4, dr, tol) || it > m->mpr_iterations) {
       if (m->mpr_output == 1) {
         // Portal-plane output: the refined portal lies (within mpr_tolerance) in the face of the Minkowski difference that the
@@ -718,16 +738,20 @@ JDEV void stage_collision(const JacoStepArgs& A, const JacoModelDev* m, L& s, in
         const long q0_ = emu_counter[7];
 #endif
         const MprGeom G1 = mpr_geom(m, s, g1, t1), G2 = mpr_geom(m, s, g2, t2);
+#ifdef JACO_ROW_REUSE
+        HullRow H1, H2;
+        H1.cell = -1; H2.cell = -1; H1.e.x = H1.e.y = H1.e.z = H1.e.w = 0.f; H2.e = H1.e;
+#endif
         const float sw = wave_bcast(sepA.w, c);
         bool hit = false, apart = false, sepvalid = false;
         v3 sep = mk3(0.f, 0.f, 0.f);
         if (sw != 0.f) {   // (wave-uniform)
           const v3 d = mk3(wave_bcast(sepA.x, c), wave_bcast(sepA.y, c), wave_bcast(sepA.z, c));
-          const Sup q = mpr_support(A, G1, G2, d, lane);
+          const Sup q = mpr_support(A, G1, G2, d, lane JROWPASS);
           apart = dot(q.v, d) < -1e-5f && fabsf(dot(d, d) - 1.f) < 1e-3f;
         }
         if (!apart) {
-          hit = mpr_penetration(A, m, G1, G2, lane, &depth, &dir, &pos, &sep, &sepvalid);
+          hit = mpr_penetration(A, m, G1, G2, lane, &depth, &dir, &pos, &sep, &sepvalid JROWPASS);
           if (seprow && lane == 0 && (sepvalid || sw != 0.f)) {
             v4 o; o.x = sep.x; o.y = sep.y; o.z = sep.z; o.w = sepvalid ? 1.f : 0.f;
             *reinterpret_cast<v4*>(seprow + 4 * pk) = o;
