@@ -65,8 +65,8 @@ _libs = {}
 
 
 def load(variant=""):
-    """variant "": the default layout (11 fused bodies, 21 dofs in blocks 9 + 6 + 6); "_d12": the build for jaco2_torque.xml;
-    "_d30": the build for jaco2_dual_torque.xml."""
+    """variant "": the default layout (11 fused bodies, 21 dofs in blocks 9 + 6 + 6); "_d12": the build for jaco2_torque.xml and jaco2_curtain_torque_sensor.xml
+    (12 hinge dofs in one tree + at most one free object); "_d30": the build for jaco2_dual_torque.xml."""
     if variant not in _libs:
         path = LIB_PATH if not variant else os.path.join(_HERE, "libjaco_env%s.so" % variant)
         if not os.path.exists(path):
@@ -85,9 +85,12 @@ def variant_for(blob_bytes):
     """Which build of the library steps this model: the loader of each build rejects models outside its compiled layout."""
     from .modelc import blob as blobmod
     M = blobmod.loads(blob_bytes)
-    if int(M["nv"][0]) > 21 or int(M["f_nbody"][0]) > 12:
+    nv, nb = int(M["nv"][0]), int(M["f_nbody"][0])
+    if nv > 21 or nb > 13:
         return "_d30"   # jaco2_dual_torque.xml: two arms + two objects (30 dofs, 20 fused bodies); sim-interface (ctrl) level only
-    return "_d12" if (int(M["nv"][0]) == 12 and int(M["f_nbody"][0]) == 12) else ""
+    # the 12-hinge arm (proximal + distal finger joints in the arm's tree), alone (jaco2_torque.xml) or with one free object
+    # (jaco2_curtain_torque_sensor.xml: 13 fused bodies, 18 dofs); sim-interface level
+    return "_d12" if (nv, nb) in ((12, 12), (18, 13)) else ""
 
 
 def model_path(name):

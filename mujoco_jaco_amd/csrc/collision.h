@@ -333,8 +333,12 @@ JDEV int cube_cell(v3 d, int R) {
   iv = iv < 0 ? 0 : (iv > R - 1 ? R - 1 : iv);
   return (face * R + iu) * R + iv;
 }
-JDEV v3 support_prim(const MprGeom& G, v3 l) {   // box / sphere, local frame
+JDEV v3 support_prim(const MprGeom& G, v3 l) {   // box / cylinder / sphere, local frame
   if (G.type == JG_BOX) return mk3(l.x > 0.f ? G.size.x : -G.size.x, l.y > 0.f ? G.size.y : -G.size.y, l.z > 0.f ? G.size.z : -G.size.z);
+  if (G.type == JG_CYLINDER) {   // radius size.x, half height size.y, axis z: rim point towards the direction's radial part
+    const float rr = sqrtf(l.x * l.x + l.y * l.y), k = rr > JMINVAL ? G.size.x / rr : 0.f;
+    return mk3(l.x * k, l.y * k, l.z > 0.f ? G.size.y : -G.size.y);
+  }
   float n = norm(l);
   return l * (n > JMINVAL ? G.size.x / n : 0.f);
 }

@@ -5,8 +5,10 @@
 #pragma once
 
 // Layout of the default build (jaco2_curtain_torque.xml and everything that fits inside it, e.g. the arm-only jaco2_reaching_torque.xml).
-// A second build of the same sources with -DJNB=12 -DJNV=12 -DJNQ=12 -DJB0=12 -DJB1=12 (libjaco_env_d12.so, __graft_entry__.build) serves
-// jaco2_torque.xml: 6 arm + 6 finger hinges (proximal + sprung distal, xml:109-133) in one kinematic tree, no free bodies.
+// A second build of the same sources with -DJNB=13 -DJNV=18 -DJNQ=19 -DJB0=12 -DJB1=18 -DJNSENS=64 (libjaco_env_d12.so, __graft_entry__.build)
+// serves the 12-hinge arm -- 6 arm + 6 finger hinges (proximal + sprung distal, jaco2_torque.xml:109-133) in one kinematic tree -- alone
+// (jaco2_torque.xml) or with one free object (jaco2_curtain_torque_sensor.xml: static cylinder geoms, 61 touch sensors;
+// jaco2_curtain_torque_old.xml).
 #ifndef JNB
 #define JNB 11        // moving (fused) bodies: 6 links, 3 fingers, object, destination pedestal
 #define JNV 21        // dofs

@@ -219,8 +219,9 @@ int jaco_model_from_blob(const void* buf, size_t size, JacoModelDev* m, std::vec
       JacoPairObb& Q = m->pair_obb[k];
       Q.code = m->pair_code[k]; Q.pad = 0;
       for (int i = 0; i < 3; i++) {
-        Q.sa[i] = gty[g1] == JG_SPHERE ? m->g_size[g1][0] : m->g_size[g1][i];
-        Q.sb[i] = gty[g2] == JG_SPHERE ? m->g_size[g2][0] : m->g_size[g2][i];
+        // box half sizes for the OBB cull: a sphere's (r, r, r), a cylinder's (r, r, h)
+        Q.sa[i] = gty[g1] == JG_SPHERE ? m->g_size[g1][0] : (gty[g1] == JG_CYLINDER ? m->g_size[g1][i < 2 ? 0 : 1] : m->g_size[g1][i]);
+        Q.sb[i] = gty[g2] == JG_SPHERE ? m->g_size[g2][0] : (gty[g2] == JG_CYLINDER ? m->g_size[g2][i < 2 ? 0 : 1] : m->g_size[g2][i]);
       }
     }
     const int b1 = m->g_body[g1], b2 = m->g_body[g2];

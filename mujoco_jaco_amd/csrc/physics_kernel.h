@@ -1185,7 +1185,8 @@ JDEV NewtonOut stage_newton(const JacoModelDev* m, L& s, const float (&mrow)[JNV
       float cv = ((j2 >> 2) & 1) ? wave_shfl(C.v[reg], (lane + 32) & 63) : C.v[reg];
       h[j2] = lane < nv ? mrow[j2] + cv : (lane == j2 ? 1.f : 0.f);
     }
-    jtf = wave_shfl(C.v[(JNV & 3) + 4 * (JNV >> 3)], (lane + 32) & 63);   // row 21 sits in the upper lane half
+    // row JNV = J^T f (default layout: row 21, which sits in the upper lane half)
+    jtf = ((JNV >> 2) & 1) ? wave_shfl(C.v[(JNV & 3) + 4 * (JNV >> 3)], (lane + 32) & 63) : C.v[(JNV & 3) + 4 * (JNV >> 3)];
     }
     float grad = Ma - (lane < nv ? jtf : 0.f);
     float gn = sqrtf(wave_sum(grad * grad));

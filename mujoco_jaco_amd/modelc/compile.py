@@ -56,6 +56,9 @@ def _geom_points(M, g, xpos, xquat):
         return p + c @ R.T, 0.0
     if t == mjcf.GEOM_SPHERE:
         return p[None, :], float(sz[0])
+    if t == mjcf.GEOM_CYLINDER:   # the corners of the enclosing box (r, r, h): a superset, which is what a "can never touch" proof may use
+        c = np.array([[sx, sy, sz_] for sx in (-1, 1) for sy in (-1, 1) for sz_ in (-1, 1)]) * np.array([sz[0], sz[0], sz[1]])
+        return p + c @ R.T, 0.0
     return None, 0.0
 
 
@@ -318,8 +321,11 @@ def compile_model(xml_name, timestep=0.001):
 def main():
     os.makedirs(OUT_DIR, exist_ok=True)
     # jaco2_torque: 6 arm + 6 finger hinges (sprung distal joints), no free bodies -- stepped by the d12 build of the library;
-    # jaco2_dual_torque: two arms + two objects (30 dofs, 106 geoms, 3 332 pairs) -- stepped by the d30 build (ctrl level)
-    for xml_name in ("jaco2_curtain_torque", "jaco2_reaching_torque", "jaco2_torque", "jaco2_dual_torque"):
+    # jaco2_dual_torque: two arms + two objects (30 dofs, 106 geoms, 3 332 pairs) -- stepped by the d30 build (ctrl level);
+    # jaco2_curtain_torque_sensor: the 12-hinge arm + one free object + five static cylinders, 61 touch sensors -- d12 build (ctrl level);
+    # jaco2_curtain_torque_old: the same arm + object among 22 static boxes, 20 touch sensors -- d12 build (ctrl level)
+    for xml_name in ("jaco2_curtain_torque", "jaco2_reaching_torque", "jaco2_torque", "jaco2_dual_torque", "jaco2_curtain_torque_sensor",
+                     "jaco2_curtain_torque_old"):
         M, names = compile_model(xml_name)
         path = os.path.join(OUT_DIR, xml_name + ".jacomdl")
         blob.save(path, M)

@@ -66,6 +66,15 @@ def _frame(el):
         quat = rot.quat_normalize(_floats(el.get("quat")))
     elif el.get("euler") is not None:
         quat = rot.euler_xyz_quat(_floats(el.get("euler")))
+    elif el.get("zaxis") is not None:
+        # [EXT] MuJoCo: the minimal rotation that takes (0, 0, 1) to the given axis (jaco2_curtain_torque_sensor.xml:73: the curtain rod)
+        z = _floats(el.get("zaxis")); z = z / np.linalg.norm(z)
+        ax = np.cross([0.0, 0.0, 1.0], z); sn, cs = np.linalg.norm(ax), z[2]
+        if sn < 1e-12:
+            quat = np.array([1.0, 0, 0, 0]) if cs > 0 else np.array([0.0, 1.0, 0, 0])
+        else:
+            half = 0.5 * np.arctan2(sn, cs)
+            quat = np.concatenate([[np.cos(half)], np.sin(half) * ax / sn])
     else:
         quat = np.array([1.0, 0, 0, 0])
     return pos, quat
@@ -148,6 +157,11 @@ def parse(xml_path, timestep=None):
             g["mass"] = density * 4 / 3 * np.pi * r ** 3
             g["inertia"] = np.full(3, 0.4 * g["mass"] * r * r)
             g["rbound"] = float(r)
+        elif g["type"] == GEOM_CYLINDER:   # size = (radius, half height), axis = local z
+            r, h = g["size"][0], g["size"][1]
+            g["mass"] = density * np.pi * r * r * 2 * h
+            g["inertia"] = g["mass"] * np.array([r * r / 4 + h * h / 3, r * r / 4 + h * h / 3, r * r / 2])
+            g["rbound"] = float(np.hypot(r, h))
         elif g["type"] == GEOM_PLANE:
             g["mass"], g["inertia"], g["rbound"] = 0.0, np.zeros(3), 0.0
         else:

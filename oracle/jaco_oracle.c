@@ -561,6 +561,11 @@ static void support_geom(const OrcModel* m, const OrcData* d, int g, const doubl
   switch (m->geom_type[g]) {
     case G_SPHERE: { double n = norm3(l); scl3(s, l, n > MINVAL ? sz[0] / n : 0); break; }
     case G_BOX: for (int i = 0; i < 3; i++) s[i] = l[i] > 0 ? sz[i] : -sz[i]; break;
+    case G_CYLINDER: { /* radius sz[0], half height sz[1], axis z [EXT: mjc_Convex treats cylinders through their support function] */
+      double rr = sqrt(l[0] * l[0] + l[1] * l[1]), k = rr > MINVAL ? sz[0] / rr : 0;
+      s[0] = l[0] * k; s[1] = l[1] * k; s[2] = l[2] > 0 ? sz[1] : -sz[1];
+      break;
+    }
     case G_MESH: {
       int md = m->geom_dataid[g], n = m->mesh_vertnum[md];
       const double* v = m->mesh_vert + 3 * m->mesh_vertadr[md];

@@ -43,7 +43,8 @@ class EmuEnv:
         self.blob = open(os.path.join(ASSETS, model + ".jacomdl"), "rb").read()
         from mujoco_jaco_amd.modelc import blob as blobmod
         M = blobmod.loads(self.blob)
-        self.L = lib("_d30" if int(M["nv"][0]) > 21 else ("" if (int(M["f_nbody"][0]) <= 11 and int(M["nv"][0]) != 12) else "_d12"))
+        from mujoco_jaco_amd import _lib as product_lib
+        self.L = lib(product_lib.variant_for(self.blob))   # (the same layout choice as the product's loader)
         self.M = M
         self.nq, self.nv, self.nu, self.ns = int(M["nq"][0]), int(M["nv"][0]), int(M["nu"][0]), int(M["nsensor"][0])
         self.nenv = nenv

@@ -288,6 +288,64 @@ def test_jaco2_torque_sibling_model_on_the_d12_build():
     assert np.median(eq) < 4e-7 and eq.max() < 1.2e-5 and ev.max() < 2e-4   # 3x measured (1.2e-7 / 4.0e-6 / 5.8e-5; up to 11 limit rows, 1 contact)
 
 
+def test_sensor_model_with_cylinder_geoms_on_the_d12_build():
+    """jaco2_curtain_torque_sensor.xml (the 12-hinge arm + one free object + 61 touch sensors; the assets' only cylinder geoms: xml:62-74
+    posts and rod, xml:278-281 the object holder's stem and disc) stepped by libjaco_env_d12.so at the sim-interface level against the fp64
+    oracle.  (A) 256 envs: the object box dropped, tilted, onto the holder's disc (box-cylinder contacts through the convex-convex path)
+    while the arm moves under random torques, 100 substeps free-running; (B) the arm-on-cylinder poses of
+    tests/golden/sensor_post_poses.npz, one substep from identical state: contact / row counts and touch readings as the oracle's."""
+    import os
+    from mujoco_jaco_amd import _lib
+    from mujoco_jaco_amd.modelc import blob
+    from oracle_binding import Oracle
+    M = blob.load(_lib.model_path("jaco2_curtain_torque_sensor"))
+    B, nsub = 256, 100
+    rng = np.random.default_rng(79)
+    q = np.tile(M["qpos0"], (B, 1))
+    q[:, :6] = rng.uniform([0.7, 3.8, 1.0, 1.8, 1.0, 0.8], [2.5, 4.0, 1.7, 2.5, 2.5, 2.3], (B, 6))
+    q[:, 6:12:2] = rng.uniform(0.0, 1.0, (B, 3)); q[:, 7:12:2] = rng.uniform(-0.3, 0.3, (B, 3))
+    q[:, 12:15] = np.array([0.0, 0.65, 0.445]) + rng.uniform(-1, 1, (B, 3)) * [0.04, 0.04, 0.002]
+    quat = np.concatenate([np.ones((B, 1)), rng.uniform(-0.1, 0.1, (B, 3))], 1); q[:, 15:19] = quat / np.linalg.norm(quat, axis=1, keepdims=True)
+    q = q.astype(np.float32).astype(np.float64)
+    c = np.concatenate([rng.uniform(-1, 1, (B, 6)) * np.array([30, 30, 30, 15, 15, 15]) * 0.2, rng.uniform(0, 1.0, (B, 3))], 1).astype(np.float32).astype(np.float64)
+    env = _env(B, "jaco2_curtain_torque_sensor")
+    assert (env.nq, env.nv, env.nu) == (19, 18, 9)
+    env.set_state(_t(q, env.device), None, None)
+    env.send_forces(_t(c, env.device), nsub=nsub)
+    gq, gv, _ = [t.cpu().numpy().astype(np.float64) for t in env.get_state()]
+    gst = env.stats().cpu().numpy()
+    o = Oracle("jaco2_curtain_torque_sensor")
+    qo, vo, wo = q.copy(), np.zeros((B, 18)), np.zeros((B, 18))
+    st = np.zeros((B, 4), np.int32)
+    o.step_batch(qo, vo, wo, np.ascontiguousarray(c), nsub=nsub, nthreads=16, stats=st)
+    eq, ev = np.abs(gq - qo).max(1), np.abs(gv - vo).max(1)
+    print("sensor model, %d substeps: qpos err median %.2e p90 %.2e max %.2e, qvel err max %.2e; oracle rows %d..%d, contacts up to %d; same row count in %d of %d envs" % (
+        nsub, np.median(eq), np.percentile(eq, 90), eq.max(), ev.max(), st[:, 1].min(), st[:, 1].max(), st[:, 0].max(), int((gst[:, 1] == st[:, 1]).sum()), B))
+    assert (env.flags().cpu().numpy() & 15).max() == 0 and (st[:, 0] >= 1).mean() > 0.9   # the box is on the disc in (nearly) every env
+    assert np.median(eq) < 1e-6 and np.percentile(eq, 90) < 1e-5 and eq.max() < 1e-3
+    # (B) arm-on-cylinder poses, one substep
+    P = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sensor_post_poses.npz"))["qpos"]
+    n = len(P)
+    q2 = q.copy(); q2[:n] = P
+    c2 = c.copy(); c2[:, :6] *= 0.5
+    env.set_state(_t(q2, env.device), torch.zeros(B, 18, device=env.device), torch.zeros(B, 18, device=env.device))
+    env.clear_flags()
+    env.send_forces(_t(c2, env.device), nsub=1)
+    gq, gv, _ = [t.cpu().numpy().astype(np.float64) for t in env.get_state()]
+    gst = env.stats().cpu().numpy()
+    gs = env.sensordata().cpu().numpy()
+    qo, vo, wo = q2.copy(), np.zeros((B, 18)), np.zeros((B, 18))
+    so = np.zeros((B, int(M["nsensor"][0])))
+    o.step_batch(qo, vo, wo, np.ascontiguousarray(c2), nsub=1, nthreads=16, stats=st, sensordata=so)
+    eq = np.abs(gq - qo).max(1)[:n]
+    print("sensor model, %d arm-on-cylinder poses, one substep: contacts %s rows %s | qpos err median %.2e max %.2e | touch err max %.2e (readings up to %.1f)" % (
+        n, st[:n, 0].tolist(), st[:n, 1].tolist(), np.median(eq), eq.max(), np.abs(gs[:n] - so[:n]).max(), so[:n].max()))
+    assert np.array_equal(gst[:n, :2], st[:n, :2])
+    assert (env.flags().cpu().numpy()[:n] & 15).max() == 0 and st[:n, 0].min() >= 2
+    assert np.median(eq) < 1e-6 and eq.max() < 1e-5
+    assert np.abs(gs[:n] - so[:n]).max() < 1e-3 * max(1.0, so[:n].max())
+
+
 def test_dual_arm_model_on_the_d30_build():
     """jaco2_dual_torque.xml (xml:48-49: two arms included side by side; 30 dofs, 106 geoms, 3 332 pairs, 18 actuators) stepped
     by libjaco_env_d30.so -- the same kernel sources compiled for that layout -- at the sim-interface (ctrl) level, against the fp64 oracle.

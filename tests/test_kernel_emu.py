@@ -180,6 +180,65 @@ def test_jaco2_torque_model_on_the_d12_build_matches_oracle():
     assert np.abs(o.get("qfrc_passive")[6:]).max() > 0.005           # ... and the springs / dampers are at work at the end
 
 
+def test_sensor_model_with_cylinder_geoms_on_the_d12_build_matches_oracle():
+    """Sibling MJCF jaco2_curtain_torque_sensor.xml: the 12-hinge arm of jaco2_torque.xml + one free object + 61 touch sensors, and the
+    only cylinder geoms among the reference's loadable assets (xml:62-74 the blocker's posts and rod, the rod turned by `zaxis`; xml:278-281
+    the object holder's stem and disc).  Cylinders go through the convex-convex path (support function: rim point towards the direction's
+    radial part).  Stepped by the d12 build (13 bodies / 18 dofs in blocks 12 + 6) against the fp64 oracle: (A) the object box dropped,
+    slightly tilted, onto the holder's disc -- box-cylinder contact, 300 substeps free-running; (B) poses in which an arm hull touches a
+    post / the stem / the disc (tests/golden/sensor_post_poses.npz), single steps re-synchronised: same contact and row counts."""
+    import os
+    from emu_binding import EmuEnv
+    from oracle_binding import Oracle
+    o = Oracle("jaco2_curtain_torque_sensor"); e = EmuEnv("jaco2_curtain_torque_sensor")
+    assert (e.nq, e.nv, e.nu, e.ns) == (19, 18, 9, 61)
+    assert sorted(np.unique(e.M["geom_type"]).tolist()) == [0, 2, 5, 6, 7]
+    q = e.M["qpos0"].copy(); q[12:15] = [0.02, 0.66, 0.445]; q[15:19] = np.array([1, 0.05, -0.03, 0.1]) / np.linalg.norm([1, 0.05, -0.03, 0.1])
+    q = q.astype(np.float32).astype(np.float64)
+    e.qpos[0] = q; o.set("qpos", q); o.set("qvel", np.zeros(18)); o.set("qacc_warmstart", np.zeros(18))
+    c = np.array([1.0, -2.0, 1.0, 0.5, -0.5, 0.2, 0.3, 0.3, 0.3])
+    touched = 0
+    for k in range(12):                                                     # (A)
+        e.step(c, nsub=25); o.step(c, n=25)
+        assert (e.stats[0, 0], e.stats[0, 1]) == (o.ncon, o.nefc) and not (e.flags[0] & 31), (k, e.stats[0], o.ncon, o.nefc)
+        touched += o.ncon
+        assert np.abs(e.qpos[0] - o.get("qpos")).max() < 2e-6 and np.abs(e.qvel[0] - o.get("qvel")).max() < 2e-4, k
+    assert touched >= 10
+    P = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sensor_post_poses.npz"))["qpos"]
+    rng = np.random.default_rng(3)
+    errs = []
+    for q in P[:8]:                                                         # (B)
+        o.reset(); o.set("qpos", q); o.set("qvel", np.zeros(18)); o.set("qacc_warmstart", np.zeros(18))
+        e.flags[0] = 0
+        ctrl = np.concatenate([rng.uniform(-1, 1, 6) * 3, [0.5] * 3])
+        for i in range(4):
+            eq, ev = _sync_step(o, e, ctrl)
+            assert (e.stats[0, 0], e.stats[0, 1]) == (o.ncon, o.nefc) and o.ncon >= 2, (i, e.stats[0], o.ncon, o.nefc)
+            errs.append(eq)
+        assert (e.flags[0] & 31) == 0
+        assert np.abs(o.get("sensordata") - e.sensordata[0]).max() < 1e-3 * max(1.0, np.abs(o.get("sensordata")).max())
+    print("sensor model, arm-on-cylinder poses: single-step qpos error median %.1e max %.1e" % (np.median(errs), max(errs)))
+    assert np.median(errs) < 1e-6 and max(errs) < 1e-4
+
+
+def test_curtain_old_model_on_the_d12_build_matches_oracle():
+    """Sibling MJCF jaco2_curtain_torque_old.xml: the 12-hinge arm + one free object among 22 static boxes, 20 touch sensors; its rest pose
+    has the distal finger joints beyond their range (limit rows from the first step).  d12 build, 60 single steps re-synchronised with the
+    oracle, the object lying on the floor: same contact and row counts every step."""
+    o = Oracle("jaco2_curtain_torque_old"); e = EmuEnv("jaco2_curtain_torque_old")
+    assert (e.nq, e.nv, e.nu, e.ns) == (19, 18, 9, 20)
+    q = e.M["qpos0"].copy(); q[12:15] = [0.3, 0.3, 0.0301]
+    q = q.astype(np.float32).astype(np.float64)
+    o.set("qpos", q); o.set("qvel", np.zeros(18)); o.set("qacc_warmstart", np.zeros(18))
+    c = np.array([3., -5., 2., 1., -1., 0.5, 0.5, 0.5, 0.5])
+    worst, rows = 0.0, 0
+    for k in range(60):
+        eq, ev = _sync_step(o, e, c)
+        assert (e.stats[0, 0], e.stats[0, 1]) == (o.ncon, o.nefc), (k, e.stats[0], o.ncon, o.nefc)
+        worst, rows = max(worst, eq), max(rows, o.nefc)
+    assert (e.flags[0] & 31) == 0 and rows >= 19 and worst < 3e-6   # measured 1.1e-6 (finger joints under limit rows: |qacc| ~ 1e3)
+
+
 def test_contact_free_kernel_with_joint_limit_rows():
     """The contact-free instantiation's Newton solve (stage_newton_limits: every row a joint-limit row held by its dof's lane) against
     the oracle: arm-only model driven into the limits of joints 1 and 2 (range [0.87, 5.41] / [0.33, 5.95]) and of the finger joints
