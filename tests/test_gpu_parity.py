@@ -302,11 +302,21 @@ def test_sensor_model_with_cylinder_geoms_on_the_d12_build():
     B, nsub = 256, 100
     rng = np.random.default_rng(79)
     q = np.tile(M["qpos0"], (B, 1))
-    q[:, :6] = rng.uniform([0.7, 3.8, 1.0, 1.8, 1.0, 0.8], [2.5, 4.0, 1.7, 2.5, 2.5, 2.3], (B, 6))
-    q[:, 6:12:2] = rng.uniform(0.0, 1.0, (B, 3)); q[:, 7:12:2] = rng.uniform(-0.3, 0.3, (B, 3))
-    q[:, 12:15] = np.array([0.0, 0.65, 0.445]) + rng.uniform(-1, 1, (B, 3)) * [0.04, 0.04, 0.002]
+    q[:, 6:12:2] = rng.uniform(0.25, 0.7, (B, 3))   # (fingers closed to 0 touch each other)
+    q[:, 12:15] = np.array([0.0, 0.65, 0.455]) + rng.uniform(-1, 1, (B, 3)) * [0.04, 0.04, 0.002]
     quat = np.concatenate([np.ones((B, 1)), rng.uniform(-0.1, 0.1, (B, 3))], 1); q[:, 15:19] = quat / np.linalg.norm(quat, axis=1, keepdims=True)
-    q = q.astype(np.float32).astype(np.float64)
+    o = Oracle("jaco2_curtain_torque_sensor")
+    gbody, objbody = M["geom_bodyid"], int(M["nbody"][0]) - 1
+    for i in range(B):   # random arm poses, re-drawn while they start inside something (the holder stands within the arm's reach)
+        for attempt in range(200):
+            q[i, :6] = rng.uniform([0.7, 3.8, 1.0, 1.8, 1.0, 0.8], [2.5, 4.0, 1.7, 2.5, 2.5, 2.3])
+            q[i] = q[i].astype(np.float32).astype(np.float64)
+            o.set("qpos", q[i]); o.forward()
+            C = o.get("contact").reshape(-1, 11)
+            C = C[(gbody[C[:, 7].astype(int)] != objbody) & (gbody[C[:, 8].astype(int)] != objbody)]   # (the tilted box may dip into the disc)
+            if len(C) == 0 or C[:, 0].min() > -0.003: break
+        else:
+            raise AssertionError("no admissible arm pose in 200 draws")
     c = np.concatenate([rng.uniform(-1, 1, (B, 6)) * np.array([30, 30, 30, 15, 15, 15]) * 0.2, rng.uniform(0, 1.0, (B, 3))], 1).astype(np.float32).astype(np.float64)
     env = _env(B, "jaco2_curtain_torque_sensor")
     assert (env.nq, env.nv, env.nu) == (19, 18, 9)
@@ -314,7 +324,6 @@ def test_sensor_model_with_cylinder_geoms_on_the_d12_build():
     env.send_forces(_t(c, env.device), nsub=nsub)
     gq, gv, _ = [t.cpu().numpy().astype(np.float64) for t in env.get_state()]
     gst = env.stats().cpu().numpy()
-    o = Oracle("jaco2_curtain_torque_sensor")
     qo, vo, wo = q.copy(), np.zeros((B, 18)), np.zeros((B, 18))
     st = np.zeros((B, 4), np.int32)
     o.step_batch(qo, vo, wo, np.ascontiguousarray(c), nsub=nsub, nthreads=16, stats=st)
@@ -322,7 +331,8 @@ def test_sensor_model_with_cylinder_geoms_on_the_d12_build():
     print("sensor model, %d substeps: qpos err median %.2e p90 %.2e max %.2e, qvel err max %.2e; oracle rows %d..%d, contacts up to %d; same row count in %d of %d envs" % (
         nsub, np.median(eq), np.percentile(eq, 90), eq.max(), ev.max(), st[:, 1].min(), st[:, 1].max(), st[:, 0].max(), int((gst[:, 1] == st[:, 1]).sum()), B))
     assert (env.flags().cpu().numpy() & 15).max() == 0 and (st[:, 0] >= 1).mean() > 0.9   # the box is on the disc in (nearly) every env
-    assert np.median(eq) < 1e-6 and np.percentile(eq, 90) < 1e-5 and eq.max() < 1e-3
+    # (the emulated kernel on the first 48 of these envs: median 1.2e-7, p90 3.2e-7, max 1.5e-5 -- one env whose fingers hit the holder hard)
+    assert np.median(eq) < 4e-7 and np.percentile(eq, 90) < 2e-6 and eq.max() < 1e-3
     # (B) arm-on-cylinder poses, one substep
     P = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sensor_post_poses.npz"))["qpos"]
     n = len(P)
