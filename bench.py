@@ -534,7 +534,8 @@ def main():
                       "wait_frac": (pm["SQ_WAIT_ANY"] / pm["SQ_WAVE_CYCLES"]) if pm.get("SQ_WAIT_ANY") and pm.get("SQ_WAVE_CYCLES") else None}
         except Exception:
             pass
-        cfgname = "config2" if (args.no_contact and args.level == "ctrl") else ("config4" if (args.no_reset and fs == 4) else ("two-arm model, sim tier" if env.nu == 18 else "config3"))
+        cfgname = "config2" if (args.no_contact and args.level == "ctrl") else ("config4" if (args.no_reset and fs == 4) else ("two-arm model, sim tier" if env.nu == 18 else
+                                                                         ("sibling model, sim tier" if (args.level == "ctrl" and args.model != "jaco2_curtain_torque") else "config3")))
         if args.level != "env":
             workload_desc = "random motor ctrl, ctrl-level jaco_physics_step"
         else:

@@ -25,6 +25,11 @@ def reset_states(qpos0, nenv, seed=0, contact=True, f32_draws=False):
         q[:, 12:16] = [1, 0, 0, 0]
         q[:, 16] = r(0.4 + rng.uniform(-0.05, 0.05, nenv))
         q[:, 17] = r(0.3 + rng.uniform(-0.05, 0.05, nenv))
+    elif nq == 19 and abs(qpos0[13] - 0.65) < 1e-9:
+        # jaco2_curtain_torque_sensor.xml (xml:283: the object starts 0.6 m above its holder): put it on the holder's disc (cylinder, top at
+        # z = 0.41), the fingers half open (closed to 0 they touch each other in this model)
+        q[:, 6:12:2] = r(rng.uniform(0.3, 0.7, (nenv, 3)))
+        q[:, 12] = r(rng.uniform(-0.04, 0.04, nenv)); q[:, 13] = r(0.65 + rng.uniform(-0.04, 0.04, nenv)); q[:, 14] = r(0.4401 if contact else 0.8)
     return q
 
 
