@@ -467,6 +467,78 @@ JDEV v3 mpr_find_pos(const Sup& p0, const Sup& p1, const Sup& p2, const Sup& p3)
 // returns true on penetration
 // On a miss that ended on a support test (the support of G1 - G2 along `dr` does not reach past the origin) *sep = dr: a separating
 // direction, which the caller caches for the pair (stage_collision, "separating directions").
+#ifdef JACO_MPR_FSM
+// A/B build (tools/build_variant.sh mprfsm -DJACO_MPR_FSM): the same routine as a state machine around ONE support-query site (the straight-line
+// version below inlines the query six times).  Phases: 0 / 1 the first two portal points, 2 portal discovery, 3 refinement until the portal
+// faces the origin, 4 refinement to tolerance.  Same arithmetic in the same order per phase: results are bit-identical.
+JDEV bool mpr_penetration(const JacoStepArgs& A, const JacoModelDev* m, const MprGeom& G1, const MprGeom& G2, int lane,
+                          float* depth, v3* dirout, v3* pos, v3* sep, bool* sepvalid JROWARG) {
+  Sup p0, p1, p2, p3;
+  const float tol = m->mpr_tolerance;
+  const int maxit = m->mpr_iterations;
+  *sepvalid = false;
+  p0.v1 = G1.P.p; p0.v = p0.v1 - G2.P.p;
+  if (norm(p0.v) < 1e-9f) p0.v.x = 1e-5f;
+  p1 = p0; p2 = p0; p3 = p0;
+  v3 dr = normalized(-p0.v);
+  int phase = 0, it = 0;
+  for (;;) {
+    phase = wave_uniform_i(phase);
+    if (phase == 2 && it > 100) return false;
+    const Sup q = mpr_support(A, G1, G2, dr, lane JROWPASS);
+    const float qd = dot(q.v, dr);
+    if (phase == 0) {
+      p1 = q;
+      if (qd <= 0.f) { *sep = dr; *sepvalid = true; return false; }
+      dr = cross(p0.v, p1.v);
+      if (norm(dr) < 1e-9f) {
+        *depth = norm(p1.v); *dirout = normalized(p1.v); *pos = p1.v1 - p1.v * 0.5f;
+        return true;
+      }
+      dr = normalized(dr);
+      phase = 1;
+    } else if (phase == 1) {
+      p2 = q;
+      if (qd <= 0.f) { *sep = dr; *sepvalid = true; return false; }
+      dr = normalized(cross(p1.v - p0.v, p2.v - p0.v));
+      if (dot(dr, p0.v) > 0.f) { Sup t = p1; p1 = p2; p2 = t; dr = -dr; }
+      phase = 2; it = 0;
+    } else if (phase == 2) {
+      p3 = q;
+      if (qd <= 0.f) { *sep = dr; *sepvalid = true; return false; }
+      bool cont = false;
+      if (dot(cross(p1.v, p3.v), p0.v) < -1e-11f) { p2 = p3; cont = true; }
+      if (!cont && dot(cross(p3.v, p2.v), p0.v) < -1e-11f) { p1 = p3; cont = true; }
+      if (cont) { dr = normalized(cross(p1.v - p0.v, p2.v - p0.v)); it++; }
+      else {
+        dr = portal_dir(p1, p2, p3);
+        phase = dot(dr, p1.v) >= 0.f ? 4 : 3; it = 0;
+      }
+    } else if (phase == 3) {
+      if (qd < 0.f) { *sep = dr; *sepvalid = true; return false; }
+      if (reach_tol(p1, p2, p3, q, dr, tol) || it > maxit) return false;
+      expand_portal(p0, p1, p2, p3, q);
+      dr = portal_dir(p1, p2, p3);
+      it++;
+      if (dot(dr, p1.v) >= 0.f) { phase = 4; it = 0; }
+    } else {
+      if (reach_tol(p1, p2, p3, q, dr, tol) || it > maxit) {
+        if (m->mpr_output == 1) { *dirout = dr; *depth = qd; }
+        else {
+          v3 cp;
+          *depth = point_tri_closest(p1.v, p2.v, p3.v, &cp);
+          *dirout = *depth < 1e-10f ? dr : normalized(cp);
+        }
+        *pos = mpr_find_pos(p0, p1, p2, p3);
+        return true;
+      }
+      expand_portal(p0, p1, p2, p3, q);
+      dr = portal_dir(p1, p2, p3);
+      it++;
+    }
+  }
+}
+#else
 JDEV bool mpr_penetration(const JacoStepArgs& A, const JacoModelDev* m, const MprGeom& G1, const MprGeom& G2, int lane,
                           float* depth, v3* dirout, v3* pos, v3* sep, bool* sepvalid JROWARG) {
   Sup p0, p1, p2, p3, v4;
@@ -528,6 +600,7 @@ JDEV bool mpr_penetration(const JacoStepArgs& A, const JacoModelDev* m, const Mp
     expand_portal(p0, p1, p2, p3, v4);
   }
 }
+#endif
 
 // ---------------------------------------------------------------- stage C
 // Pair list of the bounding-sphere phase (temporal coherence across the substeps of a launch).  Geoms move well under a
