@@ -76,3 +76,38 @@ def test_compiled_model_against_the_surveys_model_table():
     assert np.allclose(M["geom_friction"].reshape(-1, 3)[gobj], (0.95, 0.3, 0.1)) and np.allclose(M["geom_solref"].reshape(-1, 2)[gobj], (0.001, 1))
     assert M["geom_condim"][G["link6"]] == 6 and np.allclose(M["geom_solref"].reshape(-1, 2)[G["link6"]], (0.01, 1))
     assert float(M["opt_timestep"][0]) == 0.001 and np.allclose(M["opt_gravity"], (0, 0, -9.81))
+
+
+def test_cylinder_geoms_and_zaxis_frames_in_the_shipped_sensor_model():
+    """jaco2_curtain_torque_sensor.xml:62-74,278-281: five static cylinders -- two posts (.01 x .4), the rod (.01 x .5, axis turned onto x by
+    `zaxis="1 0 0"`), the object holder's stem (.01 x .2) and disc (.1 x .01).  Read from the compiled asset (no reference needed)."""
+    from mujoco_jaco_amd import _lib
+    from mujoco_jaco_amd.modelc import blob, rot
+    M = blob.load(_lib.model_path("jaco2_curtain_torque_sensor"))
+    cyl = np.nonzero(M["geom_type"] == mjcf.GEOM_CYLINDER)[0]
+    size = M["geom_size"].reshape(-1, 3)[cyl]
+    assert sorted(map(tuple, np.round(size[:, :2], 6).tolist())) == sorted([(.01, .4), (.01, .4), (.01, .5), (.01, .2), (.1, .01)])
+    assert np.allclose(M["geom_rbound"][cyl], np.hypot(size[:, 0], size[:, 1]))
+    quat = M["geom_quat"].reshape(-1, 4)[cyl]
+    rod = int(np.nonzero(np.abs(size[:, 1] - 0.5) < 1e-12)[0][0])
+    assert np.allclose(rot.quat_to_mat(quat[rod]) @ [0, 0, 1], [1, 0, 0], atol=1e-12)       # the rod lies along x
+    for i in range(len(cyl)):
+        if i != rod:
+            assert np.allclose(quat[i], [1, 0, 0, 0])
+    # the minimal rotation: about y by +90 degrees, nothing about the axis itself
+    assert np.allclose(quat[rod], [np.sqrt(0.5), 0, np.sqrt(0.5), 0], atol=1e-12)
+
+
+def test_cylinder_mass_properties():
+    """A moving cylinder's mass and inertia from its density (none of the shipped assets has one; the formulae are MuJoCo's [EXT])."""
+    import tempfile
+    xml = """<mujoco><worldbody><body name="b" pos="0 0 1"><freejoint/><geom type="cylinder" size=".05 .2" density="1000"/></body></worldbody></mujoco>"""
+    with tempfile.NamedTemporaryFile("w", suffix=".xml", delete=False) as f:
+        f.write(xml)
+    try:
+        M, names = mjcf.parse(f.name, timestep=0.001)
+    finally:
+        os.remove(f.name)
+    m = 1000 * np.pi * 0.05 ** 2 * 0.4
+    assert np.isclose(M["body_mass"][1], m)
+    assert np.allclose(M["body_inertia"].reshape(-1, 3, 3)[1], np.diag([m * (0.05 ** 2 / 4 + 0.2 ** 2 / 3)] * 2 + [m * 0.05 ** 2 / 2]))
