@@ -267,7 +267,9 @@ JDEV void collide_box_box4(const JacoModelDev* m, L& s, int cbase, int nrows, in
     }
     if (alive && !edge) {
       h1 = hv1 && !(pt1.z > 0.f); h2 = hv2 && !(pt2.z > 0.f);
-      d1 = pt1.z; d2 = pt2.z;
+      // dist = HALF the overlap at the contact's midpoint: what the reference's MuJoCo 2.0 reports for box-box face contacts, pinned by the
+      // object-on-holder transient and rest height its recorded trajectories hold (tests/golden/mujoco_rest_heights.json)
+      d1 = 0.5f * pt1.z; d2 = 0.5f * pt2.z;
       x1 = rp + Ru * pt1.x + Rv * pt1.y + nref * (rn + 0.5f * pt1.z);
       x2 = rp + Ru * pt2.x + Rv * pt2.y + nref * (rn + 0.5f * pt2.z);
       nrm = nref * (refis1 ? 1.f : -1.f);
@@ -731,7 +733,7 @@ JDEV void stage_collision(const JacoStepArgs& A, const JacoModelDev* m, L& s, in
     for (int j = 0; j < PL::NV; j++) {
       const bool have = j * 64 + lane < nl && pl.n >= 0;
       pl.e[j] = have ? tmp[have ? j * 64 + lane : 0] : 0u;
-      pl.planes |= wave_ballot(have && ((pl.e[j] >> 22) & 1u) != 0u) ? 1u << j : 0u;
+      pl.planes |= wave_ballot(have && ((pl.e[j] >> (JPL_KBITS + 2 * JPL_GBITS)) & 1u) != 0u) ? 1u << j : 0u;
     }
 #pragma unroll
     for (int p = 0; p < JGEOM_PASSES; p++) { pl.px[p] = gp[p].x; pl.py[p] = gp[p].y; pl.pz[p] = gp[p].z; }

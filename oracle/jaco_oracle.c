@@ -28,6 +28,9 @@ struct OrcModel {
   int round_state; /* control experiments: 1 = qpos/qvel/qacc_warmstart are rounded to fp32 after every step (an fp64 engine carrying fp32 state);
                       2 = fp64 state, but the forward pass sees its fp32 rounding (an engine that carries its state compensated) */
   double ls_tolerance;
+  double boxbox_depth_scale; /* dist of a box-box face contact = this x the geometric overlap.  0.5 is what the reference's MuJoCo 2.0 did: pinned by the
+                                thirteen-value push-out transient and the rest height 0.19997096 its recorded trajectories hold (tests/golden/mujoco_rest_heights.json,
+                                tools/rest_height_sweep.py, profiles/r05_rest_height_holder.txt); 1 (the geometric overlap) rests 1.45e-5 m too high */
   int *body_parentid, *body_weldid, *body_mocapid, *body_jntadr, *body_jntnum, *body_dofadr, *body_dofnum;
   double *body_pos, *body_quat, *body_ipos, *body_inertia, *body_mass, *body_invweight0;
   int *jnt_type, *jnt_bodyid, *jnt_qposadr, *jnt_dofadr, *jnt_limited;
@@ -189,7 +192,7 @@ OrcModel* orc_load_model(const char* path) {
   m->nmesh = *nmesh; m->nmocap = *nmocap; m->nsensor = *nsensor; m->npair = *npair;
   m->timestep = *ts; memcpy(m->gravity, grav, 24); m->tolerance = *tol; m->iterations = *iters;
   m->mpr_tolerance = *mprt; m->mpr_iterations = *mpri; m->meaninertia = *meani;
-  m->solver = ORC_SOLVER_NEWTON; m->ls_iterations = 50; m->ls_tolerance = 0.01; m->mpr_output = 1;
+  m->solver = ORC_SOLVER_NEWTON; m->ls_iterations = 50; m->ls_tolerance = 0.01; m->mpr_output = 1; m->boxbox_depth_scale = 0.5;
   return m;
 }
 void orc_free_model(OrcModel* m) { if (m) { free(m->blob); free(m); } }
@@ -212,6 +215,7 @@ int orc_set_option(OrcModel* m, const char* n, double v) {
   else if (!strcmp(n, "mpr_tolerance")) m->mpr_tolerance = v;
   else if (!strcmp(n, "round_state")) m->round_state = (int)v;
   else if (!strcmp(n, "mpr_output")) m->mpr_output = (int)v;
+  else if (!strcmp(n, "boxbox_depth_scale")) m->boxbox_depth_scale = v;
   else return -1;
   return 0;
 }
@@ -677,7 +681,10 @@ static void collide_box_box(const OrcModel* m, OrcData* d, int g1, int g2) {
     add_contact(d, g1, g2, -ebest, pos, n);
     return;
   }
-  /* face contact: reference box r (axis ia), incident box o */
+  /* face contact: reference box r (axis ia), incident box o.  Contact point = midpoint between the incident point and the reference face;
+     dist = HALF the overlap there (m->boxbox_depth_scale): with the full overlap the object rests on the holder at 0.19998548 and leaves its
+     1 cm spawn overlap in ~20 ms; the reference's MuJoCo rests at 0.19997096 and takes 600 ms, and with the half depth every one of its
+     thirteen recorded float32 values is reproduced (tests/test_mujoco_statics.py).  The edge-edge branch above has no recorded datum: full depth. */
   int refis1 = code < 3, ia = refis1 ? code : code - 3;
   const double (*RA)[3] = refis1 ? A : B, (*IA)[3] = refis1 ? B : A;
   const double *rs = refis1 ? s1 : s2, *is = refis1 ? s2 : s1, *rp = refis1 ? p1 : p2, *ip = refis1 ? p2 : p1;
@@ -743,7 +750,7 @@ static void collide_box_box(const OrcModel* m, OrcData* d, int g1, int g2) {
     addscl3(pos, rp, RA[iu], pts[k][0]);
     addscl3(pos, pos, RA[iv], pts[k][1]);
     addscl3(pos, pos, nref, rs[ia] + w / 2);
-    add_contact(d, g1, g2, w, pos, n12);
+    add_contact(d, g1, g2, w * m->boxbox_depth_scale, pos, n12);
   }
 }
 
