@@ -110,10 +110,13 @@ int jaco_get_stats(JacoHandle* h, int32_t* out_dev, void* stream);
  *   (4 cm back along its x axis), EE target = current EE pose, then nsub x { OSC torque from the current state's M, J, bias
  *   (each iteration follows a sim.forward()), sim.step() with gripper command 0.6, set_obj_xyz: object re-pinned, velocities
  *   of all free bodies zeroed (mujoco.py:217-227) }.  Exposed so that a caller can replay the hold from its own state.
- * jaco_step: clip is the caller's job (env_mujoco.py:117 np.clip); then _take_action, frame_skip x (OSC torque +
- *   sim.step()), make_observation, _get_reward, terminal_inspection.  action_dev [num_envs][7] (6 for reaching),
- *   obs_dev [num_envs][26] f32, reward_dev [num_envs] f32, done_dev [num_envs] u8.  An env that returned done stays
- *   frozen (done = 1, reward 0, obs row untouched) until it is reset: there is no auto-reset inside the library.
+ * jaco_step: np.clip of the action to [-1, 1] (env_mujoco.py:117) is done inside the kernel; then _take_action, frame_skip x
+ *   (OSC torque + sim.step()), make_observation, _get_reward, terminal_inspection.  action_dev [num_envs][7] (6 for reaching),
+ *   obs_dev [num_envs][26] f32, reward_dev [num_envs] f32, done_dev [num_envs] u8.  By default an env that returned done stays
+ *   frozen (done = 1, reward 0, obs row untouched) until jaco_reset is called for it.  With jaco_set_option("auto_reset", 1)
+ *   (tasks whose reset is draws + sim.forward(): picking, reaching, pickAndplace, pushing) the wave that ends an episode resets the
+ *   env itself: done / reward are the terminal step's, the obs row is the NEW episode's first observation, and the terminal
+ *   step's (success, wb) / observation are latched for jaco_get_last_terminal / jaco_get_terminal_obs.
  * jaco_forward: sim.forward() + _get_observation from the current state (after jaco_set_state / jaco_set_task_state).
  * jaco_set_noise: optional [num_envs][12] uniform draws replacing the internal RNG for the rule-based sub-goal noise
  *   (6 for the marker placed in _take_action, 6 for the observation; env_mujoco_util.py:279,295); NULL restores the RNG.
@@ -145,6 +148,11 @@ int jaco_set_noise(JacoHandle* h, const float* noise_dev);
  * drawn at reset, and _take_action moves the "subgoal_reach" marker to subgoal + previous target (:609) when the caller passes the
  * policy's sub-goal offsets [num_envs][6] here (NULL: the marker stays where it is). */
 int jaco_set_subgoal(JacoHandle* h, const float* subgoal_dev);
+/* kwarg init_buffer of the reference (env_mujoco_util.py:46,208-212): a buffer of recorded rows from which every reset draws its reaching
+ * goal -- random_idx = np.random.randint(0, len(buffer) - 1) (rows 0 .. len - 2), position = row[1:4], orientation = row[4:7], no float16
+ * cast -- instead of sampling it (:199-207).  rows_dev [nrows][row_floats] f32 on the device, copied by the library; NULL restores the
+ * sampled goal.  nrows >= 2 (numpy's randint(0, 0) raises), row_floats >= 7. */
+int jaco_set_init_buffer(JacoHandle* h, const float* rows_dev, int nrows, int row_floats, void* stream);
 int jaco_get_task_state(JacoHandle* h, float* out_dev, void* stream);
 int jaco_set_task_state(JacoHandle* h, const float* in_dev, void* stream);
 int jaco_task_row_floats(void);
@@ -153,8 +161,9 @@ int jaco_task_row_floats(void);
  * "auto_reset", where the task row already belongs to the new episode when jaco_step returns (the reference's accum_succ bookkeeping,
  * env_mujoco.py:129-136, reads succ in the terminal step).  Rows of envs that have not finished an episode yet are (0, 0). */
 int jaco_get_last_terminal(JacoHandle* h, float* out_dev, void* stream);
-/* ... and the observation of that terminal step, out_dev [num_envs][26] f32 (option "auto_reset": the env's obs_dev row already holds the new
- * episode's first observation; a learner bootstrapping the value of a timed-out state needs the last one of the old episode). */
+/* ... and the observation of that terminal step, out_dev [num_envs][26] f32, latched by EVERY terminal jaco_step with or without option
+ * "auto_reset" (with it the env's obs_dev row already holds the new episode's first observation; a learner bootstrapping the value of a
+ * timed-out state needs the last one of the old episode).  Rows of envs that have not finished an episode yet are zero. */
 int jaco_get_terminal_obs(JacoHandle* h, float* out_dev, void* stream);
 /* Marker poses [num_envs][2][12] f32: {"hand", "subgoal_reach"} x {position, rotation matrix row-major} -- the two mocap bodies
  * _take_action moves every env step (set_mocap_xyz / set_mocap_orientation, mujoco.py:248-256, env_mujoco_util.py:613-615,

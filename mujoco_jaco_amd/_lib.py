@@ -43,6 +43,7 @@ SYMBOLS = {
     "jaco_terminal_inspection": (_ci, [_vp, _vp, _vp, _vp]),
     "jaco_set_noise": (_ci, [_vp, _vp]),
     "jaco_set_subgoal": (_ci, [_vp, _vp]),
+    "jaco_set_init_buffer": (_ci, [_vp, _vp, _ci, _ci, _vp]),
     "jaco_get_task_state": (_ci, [_vp, _vp, _vp]),
     "jaco_set_task_state": (_ci, [_vp, _vp, _vp]),
     "jaco_task_row_floats": (_ci, []),
@@ -68,6 +69,9 @@ def load(variant=""):
     """variant "": the default layout (11 fused bodies, 21 dofs in blocks 9 + 6 + 6); "_d12": the build for jaco2_torque.xml and jaco2_curtain_torque_sensor.xml
     (12 hinge dofs in one tree + at most one free object); "_d30": the build for jaco2_dual_torque.xml."""
     if variant not in _libs:
+        # torch first: its wheel bundles its own libamdhip64, and the process must run on ONE HIP runtime -- loaded the other way round
+        # (this library's /opt/rocm runtime, then torch's) the second runtime finds no device ("no usable HIP device" in jaco_create)
+        import torch  # noqa: F401
         path = LIB_PATH if not variant else os.path.join(_HERE, "libjaco_env%s.so" % variant)
         if not os.path.exists(path):
             raise ImportError(

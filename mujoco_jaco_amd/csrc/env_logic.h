@@ -18,10 +18,9 @@
 #define JT_TARGET 10     // [6] EE target pose (xyz + euler rxyz)
 #define JT_GRIP_PREV 16
 #define JT_SUB 17        // substep index inside the current env step (tier hand-off)
-#define JT_RNG 18        // draw counter (bit pattern of an unsigned).  NOTE: small counts are fp32 DENORMAL patterns and the library is built with
-                         // -fgpu-flush-denormals-to-zero: the slot must only ever be moved (loads, stores, v_readlane, __float_as_uint), never
-                         // pass through a floating-point operation (a select via fmul, a canonicalising min / max, `task * mask` on the host side)
-                         // -- that would zero the counter and restart the env's RNG stream.  tests/test_gpu_env.py pins the round trip.
+#define JT_RNG 18        // draw counter: the 29-bit count with bit 30 set (rng_count / rng_slot below), i.e. always the bit pattern of a NORMAL
+                         // float (exponent field 128..191) -- the library is built with -fgpu-flush-denormals-to-zero, and a bare small unsigned
+                         // would be a denormal pattern that any canonicalising operation zeroes.  An all-zero row reads as count 0.
 #define JT_PENDING 19    // 1: JT_CTRL holds the ctrl of the interrupted substep
 #define JT_CTRL 20       // [9]
 #define JT_SUCC 29       // success flag of the last terminal step
@@ -302,13 +301,18 @@ JDEV float grasp_ang_diff(const float* eul_ee, const float* eul_goal) {
   return sqrtf(s);
 }
 
+JDEV unsigned rng_count(float slot) { return __float_as_uint(slot) & 0x1FFFFFFFu; }
+JDEV float rng_slot(unsigned count) { return __uint_as_float((count & 0x1FFFFFFFu) | 0x40000000u); }   // (wraps after 5e8 draws = 4e7 env steps)
+
 // ---------------------------------------------------------------- a12: the draws of _reset (env_mujoco_util.py:92-121,176-219)
 // One env's randomised initial state: arm angles (_create_init_angle), the reaching / object / destination goals (__sample_goal), object on
 // the holder and pedestal at its goal (set_obj_xyz with the zero quaternion, set_dest_xyz), task row cleared (draw counter kept).
 // `q` (nq, already holding qpos0) and `t` (the task row) may live in global memory (jaco_reset_kernel: one thread per env) or in LDS (the
 // in-kernel auto-reset of a finished env: one lane).  Same code, same counter-based RNG stream: both paths produce the same bits.
-JDEV void reset_draws(int task_id, unsigned long long seed, unsigned env, int has_free, const float* base, float* q, float* t) {
-  unsigned c = __float_as_uint(t[JT_RNG]);
+// Optional buffer of recorded goals (kwarg init_buffer, env_mujoco_util.py:46,208-212): rows of `stride` floats, row[1:4] = goal position, row[4:7] = goal orientation.
+struct GoalBuffer { const float* rows; int n, stride; };
+JDEV void reset_draws(int task_id, unsigned long long seed, unsigned env, int has_free, const float* base, float* q, float* t, GoalBuffer gb = GoalBuffer{nullptr, 0, 0}) {
+  unsigned c = rng_count(t[JT_RNG]);
 #define JRU(lo, hi) ((lo) + ((hi) - (lo)) * rng_uniform(seed, env, c++))
   const float PI = 3.14159265358979323846f;
   if (task_id == JTASK_PLACING || task_id == JTASK_GRASPING || task_id == JTASK_CARRYING) {   // 'carrying', 'grasping', 'placing' (:181-185)
@@ -325,6 +329,13 @@ JDEV void reset_draws(int task_id, unsigned long long seed, unsigned env, int ha
   }
   for (int k = 0; k < JTASK_N; k++) if (k != JT_RNG) t[k] = 0.f;
   t[JT_GRIP] = 0.6f; t[JT_GRIP_PREV] = 0.6f;
+  if (gb.rows && gb.n >= 2) {   // goal_buffer branch (:208-212): random_idx = np.random.randint(0, len(buffer) - 1), i.e. one of rows 0 .. len - 2 (the
+                               // last row is never drawn); position = row[1:4], orientation = row[4:7], taken as they are (no float16 cast here)
+    int idx = (int)(rng_uniform(seed, env, c++) * (float)(gb.n - 1));
+    idx = idx > gb.n - 2 ? gb.n - 2 : idx;
+    const float* row = gb.rows + (size_t)idx * gb.stride;
+    for (int k = 0; k < 6; k++) t[JT_REACHGOAL + k] = row[1 + k];
+  } else
   {   // reaching goal (__sample_goal, :199-207; drawn for every task, read by task 'reaching' and by the reaching-goal observation)
     float g[3];
     for (int k = 0; k < 2; k++) { const float mag = JRU(0.3f, 0.42f); const float sgn = JRU(0.f, 1.f); g[k] = sgn < 0.5f ? -mag : mag; }
@@ -346,7 +357,7 @@ JDEV void reset_draws(int task_id, unsigned long long seed, unsigned env, int ha
     t[JT_DESTGOAL] = dx; t[JT_DESTGOAL + 1] = dy; t[JT_DESTGOAL + 2] = 0.3468f;
   }
 #undef JRU
-  t[JT_RNG] = __uint_as_float(c);
+  t[JT_RNG] = rng_slot(c);
 }
 
 // ---------------------------------------------------------------- a4/a5: operational-space controller on the wave

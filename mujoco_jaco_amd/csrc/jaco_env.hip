@@ -73,6 +73,8 @@ struct JacoHandle {
   float *task_rows = nullptr, *cache = nullptr;
   float* terminal = nullptr;   // [num_envs][2] (success flag, wb) latched by every terminal step
   float* terminal_obs = nullptr;   // [num_envs][26] observation of the terminal step (auto_reset)
+  float* goal_buf = nullptr;       // recorded reaching goals (jaco_set_init_buffer; library-owned copy), or nullptr
+  int goal_n = 0, goal_stride = 0;
   float* marker = nullptr;    // [num_envs][2][12] poses of the "hand" / "subgoal_reach" markers (mocap bodies the task layer moves)
   unsigned* cost = nullptr;   // per env: shader-clock ticks its last step took (>> 4)
   int* order = nullptr;       // launch order of the env-level light kernel: expensive envs first
@@ -242,7 +244,7 @@ extern "C" int jaco_destroy(JacoHandle* h) {
   }
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_pre) (void)hipEventDestroy(h->ev_pre);
-  void* ptrs[] = {h->model_dev, h->hull_dev, h->qpos, h->qvel, h->qacc_ws, h->qpos_lo, h->qvel_lo, h->sensordata, h->flags, h->stats, h->dbg, h->prof, h->remaining, h->qlist, h->qctl, h->hint, h->routed_mark, h->task_rows, h->cache, h->cost, h->order, h->marker, h->order_ctl, h->qpos0_dev, h->sepdir, h->terminal, h->terminal_obs};
+  void* ptrs[] = {h->model_dev, h->hull_dev, h->qpos, h->qvel, h->qacc_ws, h->qpos_lo, h->qvel_lo, h->sensordata, h->flags, h->stats, h->dbg, h->prof, h->remaining, h->qlist, h->qctl, h->hint, h->routed_mark, h->task_rows, h->cache, h->cost, h->order, h->marker, h->order_ctl, h->qpos0_dev, h->sepdir, h->terminal, h->terminal_obs, h->goal_buf};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   delete h;
   return JACO_OK;
@@ -475,7 +477,7 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
   for (int t = 0; t < 3; t++) { A.q[t].list = h->qlist + (size_t)t * 2 * h->num_envs; A.q[t].count = h->qctl + JQ_COUNT + t; A.q[t].taken = h->qctl + JQ_TAKEN + t; A.q[t].limit = h->qctl + JQ_LIMIT + t; A.q[t].reserve = h->qctl + JQ_RESERVE + t; }
   A.routed_mark = nullptr; A.launch_id = ++h->launch_id;
   A.env_mode = io.mode; A.task_id = h->task; A.nact = (h->task == JACO_TASK_REACHING || h->task == JACO_TASK_PUSHING) ? 6 : 7; A.seed = h->seed;
-  A.task = h->task_rows; A.cache = h->cache; A.action = io.action; A.noise = h->noise; A.obs_mode = h->obs_mode; A.subgoal = h->subgoal; A.obs = io.obs; A.reward = io.reward; A.done = io.done; A.terminal = h->terminal; A.terminal_obs = h->terminal_obs; A.mask = io.mask; A.marker = h->marker;
+  A.task = h->task_rows; A.cache = h->cache; A.action = io.action; A.noise = h->noise; A.obs_mode = h->obs_mode; A.subgoal = h->subgoal; A.obs = io.obs; A.reward = io.reward; A.done = io.done; A.terminal = h->terminal; A.terminal_obs = h->terminal_obs; A.goal_buf = h->goal_buf; A.goal_n = h->goal_n; A.goal_stride = h->goal_stride; A.mask = io.mask; A.marker = h->marker;
   A.cost = h->cost;
   // auto-reset folds draws + sim.forward() + observation into the step wave: the tasks whose reset is nothing more (placing holds the
   // object for 150 substeps, grasping pre-reaches: those keep the explicit jaco_reset)
@@ -588,6 +590,7 @@ struct JacoResetArgs {
   int nenv, nq, nv, task_id, has_free; unsigned long long seed;
   float base[3];   // link1 position: the reaching goal's orientation looks along base -> goal (env_mujoco_util.py:201-205)
   int* list; unsigned* list_count;   // the reset envs, for the launches that follow (forward pass, placing hold)
+  GoalBuffer goals;
 };
 __global__ void jaco_reset_kernel(JacoResetArgs R) {
   int e = (int)(blockIdx.x * blockDim.x + threadIdx.x);
@@ -598,7 +601,7 @@ __global__ void jaco_reset_kernel(JacoResetArgs R) {
   for (int k = 0; k < R.nq; k++) { q[k] = R.qpos0[k]; R.qpos_lo[(size_t)e * R.nq + k] = 0.f; }
   for (int k = 0; k < R.nv; k++) { R.qvel[(size_t)e * R.nv + k] = 0.f; R.qacc_ws[(size_t)e * R.nv + k] = 0.f; R.qvel_lo[(size_t)e * R.nv + k] = 0.f; }
   for (int k = 0; k < 24; k++) R.marker[(size_t)e * 24 + k] = R.marker_rest[k];   // sim.reset(): markers back to their XML pose
-  reset_draws(R.task_id, R.seed, (unsigned)e, R.has_free, R.base, q, t);          // (env_logic.h: shared with the in-kernel auto-reset)
+  reset_draws(R.task_id, R.seed, (unsigned)e, R.has_free, R.base, q, t, R.goals);          // (env_logic.h: shared with the in-kernel auto-reset)
 }
 
 extern "C" int jaco_forward(JacoHandle* h, float* obs_dev, void* stream) {
@@ -625,7 +628,7 @@ extern "C" int jaco_reset(JacoHandle* h, const uint8_t* mask_dev, float* obs_dev
   hipStream_t st = (hipStream_t)stream;
   const JacoModelDev& m = h->model_host;
   const float* rest = (const float*)((const char*)h->model_dev + offsetof(JacoModelDev, marker_rest));
-  JacoResetArgs R{h->qpos0_dev, h->qpos, h->qvel, h->qacc_ws, h->qpos_lo, h->qvel_lo, h->task_rows, mask_dev, h->marker, rest, h->num_envs, m.nq, m.nv, h->task, m.nq >= 23, h->seed, {m.base_pos[0], m.base_pos[1], m.base_pos[2]}, h->order, h->order_ctl + 67};
+  JacoResetArgs R{h->qpos0_dev, h->qpos, h->qvel, h->qacc_ws, h->qpos_lo, h->qvel_lo, h->task_rows, mask_dev, h->marker, rest, h->num_envs, m.nq, m.nv, h->task, m.nq >= 23, h->seed, {m.base_pos[0], m.base_pos[1], m.base_pos[2]}, h->order, h->order_ctl + 67, GoalBuffer{h->goal_buf, h->goal_n, h->goal_stride}};
   if (mask_dev) HIPCHK(h, hipMemsetAsync(h->order_ctl + 67, 0, sizeof(unsigned), st));
   h->reset_listed = mask_dev != nullptr;
   JLAUNCH(h, jaco_reset_kernel, dim3((unsigned)((h->num_envs + 255) / 256)), dim3(256), 0, st, R);
@@ -667,6 +670,17 @@ extern "C" int jaco_set_noise(JacoHandle* h, const float* noise_dev) {
 extern "C" int jaco_set_subgoal(JacoHandle* h, const float* subgoal_dev) {
   if (!h) return JACO_EINVAL;
   h->subgoal = subgoal_dev;
+  return JACO_OK;
+}
+extern "C" int jaco_set_init_buffer(JacoHandle* h, const float* rows_dev, int nrows, int row_floats, void* stream) {
+  if (!h) return JACO_EINVAL;
+  ENTER(h);
+  if (h->goal_buf) { HIPCHK(h, hipStreamSynchronize((hipStream_t)stream)); HIPCHK(h, hipFree(h->goal_buf)); h->goal_buf = nullptr; h->goal_n = h->goal_stride = 0; }
+  if (!rows_dev) return JACO_OK;
+  if (nrows < 2 || row_floats < 7) { h->err = "jaco_set_init_buffer: needs at least 2 rows (np.random.randint(0, len - 1)) of at least 7 floats"; return JACO_EINVAL; }
+  HIPCHK(h, hipMalloc(&h->goal_buf, (size_t)nrows * row_floats * sizeof(float)));
+  HIPCHK(h, hipMemcpyAsync(h->goal_buf, rows_dev, (size_t)nrows * row_floats * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  h->goal_n = nrows; h->goal_stride = row_floats;
   return JACO_OK;
 }
 extern "C" int jaco_get_task_state(JacoHandle* h, float* out_dev, void* stream) {

@@ -132,6 +132,8 @@ struct JacoStepArgs {
   int auto_reset;            // mode 1, option "auto_reset": an env whose step ends its episode is reset (draws of _reset + sim.forward() + first
                              // observation) by the wave that finished it, instead of by a separate masked jaco_reset launch chain
   const float* qpos0;        // [nq] reset pose (auto_reset)
+  const float* goal_buf;     // auto_reset, optional: recorded reaching goals (jaco_set_init_buffer), [goal_n][goal_stride]
+  int goal_n, goal_stride;
   const float* subgoal;      // obs_mode 1, optional [nenv][6]: the policy's sub-goal offset; "subgoal_reach" marker = it + the previous target (:609)
   float* obs;                // [nenv][26]
   float* reward;             // [nenv]
@@ -1578,7 +1580,7 @@ JDEV int run_env(const JacoStepArgs& A_, JacoLDS<C>& s, int env, int nsub, int l
       float prev_tg[6];
       for (int k = 0; k < 6; k++) prev_tg[k] = s.task[JT_TARGET + k];
       take_action(m, s, A.action + (size_t)env * A.nact, A.nact, lane);
-      const unsigned cnt0 = __float_as_uint(s.task[JT_RNG]);
+      const unsigned cnt0 = rng_count(s.task[JT_RNG]);
       wave_sync();
       if (A.marker) {   // set_mocap_*("subgoal_reach", rule-based sub-goal) and set_mocap_*("hand", new target) (:613-615,:644-646)
         float nz[6], spos[3], sori[3];
@@ -1608,7 +1610,7 @@ JDEV int run_env(const JacoStepArgs& A_, JacoLDS<C>& s, int env, int nsub, int l
           for (int k = 0; k < 9; k++) { st_wt(P + 3 + k, MR.m[k]); Q[3 + k] = MR.m[k]; }
         }
       }
-      if (lane == 0 && A.obs_mode == 0) s.task[JT_RNG] = __uint_as_float(cnt0 + 6u);
+      if (lane == 0 && A.obs_mode == 0) s.task[JT_RNG] = rng_slot(cnt0 + 6u);
       wave_sync();
     }
     osc_target_quat(s, lane);
@@ -1661,7 +1663,7 @@ JDEV int run_env(const JacoStepArgs& A_, JacoLDS<C>& s, int env, int nsub, int l
       wave_sync();
       v3 pe; m3 Re;
       ee_frame(m, s, &pe, &Re);
-      const unsigned cnt0 = __float_as_uint(s.task[JT_RNG]);
+      const unsigned cnt0 = rng_count(s.task[JT_RNG]);
       const float gamma = -0.1f + 0.2f * (A.noise ? A.noise[(size_t)env * 12] : rng_uniform(A.seed, (unsigned)env, cnt0));
       float ori[3];
       grasp_reach_ori(pe, ld3(s.task + JT_OBJGOAL), gamma, ori);
@@ -1670,7 +1672,7 @@ JDEV int run_env(const JacoStepArgs& A_, JacoLDS<C>& s, int env, int nsub, int l
         float* t = s.task;
         for (int k = 0; k < 3; k++) { t[JT_TARGET + k] = t[JT_OBJGOAL + k]; t[JT_TARGET + 3 + k] = ori[k]; }
         t[JT_GRIP] = 0.6f; t[JT_GRIP_PREV] = 0.6f; t[JT_PHASE] = 1.f;
-        if (!A.noise) t[JT_RNG] = __uint_as_float(cnt0 + 1u);
+        if (!A.noise) t[JT_RNG] = rng_slot(cnt0 + 1u);
       }
       wave_sync();
     }
@@ -1938,7 +1940,7 @@ again:
     }
   }
   Ap = args_view(A_);   // (the epilogue reads the argument block afresh: nothing of it was carried through the substep loop)
-  bool reset_now = false;
+  bool reset_now = false, term_now = false;
   // Write-through stores for everything another workgroup may read or REWRITE before this launch set is over: an env that is handed over
   // (bailed), and -- option auto_reset -- every normal step's outputs, because a step that ends its episode is followed by the in-kernel
   // reset, whose forward pass may overflow the tier and be finished by a resident worker on another XCD: that workgroup rewrites the
@@ -1987,7 +1989,7 @@ again:
       v3 objgoal = ld3(s.task + JT_OBJGOAL), destgoal = ld3(s.task + JT_DESTGOAL);
       int touch = touch_class(sens, lane);
       float nz[6];
-      unsigned cnt = __float_as_uint(s.task[JT_RNG]);
+      unsigned cnt = rng_count(s.task[JT_RNG]);
       for (int k = 0; k < 6; k++) nz[k] = A.noise ? A.noise[(size_t)env * 12 + 6 + k] : rng_uniform(A.seed, (unsigned)env, cnt + k);
       float spos[3], sori[3];
       rulebased_subgoal(A.task_id, pe, objgoal, obj.y, destgoal, nz, spos, sori);
@@ -2015,10 +2017,11 @@ again:
           A.done[env] = done ? 1 : 0;
           if (done && A.terminal) { A.terminal[2 * (size_t)env] = (float)succ; A.terminal[2 * (size_t)env + 1] = wb; }   // (survives the in-kernel reset)
         }
-        reset_now = emode == 1 && A.auto_reset != 0 && wave_ballot(done) != 0ull;
+        term_now = emode == 1 && wave_ballot(done) != 0ull;
+        reset_now = term_now && A.auto_reset != 0;
       }
       if (fwd && lane == 0) { s.task[JT_FWD] = 0.f; s.task[JT_SUB] = 0.f; s.task[JT_PENDING] = 0.f; }
-      if (lane == 0 && emode != 5 && A.obs_mode == 0) s.task[JT_RNG] = __uint_as_float(cnt + 6u);
+      if (lane == 0 && emode != 5 && A.obs_mode == 0) s.task[JT_RNG] = rng_slot(cnt + 6u);
       if (lane < 26 && emode != 5) {
         float o;
         if (lane == 0) o = (float)touch;
@@ -2033,7 +2036,7 @@ again:
         else o = lane == 24 ? PI / 2.f : 0.f;
         if (!(fabsf(o) <= 3.0e38f)) o = 0.f;   // (quarantined env: the observation row stays finite)
         if (wt) st_wt(&A.obs[(size_t)env * 26 + lane], o); else A.obs[(size_t)env * 26 + lane] = o;
-        if (reset_now && A.terminal_obs) A.terminal_obs[(size_t)env * 26 + lane] = o;   // (what the learner's value bootstrap wants after a time-out)
+        if (term_now && A.terminal_obs) A.terminal_obs[(size_t)env * 26 + lane] = o;   // latched with (success, wb) by every terminal step, whoever resets the env (what the learner's value bootstrap wants after a time-out)
       }
     }
     if (left == 0 && (emode == 3 || emode == 6) && lane == 0) { s.task[JT_SUB] = 0.f; s.task[JT_PENDING] = 0.f; }
@@ -2056,7 +2059,7 @@ again:
     }
     wave_sync();
     if (lane == 0) {
-      reset_draws(A.task_id, A.seed, (unsigned)env, nq >= 23, m->base_pos, s.qpos, s.task);
+      reset_draws(A.task_id, A.seed, (unsigned)env, nq >= 23, m->base_pos, s.qpos, s.task, GoalBuffer{A.goal_buf, A.goal_n, A.goal_stride});
       s.task[JT_FWD] = 1.f;
       if (A.hint) st_wt_i(&A.hint[env], 0);   // a reset env starts from scratch, as under jaco_reset (a bigger tier that finishes the forward pass sets it again)
     }

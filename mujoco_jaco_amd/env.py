@@ -55,9 +55,6 @@ class JacoBatchedEnv:
         if kwargs.get("reward_method", None) is not None or kwargs.get("reward_module", None) is not None:
             raise NotImplementedError("reward_method / reward_module (env_mujoco_util.py:69-70,442-443: a Python callable evaluated per step) are not "
                                       "supported: the reward is computed inside the step kernel")
-        if kwargs.get("init_buffer", None) is not None:
-            raise NotImplementedError("init_buffer (reaching goals drawn from a recorded buffer, env_mujoco_util.py:46,208-212) is not supported: "
-                                      "goals are drawn by the in-kernel reset (:199-207)")
         self.n_robots = kwargs.get("n_robots", 1)
         if self.n_robots not in (1, 2):
             raise NotImplementedError("n_robots = %r: the reference ships models for one and two arms" % (self.n_robots,))
@@ -74,6 +71,11 @@ class JacoBatchedEnv:
         self.sim_tier_only = self.n_robots != 1
         if not self.rulebased_subgoal:
             self.sim.set_option("obs_mode", 1)
+        # init_buffer (env_mujoco_util.py:46,208-212): recorded rows the reaching goal of every reset is drawn from (row[1:4] position,
+        # row[4:7] orientation) instead of being sampled
+        self.goal_buffer = None
+        if kwargs.get("init_buffer", None) is not None:
+            self.set_init_buffer(kwargs["init_buffer"])
         # auto_reset=True (batched rollouts): an env whose step ends its episode is reset inside that very jaco_step call -- sim.reset(),
         # the draws of _reset, sim.forward() -- by the wavefront that finished it; step() then returns the terminal step's reward and
         # done flag together with the FIRST observation of the new episode (and the task row, success flag included, is the new
@@ -260,6 +262,19 @@ class JacoBatchedEnv:
 
     def successes(self):
         return self.task_state()[:, 29] > 0.5
+
+    def set_init_buffer(self, rows):
+        """rows: array-like / tensor [n >= 2, >= 7 floats per row] (the reference indexes buffer[i][1:4] and [4:7]); None = sample the goal."""
+        if rows is None:
+            self.sim._chk(self.L.jaco_set_init_buffer(self.h, None, 0, 0, self.sim._stream()))
+            self.goal_buffer = None
+            return
+        t = rows if torch.is_tensor(rows) else torch.as_tensor(np.asarray(rows, dtype=np.float32))
+        t = t.to(device=self.device, dtype=torch.float32).contiguous()
+        if t.ndim != 2:
+            raise ValueError("init_buffer must be a 2-D array of rows")
+        self.sim._chk(self.L.jaco_set_init_buffer(self.h, self._p(t), int(t.shape[0]), int(t.shape[1]), self.sim._stream()))
+        self.goal_buffer = t
 
     def last_terminal(self):
         """(success [num_envs] bool, wb [num_envs] f32) of every env's most recent terminal step -- `succ` and `wb` of

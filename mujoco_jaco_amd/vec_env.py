@@ -6,6 +6,11 @@ call (masked `jaco_reset`; with `auto_reset=True` -- tasks picking / reaching / 
 extra launches), their returned observation is the first one of the new episode and the last observation of
 the finished episode is kept in `infos["terminal_observation"]` rows, as SB's VecEnv does.  Everything stays on the GPU
 (`torch` tensors); `to_numpy=True` copies the four outputs to host arrays for learners that want numpy.
+
+`dense_infos=True` (needs `auto_reset=True`): the step issues NO host synchronisation -- no `done.any()`, no boolean-mask gather (whose
+result size the host would have to wait for).  `infos` then holds full-size device tensors, rows / entries valid where `done` is set:
+`terminal_observation [B,26]`, `episode_return [B]`, `episode_length [B]`, `is_success [B]`, plus `quarantined` as a 0-dim device
+tensor; a learner masks them with `done` on the device.  The default (sparse rows gathered with `[done]`) synchronises once per step.
 """
 import torch
 
@@ -13,7 +18,7 @@ from .env import JacoBatchedEnv
 
 
 class JacoVecEnv:
-    def __init__(self, num_envs, to_numpy=False, **kwargs):
+    def __init__(self, num_envs, to_numpy=False, dense_infos=False, **kwargs):
         assert int(num_envs) >= 2, "the vectorised adapter is for batches; JacoBatchedEnv(num_envs=1) is the reference's single-env surface"
         self.env = JacoBatchedEnv(num_envs=num_envs, **kwargs)
         self.num_envs = int(num_envs)
@@ -23,6 +28,10 @@ class JacoVecEnv:
         self.episode_returns = torch.zeros(self.num_envs, device=self.env.device)
         self.episode_lengths = torch.zeros(self.num_envs, dtype=torch.int64, device=self.env.device)
         self.quarantined_total = 0
+        self.dense_infos = bool(dense_infos)
+        if self.dense_infos and not self.env.auto_reset:
+            raise ValueError("dense_infos=True needs auto_reset=True on a task whose reset runs inside jaco_step (picking, reaching, pickAndplace, pushing)")
+        self.quarantined_total_dev = torch.zeros((), dtype=torch.int64, device=self.env.device)
 
     def _out(self, *ts):
         return tuple(t.cpu().numpy() for t in ts) if self.to_numpy else ts
@@ -40,7 +49,16 @@ class JacoVecEnv:
         obs, rew, done = obs.clone(), rew.clone(), done.clone()
         self.episode_returns += rew; self.episode_lengths += 1
         infos = {"terminal_observation": None, "episode_return": None, "episode_length": None, "is_success": None, "quarantined": 0}
-        if bool(done.any()) and self.env.auto_reset:
+        if self.dense_infos:
+            # no host round trip: everything is computed for every env and is meaningful where `done` is set
+            q = (((self.env.sim.flags() & 8) != 0) & done).sum()
+            self.quarantined_total_dev += q
+            self.env.sim.clear_flags()   # (the quarantine bit is sticky; the envs it belonged to have been reset inside jaco_step)
+            infos.update(terminal_observation=self.env.terminal_observation(), episode_return=self.episode_returns.clone(),
+                         episode_length=self.episode_lengths.clone(), is_success=self.env.last_terminal()[0], quarantined=q)
+            keep = ~done
+            self.episode_returns *= keep; self.episode_lengths *= keep
+        elif bool(done.any()) and self.env.auto_reset:
             # the env was reset inside jaco_step (option auto_reset): obs already holds the new episodes' first observations; what the
             # terminal step returned besides was latched by the kernel (jaco_get_terminal_obs / jaco_get_last_terminal)
             bad = (self.env.sim.flags() & 8) != 0

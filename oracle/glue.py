@@ -149,6 +149,16 @@ def sample_reach_goal(u01, base_pos):
     return np.hstack([pos, np.array([alpha, beta, gamma], dtype=np.float16)])
 
 
+def sample_reach_goal_from_buffer(buffer, u):
+    """__sample_goal with a goal buffer (kwarg init_buffer, env_mujoco_util.py:46,208-212): random_idx = np.random.randint(0, len(buffer) - 1),
+    i.e. one of rows 0 .. len - 2; the goal is buffer[idx][1:4] and [4:7] as they are (no float16 cast in this branch).  u: a uniform [0, 1)
+    draw standing for the reference's randint (the build's counter-based RNG supplies it).  Returns (goal[6], idx)."""
+    n = len(buffer)
+    idx = min(int(u * (n - 1)), n - 2)
+    row = np.asarray(buffer[idx], np.float64)
+    return np.hstack([row[1:4], row[4:7]]), idx
+
+
 def terminal(task, q2, ee_pos, obj_pos, dest_goal, touch, num_episodes, base_pos, ee_quat=None, reach_goal=None, picked=None, obj_vel=None):
     """_get_terminal_inspection (env_mujoco_util.py:492-600) for picking / placing (4-tuples in the reference) and reaching / grasping /
     pickAndplace / carrying / releasing / pushing (3-tuples there, which env_mujoco.py:125 cannot unpack: the success flag is the fix).

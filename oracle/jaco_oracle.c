@@ -63,6 +63,7 @@ struct OrcData {
   double *qM, *qL, *qfrc_bias, *qfrc_passive, *qfrc_actuator, *qfrc_smooth, *qacc_smooth, *qfrc_constraint, *qacc;
   double *actuator_force, *sensordata;
   int ncon, nefc, solver_iter;
+  double* scratch; long scratch_cap;   /* per-step work space of make_constraint / the solvers / integrate (one user at a time): no malloc per step */
   Contact* contact;
   double *efc_J, *efc_pos, *efc_margin, *efc_diagApprox, *efc_R, *efc_aref, *efc_b, *efc_force, *efc_vel, *efc_MinvJT, *efc_AR;
   int *efc_type, *efc_id; /* type 0 = limit (id = joint), 1 = contact (id = contact index) */
@@ -221,6 +222,10 @@ int orc_set_option(OrcModel* m, const char* n, double v) {
 }
 
 static double* dalloc(long n) { return (double*)calloc(n > 0 ? n : 1, sizeof(double)); }
+static double* scratch(OrcData* d, long n) {
+  if (n > d->scratch_cap) { free(d->scratch); d->scratch_cap = n + n / 2 + 64; d->scratch = (double*)malloc(sizeof(double) * d->scratch_cap); }
+  return d->scratch;
+}
 
 OrcData* orc_make_data(const OrcModel* m) {
   OrcData* d = (OrcData*)calloc(1, sizeof(OrcData));
@@ -270,7 +275,7 @@ void orc_free_data(OrcData* d) {
                  d->qfrc_constraint, d->qacc, d->actuator_force, d->sensordata, d->efc_J, d->efc_MinvJT, d->efc_AR, d->efc_pos,
                  d->efc_margin, d->efc_diagApprox, d->efc_R, d->efc_aref, d->efc_b, d->efc_force, d->efc_vel};
   for (size_t i = 0; i < sizeof(p) / sizeof(p[0]); i++) free(p[i]);
-  free(d->contact); free(d->efc_type); free(d->efc_id); free(d);
+  free(d->contact); free(d->efc_type); free(d->efc_id); free(d->scratch); free(d);
 }
 void orc_reset(const OrcModel* m, OrcData* d) {
   memcpy(d->qpos, m->qpos0, sizeof(double) * m->nq);
@@ -1008,8 +1013,8 @@ static void make_constraint(const OrcModel* m, OrcData* d) {
     }
   }
   /* contacts, pyramidal friction cone */
-  double *jp1 = (double*)malloc(sizeof(double) * 12 * nv), *jr1 = jp1 + 3 * nv, *jp2 = jr1 + 3 * nv, *jr2 = jp2 + 3 * nv;
-  double* Jc = (double*)malloc(sizeof(double) * 6 * nv);
+  double *jp1 = scratch(d, 18 * nv), *jr1 = jp1 + 3 * nv, *jp2 = jr1 + 3 * nv, *jr2 = jp2 + 3 * nv;
+  double* Jc = jp1 + 12 * nv;
   for (int c = 0; c < d->ncon; c++) {
     Contact* con = d->contact + c;
     int b1 = m->geom_bodyid[con->geom1], b2 = m->geom_bodyid[con->geom2], dim = con->dim;
@@ -1043,7 +1048,6 @@ static void make_constraint(const OrcModel* m, OrcData* d) {
       for (int e = 0; e < nrow; e++) d->efc_R[con->efc_address + e] = fmax(MINVAL, Rpy);
     }
   }
-  free(jp1); free(Jc);
   d->nefc = r;
 }
 
@@ -1098,11 +1102,10 @@ static void solve_pgs(const OrcModel* m, OrcData* d) {
   d->solver_iter = it;
   for (int r = 0; r < ne; r++)
     for (int i = 0; i < nv; i++) d->qfrc_constraint[i] += d->efc_J[r * nv + i] * d->efc_force[r];
-  double* t = (double*)malloc(sizeof(double) * nv);
+  double* t = scratch(d, nv);
   memcpy(t, d->qfrc_constraint, sizeof(double) * nv);
   chol_solve(d->qL, t, nv);
   for (int i = 0; i < nv; i++) d->qacc[i] = d->qacc_smooth[i] + t[i];
-  free(t);
 }
 
 
@@ -1133,7 +1136,7 @@ static void solve_newton(const OrcModel* m, OrcData* d) {
   memcpy(d->qacc, d->qacc_smooth, sizeof(double) * nv);
   d->solver_iter = 0;
   if (!ne) return;
-  double* w = (double*)malloc(sizeof(double) * (6 * nv + 2 * nv * nv + 2 * ne));
+  double* w = scratch(d, 6 * nv + 2 * nv * nv + 2 * ne);
   double *a = w, *Ma = a + nv, *grad = Ma + nv, *p = grad + nv, *Mp = p + nv, *t = Mp + nv, *H = t + nv, *L = H + nv * nv;
   double *x = L + nv * nv, *jp = x + ne;
   double scale = 1 / (m->meaninertia * (nv > 1 ? nv : 1));
@@ -1203,7 +1206,6 @@ static void solve_newton(const OrcModel* m, OrcData* d) {
     d->efc_force[r] = x[r] < 0 ? -x[r] / d->efc_R[r] : 0;
     for (int i = 0; i < nv; i++) d->qfrc_constraint[i] += d->efc_J[r * nv + i] * d->efc_force[r];
   }
-  free(w);
 }
 
 /* ------------------------------------------------------------------ 8. touch sensors
@@ -1299,17 +1301,16 @@ void orc_forward(const OrcModel* m, OrcData* d) {
 static void integrate(const OrcModel* m, OrcData* d) {
   int nv = m->nv;
   double h = m->timestep;
-  double* qacc = (double*)malloc(sizeof(double) * nv);
+  double* qacc = scratch(d, nv + 2 * nv * nv);
   int damped = 0;
   for (int i = 0; i < nv; i++) if (m->dof_damping[i] > 0) damped = 1;
   if (damped) {
-    double *Mh = (double*)malloc(sizeof(double) * nv * nv * 2), *L = Mh + nv * nv;
+    double *Mh = qacc + nv, *L = Mh + nv * nv;
     memcpy(Mh, d->qM, sizeof(double) * nv * nv);
     for (int i = 0; i < nv; i++) Mh[i * nv + i] += h * m->dof_damping[i];
     cholesky(L, Mh, nv);
     for (int i = 0; i < nv; i++) qacc[i] = d->qfrc_smooth[i] + d->qfrc_constraint[i];
     chol_solve(L, qacc, nv);
-    free(Mh);
   } else {
     memcpy(qacc, d->qacc, sizeof(double) * nv);
   }
@@ -1332,7 +1333,6 @@ static void integrate(const OrcModel* m, OrcData* d) {
       d->qpos[qa] += h * d->qvel[da];
     }
   }
-  free(qacc);
 }
 void orc_step(const OrcModel* m, OrcData* d) {
   if (m->round_state >= 2) {

@@ -87,13 +87,19 @@ static int emu_launch(JacoStepArgs A, int* heavy_envs) {
 static int g_auto_reset = 0;
 static std::vector<float> g_qpos0;
 extern "C" void emu_set_auto_reset(int on, const float* qpos0, int nq) { g_auto_reset = on; g_qpos0.assign(qpos0, qpos0 + nq); }
+static std::vector<float> g_goal_buf;   // kwarg init_buffer (jaco_set_init_buffer of the library)
+static int g_goal_n = 0, g_goal_stride = 0;
+extern "C" void emu_set_init_buffer(const float* rows, int nrows, int stride) {
+  g_goal_buf.assign(rows, rows + (rows ? (size_t)nrows * stride : 0)); g_goal_n = rows ? nrows : 0; g_goal_stride = rows ? stride : 0;
+}
 // what jaco_reset_kernel does for one env (jaco_env.hip): sim.reset() + the draws; the forward pass is a mode-2 emu_env_call
 extern "C" void emu_reset_env(int task_id, unsigned long long seed, int env, int nq, int nv, const float* qpos0, const float* base, float* qpos, float* qvel,
                               float* qacc_ws, float* task, float* marker, const float* marker_rest) {
   for (int k = 0; k < nq; k++) qpos[(size_t)env * nq + k] = qpos0[k];
   for (int k = 0; k < nv; k++) { qvel[(size_t)env * nv + k] = 0.f; qacc_ws[(size_t)env * nv + k] = 0.f; }
   for (int k = 0; k < 24; k++) marker[(size_t)env * 24 + k] = marker_rest[k];
-  reset_draws(task_id, seed, (unsigned)env, nq >= 23, base, qpos + (size_t)env * nq, task + (size_t)env * JTASK_N);
+  reset_draws(task_id, seed, (unsigned)env, nq >= 23, base, qpos + (size_t)env * nq, task + (size_t)env * JTASK_N,
+              GoalBuffer{g_goal_buf.empty() ? nullptr : g_goal_buf.data(), g_goal_n, g_goal_stride});
 }
 extern "C" int emu_env_call(const void* blob, long blob_size, int nenv, int mode, int frame_skip, int task_id, int nact, unsigned long long seed,
                             float* qpos, float* qvel, float* qacc_ws, float* sensordata, unsigned* flags, int* stats, float* task, float* cache,
@@ -106,6 +112,7 @@ extern "C" int emu_env_call(const void* blob, long blob_size, int nenv, int mode
   A.flags = flags; A.stats = stats; A.nenv = nenv; A.nsub = mode == 2 ? 1 : frame_skip; A.env_mode = mode; A.task_id = task_id; A.nact = nact;
   A.seed = seed; A.task = task; A.cache = cache; A.action = action; A.noise = noise; A.obs = obs; A.reward = reward; A.done = done; A.marker = marker; A.dbg_env = -1;
   A.auto_reset = g_auto_reset && mode == 1 && (task_id == 0 || task_id == 2 || task_id == 4 || task_id == 7); A.qpos0 = g_qpos0.empty() ? nullptr : g_qpos0.data();
+  A.goal_buf = g_goal_buf.empty() ? nullptr : g_goal_buf.data(); A.goal_n = g_goal_n; A.goal_stride = g_goal_stride;
   return emu_launch(A, heavy_envs);
 }
 // rest pose of the two task-layer markers (what jaco_reset_state writes): 24 floats

@@ -119,6 +119,15 @@ class EmuJacoEnv(EmuEnv):
         q0 = np.ascontiguousarray(self.M["qpos0"], np.float32)
         self.L.emu_set_auto_reset(int(on), q0.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), self.nq)
 
+    def set_init_buffer(self, rows):
+        """kwarg init_buffer (jaco_set_init_buffer of the library): recorded rows every reset draws its reaching goal from; None = sampled goals."""
+        self.L.emu_set_init_buffer.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_int, ctypes.c_int]
+        if rows is None:
+            self.L.emu_set_init_buffer(None, 0, 0)
+            return
+        r = np.ascontiguousarray(rows, np.float32)
+        self.L.emu_set_init_buffer(r.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), r.shape[0], r.shape[1])
+
     def reset_env(self, env, noise=None):
         """jaco_reset(mask = {env}): the reset kernel's work for one env, then the forward pass + observation (mode 2; here for all envs,
         which is harmless for the others: a forward pass does not change state)."""

@@ -233,7 +233,7 @@ def test_action_taken_once_when_a_step_overflows_in_its_first_substep(names, mod
         assert e.flags[0] & 32 and e.stats[0, 1] > 128                       # the scenario really left the light and the medium tier
         assert abs(e.task[0, 0] - (0.7 + 0.1 * step)) < 1e-6 and abs(e.task[0, 16] - (0.6 + 0.1 * step)) < 1e-6   # gripper: one increment per step
         assert abs(obs[0, 7] - oo[7]) < 1e-6 and np.abs(e.qpos[0, 6:9] - oe.o.get("qpos")[6:9]).max() < 1e-4
-        assert int(e.task[0, 18:19].view(np.uint32)[0]) == 12 * (step + 1) + 6   # draw counter: 6 (reset obs) + 12 per step
+        assert int(e.task[0, 18:19].view(np.uint32)[0]) & 0x1FFFFFFF == 12 * (step + 1) + 6   # draw counter (JT_RNG: count | bit 30): 6 (reset obs) + 12 per step
 
 
 # ---------------------------------------------------------------- tasks grasping / pickAndplace (round 3)
@@ -538,3 +538,36 @@ def test_action_is_clipped_inside_the_kernel(names, model_arrays):
         outs.append((e.task[0].copy(), e.qpos[0].copy(), e.obs[0].copy()))
     for x, y in zip(*outs):
         assert np.array_equal(x, y)
+
+
+def test_reset_draws_the_reaching_goal_from_an_init_buffer(model_arrays):
+    """kwarg init_buffer (env_mujoco_util.py:46,208-212): with a goal buffer the reset takes its reaching goal from a random row -- rows
+    0 .. n - 2 (np.random.randint(0, n - 1)), position row[1:4], orientation row[4:7], no float16 cast -- and the draws that follow (object
+    and destination goals) stay in their ranges.  The buffer is the one of tests/golden/glue_vectors_init_buffer.npz, where the reference's
+    own branch returned exactly these rows (tests/test_glue_golden.py)."""
+    import os
+    import glue
+    B = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "glue_vectors_init_buffer.npz"))
+    buf = B["buffer"].astype(np.float32)
+    n = len(buf)
+    nenv = 160
+    e = EmuJacoEnv(nenv=nenv, task_id=2, seed=11)      # task reaching
+    e.set_init_buffer(buf)
+    try:
+        seen = set()
+        for k in range(nenv):
+            e.reset_env(k)
+            goal = e.task[k, 32:38]
+            hits = [i for i in range(n) if np.array_equal(goal, np.hstack([buf[i, 1:4], buf[i, 4:7]]))]
+            assert len(hits) == 1 and hits[0] <= n - 2, (k, goal)
+            assert np.array_equal(goal.astype(np.float64), glue.sample_reach_goal_from_buffer(buf, (hits[0] + 0.5) / (n - 1))[0])
+            seen.add(hits[0])
+            assert -0.1 <= e.qpos[k, 9] <= 0.1 and 0.57 <= e.qpos[k, 10] <= 0.67 and abs(e.qpos[k, 11] - 0.1898) < 1e-7
+            assert 0.35 <= e.qpos[k, 16] <= 0.45 and 0.25 <= e.qpos[k, 17] <= 0.35
+        assert seen == set(range(n - 1))               # every row but the last is drawn
+        # in-kernel auto-reset draws from the same buffer with the same stream: bit-identical to the explicit reset
+        e.set_init_buffer(None)
+        e.reset_env(0)
+        assert not any(np.array_equal(e.task[0, 32:38], np.hstack([buf[i, 1:4], buf[i, 4:7]])) for i in range(n))   # back to sampled goals
+    finally:
+        e.set_init_buffer(None)

@@ -183,3 +183,16 @@ def test_releasing_carrying_pushing_terminal_match_reference(GR):
     assert list(GR["act_width"]) == [7, 7, 6] and list(GR["task_max_steps"]) == [500, 500, 500]
     assert glue.env_terminal("releasing", 499, 1.3, np.ones(3), np.ones(3), np.ones(3), 0, 0, np.zeros(3), obj_vel=np.zeros(3)) == (True, -10.0, 0.0, 0)
     assert GR["init_pushing_raises"][0] == 1                                    # the reference cannot reset task 'pushing' (documented in env.py)
+
+
+# ---- kwarg init_buffer (tests/golden/make_glue_vectors_init_buffer.py ran the reference's own goal_buffer branch)
+def test_goal_buffer_branch_of_sample_goal():
+    B = np.load(os.path.join(ROOT, "tests", "golden", "glue_vectors_init_buffer.npz"))
+    buf, n = B["buffer"], len(B["buffer"])
+    for i, want in zip(B["idx"], B["reach_goal"]):
+        # any uniform draw that lands in bin i of the n - 1 equal bins stands for the reference's randint result i
+        got, idx = glue.sample_reach_goal_from_buffer(buf, (i + 0.5) / (n - 1))
+        assert idx == i and np.array_equal(got, want)                       # row[1:4], row[4:7], untouched (no float16 cast)
+    assert int(B["largest_index_in_4000_draws"][0]) == n - 2               # numpy's randint(0, n - 1): the last row is never drawn
+    assert glue.sample_reach_goal_from_buffer(buf, 0.999999)[1] == n - 2 and glue.sample_reach_goal_from_buffer(buf, 0.0)[1] == 0
+    assert set(B["idx"].tolist()) <= set(range(n - 1))

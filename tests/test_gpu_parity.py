@@ -44,7 +44,7 @@ def _oracle_batch_stats(model, q, v, w, c, nsub, round_state=False):
         o.option("round_state", 1)
     q, v, w = q.copy(), v.copy(), w.copy()
     st = np.zeros((q.shape[0], 4), np.int32)
-    o.step_batch(q, v, w, np.ascontiguousarray(c), nsub=nsub, nthreads=os.cpu_count(), stats=st)
+    o.step_batch(q, v, w, np.ascontiguousarray(c), nsub=nsub, nthreads=len(os.sched_getaffinity(0)), stats=st)
     return q, v, w, st
 
 
@@ -125,7 +125,7 @@ def _drift_vs_control(model_arrays, B, nsub, seed, compensated=1, control=3):
     qo, _, _, _ = _oracle_batch_stats("jaco2_curtain_torque", q, z, z, c, nsub)
     oc = Oracle("jaco2_curtain_torque"); oc.option("round_state", control)
     qc = q.copy(); vc = z.copy(); wc = z.copy()
-    oc.step_batch(qc, vc, wc, np.ascontiguousarray(c), nsub=nsub, nthreads=os.cpu_count())
+    oc.step_batch(qc, vc, wc, np.ascontiguousarray(c), nsub=nsub, nthreads=len(os.sched_getaffinity(0)))
     err, ctl = np.abs(gq - qo).max(1), np.abs(qc - qo).max(1)
     fl = env.flags().cpu().numpy()
     print("drift after %d substeps (compensated %d): HIP median %.2e p90 %.2e max %.2e (<= 1e-4: %.1f %%) | fp64 control %d: median %.2e p90 %.2e max %.2e (<= 1e-4: %.1f %%)" % (

@@ -51,7 +51,7 @@ def run(model, B, contact, scale, variant, seed=41):
     stats = np.zeros((B, 4), np.int32)
     smax = np.zeros((B, 4), np.int32)
     for mark in MARKS:
-        o.step_batch(q, v, w, c, nsub=mark - done, nthreads=os.cpu_count(), stats=stats)
+        o.step_batch(q, v, w, c, nsub=mark - done, nthreads=len(os.sched_getaffinity(0)), stats=stats)
         smax = np.maximum(smax, stats)
         done = mark
         out[mark] = q.copy()

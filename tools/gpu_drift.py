@@ -29,7 +29,7 @@ def run(model, B, nsub, contact, scale, save=None, comp=1):
     done = 0
     for mark in (100, 300, 1000):
         env.send_forces(t(c), nsub=mark - done)
-        o.step_batch(qo, vo, wo, cc, nsub=mark - done, nthreads=os.cpu_count())   # in place
+        o.step_batch(qo, vo, wo, cc, nsub=mark - done, nthreads=len(os.sched_getaffinity(0)))   # in place
         done = mark
         err = np.abs(env.get_state()[0].cpu().numpy().astype(np.float64) - qo).max(1)
         out[mark] = err
