@@ -983,8 +983,10 @@ JDEV void stage_contact_rows(const JacoModelDev* m, L& s, int lane, unsigned& fl
     if (lane < kept) {
       s.c_efc[ci] = r0;
       int blk = ((mm & ((1u << JB0) - 1u)) ? 1 : 0) | (((mm >> JB0) & ((1u << (JB1 - JB0)) - 1u)) ? 2 : 0) | ((mm >> JB1) ? 4 : 0);
+      // body-space rows carry their body pair: (fused body + 1) of geom 1 / geom 2, 0 = static (c_ob keeps them at bits 8 / 24)
+      const int bodies = L::Caps::WRENCH ? ((((s.c_ob[ci] >> 8) & 31) << 19) | (((s.c_ob[ci] >> 24) & 31) << 24)) : 0;
       if (!sidec) for (int e = 0; e < nrow; e++) {
-        s.e_con[r0 + e] = ci | (e << 8) | (blk << 16);
+        s.e_con[r0 + e] = ci | (e << 8) | (blk << 16) | bodies;
         s.e_f[r0 + e] = e < 4 ? mu0 : (e < 6 ? mu1 : mu2);   // friction of the row's pyramid edge (e_f is free until the solver runs)
       }
       pa0[ci] = a0; pbc[ci] = bcoef; s.c_fn[ci] = dinv;
@@ -1010,6 +1012,23 @@ JDEV void stage_contact_rows(const JacoModelDev* m, L& s, int lane, unsigned& fl
         for (int e = 0; e < 4; e++) if (e < nrow) { sd[JSIDE_AREF + r0 - JSIDE_BASE + e] = aside[e]; sd[JSIDE_D + r0 - JSIDE_BASE + e] = dinv; }
       }
     }
+    if (L::Caps::WRENCH) {
+      // the rows themselves, lane = row: wrench of pyramid edge e of contact c about the world origin -- linear part dir = n +- mu t_k
+      // (k < 3) or n (torsional / rolling edges), angular part pos x dir (+- mu axis_k for k >= 3) -- so that J[r][d] = sgn_d(r) w . S_d
+      for (int rr = rowbase + lane; rr < total; rr += 64) {
+        const int ce = s.e_con[rr], c = ce & 255, e = (ce >> 8) & 15, pd = s.c_dim[c];
+        const int kf = pd == 1 ? 0 : 1 + (e >> 1);
+        const float smu = ((e & 1) ? -1.f : 1.f) * s.e_f[rr];
+        const float* fr = s.c_frame[c];
+        const v3 n = ld3(fr), pos = ld3(s.c_pos[c]);
+        v3 lin = n, ang = mk3(0.f, 0.f, 0.f);
+        if (kf == 1 || kf == 2) lin = n + ld3(fr + 3 * kf) * smu;
+        if (kf >= 3) ang = ld3(fr + 3 * (kf - 3)) * smu;
+        ang = ang + cross(pos, lin);
+        float* R = s.J + 8 * rr;
+        R[0] = ang.x; R[1] = ang.y; R[2] = ang.z; R[3] = lin.x; R[4] = lin.y; R[5] = lin.z; R[6] = 0.f; R[7] = 0.f;
+      }
+    } else
     for (int c0 = 0; c0 < kept; c0 += CPP) {
       int c = c0 + (cl < CPP ? cl : 0);
       int src = c < 64 ? c : 0;

@@ -23,10 +23,22 @@
 //   heavy: <= 256 rows / 64 contacts -> 4 rows per lane, ~43 KB LDS, for envs that overflow medium;
 //   huge: <= 512 rows / 128 contacts -> 8 rows per lane, ~80 KB LDS, for envs that overflow heavy (beyond that rows are dropped and flagged).
 // A light wave that meets an overflow hands its env (state untouched for that substep) to the heavy launch.
+// Constraint rows in body space (round 5; -DJACO_WRENCH=0 builds the dense rows of rounds 1-4 for comparison).  A contact row is
+// J_r = w_r^T (J_B - J_A): a 6-vector wrench w_r = (pos x dir + rotational part, dir) applied to the motion subspaces S_k of the dofs that move
+// body B but not body A (and with the opposite sign vice versa).  The row is stored as that wrench (8 floats with the solver's two per-row
+// staging slots) plus the two body ids -- 48 bytes with its parameters instead of 100 -- and every product with J is formed from it:
+//   J v      = w . (V_B - V_A),  V_b = sum over the chain of b of S_k v_k   (one 6-vector per body, then 12 LDS reads per row)
+//   J^T D J  = the matrix-core pass generates its J entries on the fly: lane (column k) holds S_k and forms sgn_k(r) w_r . S_k per row
+//   J^T f    = S_k . (sum of the contacts' wrenches acting below dof k)
+// so the light tier holds 128 rows in the LDS that used to hold 64.  Joint-limit rows (J = +-e_d) are "unit rows": flag + dof + sign.
+#ifndef JACO_WRENCH
+#define JACO_WRENCH 1
+#endif
 template <int MAXEFC_, int MAXCON_, int MAXCAND_, bool CONTACT_ = true>
 struct JacoCaps {
   static_assert(MAXEFC_ % 64 == 0, "rows are dealt out 64 at a time (one per lane): the row capacity must be a multiple of 64");
-  static_assert(JMAXGEOM != 64 || JNV != 21 || MAXCAND_ <= MAXEFC_ * 25 - 520 - 256 - 576, "default layout: the candidate list must fit behind the geom poses in the constraint-row area");
+  static constexpr bool WRENCH = CONTACT_ && JACO_WRENCH != 0;
+  static_assert(WRENCH || JMAXGEOM != 64 || JNV != 21 || MAXCAND_ <= MAXEFC_ * 25 - 520 - 256 - 576, "default layout: the candidate list must fit behind the geom poses in the constraint-row area");
   static constexpr int MAXEFC = MAXEFC_, MAXCON = MAXCON_, MAXCAND = MAXCAND_, NR = MAXEFC_ / 64;
   // CONTACT = false: the contact-free instantiation (arm-only models, option disable_contact): no geom poses, no contact list, and
   // Jacobian storage for the joint-limit rows only (at most one per body)
@@ -37,7 +49,11 @@ struct JacoCaps {
 // Candidates = bounding-sphere survivors (closed fingers alone contribute > 64; with the EE sticks on the marker's sticks 130-200): their
 // list shares LDS with the constraint rows, which are bigger, so its capacity costs nothing -- and it must not be what sends
 // an env to a bigger tier (round 2 found 74 % of the envs of a small-action rollout in the heavy tier because of a 128-entry list).
+#if JACO_WRENCH
+typedef JacoCaps<128, 32, 240> JacoLight;    // body-space rows: 128 rows x 48 B fit where 64 dense rows x 100 B did
+#else
 typedef JacoCaps<64, 32, 240> JacoLight;
+#endif
 typedef JacoCaps<128, 32, 512> JacoMedium;   // (32 contacts x 4 pyramid rows = 128 rows; 20.2 KB -> 8 envs per CU = the 2 waves per SIMD its 256 VGPRs allow)  2 rows per lane: the EE axis sticks resting on the "hand" marker's sticks add ~36 rows to the usual 32
 #ifndef JACO_HEAVY_ROWS
 #define JACO_HEAVY_ROWS 256
@@ -49,6 +65,9 @@ typedef JacoCaps<64, 1, 1, false> JacoArm;    // contact-free: 8.4 KB of LDS, 12
 typedef JacoCaps<512, 128, 512> JacoHuge;    // 8 rows per lane: a reset that puts the hand inside the pedestal (1 % of picking resets: up to ~90 contacts / ~410 rows)
 #define JDBG_MAXCON 64
 #define JDBG_MAXEFC 256
+#define JW_WT 6       // body-space row record: slot of the solver's row weight (D on active rows, else 0)
+#define JW_X 7        // ... and of the row residual J a - aref
+#define JW_UNIT (1 << 30)   // e_con flag of a joint-limit row: J = w[0] e_dof
 #define JLD (JNV)     // row stride of per-row dof vectors in LDS (21: odd, conflict-free for lane-per-row access)
 
 #define JFLAG_CON_OVERFLOW 1u
@@ -232,9 +251,12 @@ struct JacoLDS {
   };
   union {
     struct {                                    // row builders .. Euler: constraint rows
-      alignas(16) float J[C::JROWS * JLD];
+      // dense rows: J[r][JLD]; body-space rows (C::WRENCH): 8 floats per row = wrench (angular 3, linear 3), then the solver's two staging
+      // slots (JW_WT: D * active, JW_X: residual); never smaller than the JSCRATCH floats the early stages borrow
+      alignas(16) float J[C::WRENCH ? (8 * C::MAXEFC > JSCRATCH ? 8 * C::MAXEFC : JSCRATCH) : C::JROWS * JLD];
       float e_aref[C::MAXEFC], e_D[C::MAXEFC], e_f[C::MAXEFC];
-      int e_con[C::MAXEFC];                     // contact | edge << 8 | block bits << 16
+      int e_con[C::MAXEFC];                     // contact | edge << 8 | block bits << 16; body-space rows: | (body A + 1) << 19 | (body B + 1) << 24 (0: static),
+                                                // joint-limit rows: JW_UNIT | dof << 19
     };
     struct {                                    // tree walk .. collision: geom poses, broadphase survivors
       float early_scratch[JSCRATCH];
@@ -243,7 +265,7 @@ struct JacoLDS {
       int cand[C::MAXCAND];
     };
   };
-  float e_x[C::MAXEFC > 64 ? C::MAXEFC : 1];    // heavy tier only: residuals staged for the MFMA pass (light reuses `smooth`)
+  float e_x[(C::MAXEFC > 64 && !C::WRENCH) ? C::MAXEFC : 1];    // dense rows, bigger tiers: residuals staged for the MFMA pass (light reuses `smooth`)
   int ncon, nefc, ncand, nlimit, nsphere;      // (ncand: narrowphase candidates after the OBB cull; nsphere: bounding-sphere survivors before it)
   int nside, nside_cand;                       // rows in the side buffer (light tier, split mode; collision.h) / rows that could go there (every tier)
   float task[JTASK_FLOATS];                    // (= JTASK_N of env_logic.h)
@@ -254,6 +276,7 @@ struct JacoLDS {
     int b_jtype[JNB], b_qadr[JNB], b_dadr[JNB], b_parent[JNB];
     int inner_body[JMAXINNER];
     unsigned b_descmask[JNB];
+    unsigned b_chain[JNB];                      // bit d set: dof d moves body b
     int b_anc[JNB][3];                          // ancestors 1, 2 and 4 levels up (-1: none), for the pointer-jumping tree stages
     int d_body[JNV], d_parent[JNV];
     int q_dof[JNQ + 1];                         // dof that advances position coordinate q linearly (hinge angle, free-body translation), -1: quaternion component
@@ -272,6 +295,7 @@ JDEV void stage_model(const JacoModelDev* m, L& s, int lane) {
     int p1 = m->b_parent[b], p2 = p1 >= 0 ? m->b_parent[p1] : -1, p3 = p2 >= 0 ? m->b_parent[p2] : -1, p4 = p3 >= 0 ? m->b_parent[p3] : -1;
     s.mc.b_parent[b] = p1;
     s.mc.b_descmask[b] = m->b_descmask[b];
+    s.mc.b_chain[b] = m->b_chainmask[b];
     if (b < JMAXINNER) s.mc.inner_body[b] = m->inner_body[b];
     s.mc.b_anc[b][0] = p1; s.mc.b_anc[b][1] = p2; s.mc.b_anc[b][2] = p4;
     const int qa = m->b_qadr[b], da = m->b_dadr[b];
@@ -976,12 +1000,17 @@ JDEV void stage_limit_rows(const JacoModelDev* m, L& s, int lane, const StagePre
   unsigned long long mask = wave_ballot(act);
   int r = wave_prefix_count(mask);
   if (act) {
-    for (int k = 0; k < JNV; k++) s.J[r * JLD + k] = 0.f;
-    s.J[r * JLD + d] = sgn;
+    if (L::Caps::WRENCH) {
+      for (int k = 0; k < 8; k++) s.J[r * 8 + k] = 0.f;
+      s.J[r * 8] = sgn;
+    } else {
+      for (int k = 0; k < JNV; k++) s.J[r * JLD + k] = 0.f;
+      s.J[r * JLD + d] = sgn;
+    }
     float R;
     s.e_aref[r] = row_params(m->b_solref[lane], m->b_solimp[lane], dist, sgn * s.qvel[d], m->d_invweight[d], &R);
     s.e_D[r] = 1.f / R;
-    s.e_con[r] = (d < JB0 ? 1 : (d < JB1 ? 2 : 4)) << 16;
+    s.e_con[r] = ((d < JB0 ? 1 : (d < JB1 ? 2 : 4)) << 16) | (L::Caps::WRENCH ? (JW_UNIT | (d << 19)) : 0);
   }
   if (lane == 0) { s.nefc = popc64(mask); s.nlimit = s.nefc; }
 }
@@ -1257,6 +1286,277 @@ JDEV NewtonOut stage_newton(const JacoModelDev* m, L& s, const float (&mrow)[JNV
   out.iters = it | (nls << 8);
 #pragma unroll
   for (int q = 0; q < NR; q++) if (valid[q]) s.e_f[lane + 64 * q] = f[q];
+  return out;
+}
+
+// ---------------------------------------------------------------- stage S on body-space rows (JacoCaps::WRENCH)
+// A lane's dof column: the motion subspace S_col (angular, linear at the world origin) and the bodies the dof moves (bit b + 1; bit 0 = static, never set).
+struct WCol { sv S; unsigned mv; };
+template <class L>
+JDEV WCol wcol_load(const L& s, int col, int nv) {
+  WCol c;
+  const bool ok = col < nv;
+  c.S = ldsv(s.cdof[ok ? col : 0]);
+  if (!ok) { c.S.a = mk3(0.f, 0.f, 0.f); c.S.b = mk3(0.f, 0.f, 0.f); }
+  c.mv = ok ? s.mc.b_descmask[s.mc.d_body[col]] << 1 : 0u;
+  return c;
+}
+// J[r][col] of a row record (a = w[0..3], b = w[4], w[5], weight, residual) with e_con word `con`
+JDEV float wrow_entry(const WCol& c, int col, const v4& a, const v4& b, int con) {
+  const float sgn = (float)((int)((c.mv >> ((con >> 24) & 31)) & 1u) - (int)((c.mv >> ((con >> 19) & 31)) & 1u));
+  const float body = sgn * (a.x * c.S.a.x + a.y * c.S.a.y + a.z * c.S.a.z + a.w * c.S.b.x + b.x * c.S.b.y + b.y * c.S.b.z);
+  return (con & JW_UNIT) ? (((con >> 19) & 31) == col ? a.x : 0.f) : body;
+}
+// out[q] = (J v)[row(q)]: v (one element per dof lane) -> one 6-vector per CONTACT, D_c = sum of S_k v_k over the dofs that move body B but not
+// body A minus the same over those that move A but not B (lane = (contact, component); dofs common to both chains are left out exactly, as in a
+// dense row -- formed per body and subtracted, two arm bodies' common prefix would cost the difference its last bits) -> w . D_c per row.
+// D_c is staged in the contact frame's tangent slots (dead since the row builder); a joint-limit row reads v[dof].  `vs`: v in LDS (s.smooth + 32).
+template <int NR, class L>
+JDEV void rows_dot_w(L& s, const float (&w)[NR][6], const int (&con)[NR], float vk, int lane, int nv, int ncon, float (&out)[NR]) {
+  float* vs = s.smooth + 32;
+  wave_sync();   // the previous call's readers of vs / the staged vectors are done
+  if (lane < nv) vs[lane] = vk;
+  wave_sync();
+  for (int idx = lane; idx < 6 * ncon; idx += 64) {
+    const int c = idx / 6, comp = idx - 6 * c, obs = s.c_ob[c];
+    const int B1 = (obs >> 8) & 31, B2 = (obs >> 24) & 31;
+    const unsigned m1 = B1 ? s.mc.b_chain[B1 - 1] : 0u, m2 = B2 ? s.mc.b_chain[B2 - 1] : 0u;
+    const unsigned plus = m2 & ~m1;
+    unsigned mask = m1 ^ m2;
+    float acc = 0.f;
+    while (mask) {
+      const int k = __builtin_ctz(mask);
+      mask &= mask - 1u;
+      const float t = s.cdof[k][comp] * vs[k];
+      acc += ((plus >> k) & 1u) ? t : -t;
+    }
+    s.c_frame[c][3 + comp] = acc;
+  }
+  wave_sync();
+#pragma unroll
+  for (int q = 0; q < NR; q++) {
+    const bool unit = (con[q] & JW_UNIT) != 0;
+    const float* Dc = s.c_frame[unit ? 0 : (con[q] & 255)] + 3;
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < 6; c++) acc += w[q][c] * Dc[c];
+    out[q] = unit ? w[q][0] * vs[(con[q] >> 19) & 31] : acc;
+  }
+}
+
+// The same primal Newton iteration as stage_newton (start point, tolerances, block logic, exact line search), on body-space rows.
+template <class L>
+JDEV NewtonOut stage_newton_w(const JacoModelDev* m, L& s, const float (&mrow)[JNV], float smooth, float hd, int lane, JProfCtx& pc) {
+  (void)pc;
+  constexpr int NR = L::Caps::NR, MAXEFC = L::Caps::MAXEFC;
+  NewtonOut out;
+  const int nv = m->nv, ncon = wave_uniform_i(s.ncon), nlim = wave_uniform_i(s.nlimit);
+  int ne = wave_uniform_i(s.nefc);
+  out.qfrc_con = 0.f; out.iters = 0; out.qdamped = 0.f; out.have_qdamped = false;
+  float h0[JNV];
+#pragma unroll
+  for (int j = 0; j < JNV; j++) h0[j] = lane < nv ? mrow[j] : (lane == j ? 1.f : 0.f);
+  const int blockmask = 1 | (nv > JB0 ? 2 : 0) | (nv > JB1 ? 4 : 0);
+  if (ne == 0) {   // unconstrained: qacc = M^-1 qfrc_smooth
+    if (m->has_damping == 1) {
+      out.qacc = ldl_block0_dual(h0, smooth, hd, lane, &out.qdamped) + ldl_solve_blocks(h0, smooth, lane, blockmask & 6);
+      out.have_qdamped = true;
+    } else out.qacc = ldl_solve_blocks(h0, smooth, lane, blockmask);
+    return out;
+  }
+  if (ne > MAXEFC) ne = MAXEFC;
+  bool valid[NR];
+  float D[NR], ar[NR], x[NR], f[NR], jp[NR], w[NR][6];
+  int con[NR];
+#pragma unroll
+  for (int q = 0; q < NR; q++) {
+    const int r = lane + 64 * q;
+    valid[q] = r < ne;
+    const int rc = valid[q] ? r : 0;
+    D[q] = valid[q] ? s.e_D[rc] : 0.f;
+    ar[q] = valid[q] ? s.e_aref[rc] : 0.f;
+    con[q] = valid[q] ? s.e_con[rc] : 0;
+    const v4 a = ld4(s.J + 8 * rc), b = ld4(s.J + 8 * rc + 4);
+    w[q][0] = valid[q] ? a.x : 0.f; w[q][1] = valid[q] ? a.y : 0.f; w[q][2] = valid[q] ? a.z : 0.f;
+    w[q][3] = valid[q] ? a.w : 0.f; w[q][4] = valid[q] ? b.x : 0.f; w[q][5] = valid[q] ? b.y : 0.f;
+  }
+  const float scale = 1.f / (m->meaninertia * (float)(nv > 1 ? nv : 1));
+  const float tol = m->tolerance;
+  int rowblk = 0;
+#pragma unroll
+  for (int q = 0; q < NR; q++) rowblk |= (con[q] >> 16) & 7;
+  const int rowblocks = (wave_ballot(rowblk & 1) ? 1 : 0) | (wave_ballot(rowblk & 2) ? 2 : 0) | (wave_ballot(rowblk & 4) ? 4 : 0);
+  const bool mine = lane < nv && ((lane < JB0 ? 1 : (lane < JB1 ? 2 : 4)) & rowblocks) != 0;
+  float afree;
+  if ((rowblocks & 1) == 0 && m->has_damping == 1) {
+    afree = ldl_block0_dual(h0, smooth, hd, lane, &out.qdamped);
+    out.have_qdamped = true;
+    afree += ldl_solve_blocks(h0, smooth, lane, ~rowblocks & 6 & blockmask);
+  } else afree = ldl_solve_blocks(h0, smooth, lane, ~rowblocks & 7 & blockmask);
+  float a = mine ? s.qacc_ws[lane] : afree;
+  float Ma = mat_vec(mrow, a) - smooth;
+  Ma = mine ? Ma : 0.f;
+  rows_dot_w<NR>(s, w, con, a, lane, nv, ncon, x);
+#pragma unroll
+  for (int q = 0; q < NR; q++) x[q] = valid[q] ? x[q] - ar[q] : 0.f;
+  JSTAMP(11);
+  // the dof columns of the matrix-core pass: lane -> column lane & 31 of the 32 x 32 tile, or dof JB0 + (lane & 15) of the 16 x 16 one
+  const bool small_tile = (rowblocks & 1) == 0;
+  const int col = small_tile ? (lane & 15) : (lane & 31);
+  const int cdof_ = small_tile ? (col < JNV - JB0 ? JB0 + col : JNV) : col;
+  const WCol cc = wcol_load(s, cdof_ < JNV ? cdof_ : nv, nv);
+  const float cx = (small_tile ? col == JNV - JB0 : col == JNV) ? -1.f : 0.f;
+  int it = 0, nls = 0;
+  for (; it < m->iterations; it++) {
+    lane = wave_opaque_i(lane);
+    bool coupled = false;
+#pragma unroll
+    for (int q = 0; q < NR; q++) {
+      f[q] = x[q] < 0.f ? -D[q] * x[q] : 0.f;
+      const int bk = (con[q] >> 16) & 7;
+      coupled = coupled || (x[q] < 0.f && (bk & (bk - 1)) != 0);
+    }
+    const bool full = wave_ballot(coupled) != 0ull;
+#pragma unroll
+    for (int q = 0; q < NR; q++) if (valid[q]) { float* R = s.J + 8 * (lane + 64 * q); R[JW_WT] = x[q] < 0.f ? D[q] : 0.f; R[JW_X] = x[q]; }
+    wave_sync();
+    float h[JNV], jtf;
+    const int last = ne - 1;
+    if (small_tile) {
+      acc16x16 C;
+      acc_zero(C);
+      const int uq = lane >> 4;
+      for (int r0 = 0; r0 < ne; r0 += 16) {
+        float jv[4], wv[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int r = r0 + 4 * u + uq, rc = r < last ? r : last;
+          const v4 ra = ld4(s.J + 8 * rc), rb = ld4(s.J + 8 * rc + 4);
+          jv[u] = wrow_entry(cc, cdof_, ra, rb, s.e_con[rc]) + cx * rb.w;
+          wv[u] = r < ne ? rb.z : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) wave_mfma_16x16x4(jv[u], wv[u] * jv[u], C);
+      }
+      JSTAMP(12);
+      const int jd = (lane >= JB0 && lane < JNV) ? lane - JB0 : 0;
+#pragma unroll
+      for (int j2 = 0; j2 < JNV; j2++) {
+        float cv = 0.f;
+        if (j2 >= JB0) { const int c = j2 - JB0; cv = wave_shfl(C.v[c & 3], jd + 16 * (c >> 2)); }
+        h[j2] = lane < nv ? mrow[j2] + (lane >= JB0 ? cv : 0.f) : (lane == j2 ? 1.f : 0.f);
+      }
+      jtf = wave_shfl(C.v[(JNV - JB0) & 3], jd + 16 * ((JNV - JB0) >> 2));
+      jtf = lane >= JB0 ? jtf : 0.f;
+    } else {
+      acc32x32 C;
+      acc_zero(C);
+      const int uh = lane >> 5;
+      for (int r0 = 0; r0 < ne; r0 += 8) {
+        float jv[4], wv[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int r = r0 + 2 * u + uh, rc = r < last ? r : last;
+          const v4 ra = ld4(s.J + 8 * rc), rb = ld4(s.J + 8 * rc + 4);
+          jv[u] = wrow_entry(cc, cdof_, ra, rb, s.e_con[rc]) + cx * rb.w;
+          wv[u] = r < ne ? rb.z : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) wave_mfma_32x32x2(jv[u], wv[u] * jv[u], C);
+      }
+      JSTAMP(12);
+#pragma unroll
+      for (int j2 = 0; j2 < JNV; j2++) {
+        const int reg = (j2 & 3) + 4 * (j2 >> 3);
+        float cv = ((j2 >> 2) & 1) ? wave_shfl(C.v[reg], (lane + 32) & 63) : C.v[reg];
+        h[j2] = lane < nv ? mrow[j2] + cv : (lane == j2 ? 1.f : 0.f);
+      }
+      jtf = ((JNV >> 2) & 1) ? wave_shfl(C.v[(JNV & 3) + 4 * (JNV >> 3)], (lane + 32) & 63) : C.v[(JNV & 3) + 4 * (JNV >> 3)];
+    }
+    float grad = Ma - (lane < nv ? jtf : 0.f);
+    float gn = sqrtf(wave_sum(grad * grad));
+    if (gn * scale < tol) break;
+    float p = !full ? ldl_solve_blocks(h, -grad, lane, rowblocks) : ((rowblocks & 1) == 0 ? ldl_block<JB0, JNV>(h, -grad, lane) : ldl_solve<true>(h, -grad, lane));
+    p = lane < nv ? p : 0.f;
+    JSTAMP(13);
+    float Mp = mat_vec(mrow, p);
+    float pMp, pMa;
+    wave_sum2(p * Mp, p * Ma, &pMp, &pMa);
+    rows_dot_w<NR>(s, w, con, p, lane, nv, ncon, jp);
+#pragma unroll
+    for (int q = 0; q < NR; q++) jp[q] = valid[q] ? jp[q] : 0.f;
+    float al = 0.f, lo = 0.f, hi = 3.0e38f, d10 = 0.f, dlo = 0.f, dhi = 0.f;
+    for (int ls = 0; ls < m->ls_iterations; ls++) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int q = 0; q < NR; q++) {
+        float xa = x[q] + al * jp[q];
+        s1 += xa < 0.f ? D[q] * xa * jp[q] : 0.f;
+        s2 += xa < 0.f ? D[q] * jp[q] * jp[q] : 0.f;
+      }
+      float w1, w2;
+      wave_sum2(s1, s2, &w1, &w2);
+      float d1 = pMa + al * pMp + w1, d2 = pMp + w2;
+      if (ls == 0) d10 = fabsf(d1);
+      if (ls > 0 && fabsf(d1) <= 1e-6f * d10) break;
+      if (d1 < 0.f) { lo = al; dlo = -d1; } else { hi = al; dhi = d1; }
+      if (hi < 1.0e38f && fmaxf(dlo, dhi) * (hi - lo) * scale < 1e-3f * tol) break;
+      const float stepn = d1 / d2;
+      float nx = al - stepn;
+      if (!(nx > lo && nx < hi)) nx = hi < 1.0e38f ? 0.5f * (lo + hi) : 2.f * al + 1.f;
+      if (nx == al) break;
+      al = nx;
+      nls++;
+    }
+    float dc = 0.f;
+#pragma unroll
+    for (int q = 0; q < NR; q++) {
+      float dx = al * jp[q], xn = x[q] + dx;
+      bool was = x[q] < 0.f, is = xn < 0.f;
+      dc += (was && is) ? 0.5f * D[q] * dx * (2.f * x[q] + dx) : (is ? 0.5f * D[q] * xn * xn : (was ? -0.5f * D[q] * x[q] * x[q] : 0.f));
+      x[q] = xn;
+    }
+    float improvement = -(al * pMa + 0.5f * al * al * pMp + wave_sum(dc));
+    JSTAMP(14);
+    a += al * p; Ma += al * Mp;
+    if (improvement * scale < tol) { it++; break; }
+  }
+#pragma unroll
+  for (int q = 0; q < NR; q++) f[q] = x[q] < 0.f ? -D[q] * x[q] : 0.f;
+  out.qacc = a;
+  out.iters = it | (nls << 8);
+  // J^T f: row forces -> one wrench per contact (its rows share the body pair; kept in the contact frame's tangent slots, dead since the row
+  // builder) -> per dof the wrenches of the contacts it moves, dotted with its motion subspace; joint-limit rows add +-f to their dof
+  wave_sync();
+#pragma unroll
+  for (int q = 0; q < NR; q++) if (valid[q]) { s.e_f[lane + 64 * q] = f[q]; s.J[8 * (lane + 64 * q) + JW_WT] = f[q]; }
+  wave_sync();
+  for (int ci = lane; ci < ncon; ci += 64) {
+    const int cd = s.c_dim[ci], nrow = cd == 1 ? 1 : 2 * (cd - 1), r0 = s.c_efc[ci];
+    float F[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int e = 0; e < nrow; e++) {
+      const v4 ra = ld4(s.J + 8 * (r0 + e)), rb = ld4(s.J + 8 * (r0 + e) + 4);
+      F[0] += rb.z * ra.x; F[1] += rb.z * ra.y; F[2] += rb.z * ra.z; F[3] += rb.z * ra.w; F[4] += rb.z * rb.x; F[5] += rb.z * rb.y;
+    }
+#pragma unroll
+    for (int c = 0; c < 6; c++) s.c_frame[ci][3 + c] = F[c];
+  }
+  wave_sync();
+  {
+    const WCol own = wcol_load(s, lane, nv);
+    float acc = 0.f;
+    for (int c = 0; c < ncon; c++) {
+      const int obs = s.c_ob[c];
+      const float sgn = (float)((int)((own.mv >> ((obs >> 24) & 31)) & 1u) - (int)((own.mv >> ((obs >> 8) & 31)) & 1u));
+      const float* F = s.c_frame[c] + 3;
+      acc += sgn * (F[0] * own.S.a.x + F[1] * own.S.a.y + F[2] * own.S.a.z + F[3] * own.S.b.x + F[4] * own.S.b.y + F[5] * own.S.b.z);
+    }
+    for (int r = 0; r < nlim; r++) {
+      const int cn = s.e_con[r];
+      if (((cn >> 19) & 31) == lane) acc += s.J[8 * r] * s.J[8 * r + JW_WT];
+    }
+    out.qfrc_con = lane < nv ? acc : 0.f;
+  }
   return out;
 }
 
@@ -1806,7 +2106,8 @@ again:
     wave_sync();
     const float hdamp = (m->has_damping && lane < nv) ? m->timestep * pf.damping : 0.f;
     NewtonOut nw;
-    if constexpr (C::CONTACT) nw = stage_newton(m, s, mrow, smooth, hdamp, lane, pc);
+    if constexpr (C::WRENCH) nw = stage_newton_w(m, s, mrow, smooth, hdamp, lane, pc);
+    else if constexpr (C::CONTACT) nw = stage_newton(m, s, mrow, smooth, hdamp, lane, pc);
     else nw = stage_newton_limits(m, s, mrow, smooth, hdamp, lane);
     if (SideRows<JacoLDS<C>>::on) { if (wave_uniform_i(s.nside) > 0) newton_side(m, s, mrow, smooth, lane, nw); }
     JSTAMP(6);

@@ -41,6 +41,9 @@ def gpu_leg(out_path, B, nstep, compensated=1, task="picking", scale=1.0):
     q0, act, noise = inputs(B, nstep, scale=scale)
     env = JacoBatchedEnv(num_envs=B, task=task)
     env.sim.set_option("compensated", compensated)
+    for kv in os.environ.get("JACO_DRIFT_OPTS", "").split(","):   # e.g. JACO_DRIFT_OPTS=sep_cache=0,pair_list=0 (which execution option owns an outlier?)
+        if kv:
+            env.sim.set_option(kv.split("=")[0], float(kv.split("=")[1]))
     dev = env.device
     env.sim.set_state(torch.tensor(q0, dtype=torch.float32, device=dev), torch.zeros(B, 21, device=dev), torch.zeros(B, 21, device=dev))
     t = env.task_state(); t[:] = 0; t[:, 0] = 0.6; t[:, 16] = 0.6

@@ -12,7 +12,7 @@ rounding (U(-1, 1) x 2e-7 on the arm / finger angles, `draws` times):
 
 An env whose oracle twins all stay within 1e-5 while the HIP env parts by > 1e-4 would be a discrepancy of the kernel itself: listed as UNEXPLAINED.
 
-  python tools/env_drift_causes.py <gpu.npz> <oracle.npz> [draws] [nproc]  > profiles/r05_env_drift_causes.txt
+  python tools/env_drift_causes.py <gpu.npz> <oracle.npz> [draws] [nproc] [control envs]  > profiles/r05_env_drift_causes.txt
 """
 import os
 import sys
@@ -43,9 +43,11 @@ def _geom_label(names, M, g):
 class Twin:
     """OracleEnv with a per-substep record of the contact list and the controller branch."""
 
-    def __init__(self, names, q0k):
+    def __init__(self, names, q0k, round_state=0):
         from oracle_env import OracleEnv
         self.oe = OracleEnv(names)
+        if round_state:
+            self.oe.o.option("round_state", round_state)   # 3: fp64 state, every forward pass evaluated at its fp32 rounding (oracle/jaco_oracle.c orc_step)
         self.oe.obj_goal = q0k[9:12].astype(np.float32).astype(np.float64)
         self.oe.dest_goal = np.array([q0k[16], q0k[17], 0.3468]).astype(np.float32).astype(np.float64)
         self.oe.set_state(q0k)
@@ -177,6 +179,49 @@ def analyse(job):
     return k, nbad, ends.max(), bool(with_flip), "\n".join(lines)
 
 
+def control_one(k):
+    """Env k of the drift workload on the fp64 oracle twice: as it is, and with every forward pass evaluated at the fp32 rounding of its fp64
+    state (no fp32 arithmetic anywhere): the end error of the pair and, when it is beyond 1e-4, the first substep whose contact lists differ."""
+    q0, act, noise, names, M, nstep = _W["q0"], _W["act"], _W["noise"], _W["names"], _W["M"], _W["nstep"]
+    a, nz = act[:, k], noise[:, k]
+    qb, recb = Twin(names, q0[k]).run(a, nz, 0, nstep, record=True)
+    qt, rect = Twin(names, q0[k], round_state=3).run(a, nz, 0, nstep, record=True)
+    n = min(len(qb), len(qt))
+    e = np.abs(qb[:n] - qt[:n]).max(1)
+    msg = None
+    if e[-1] > 1e-4:
+        onset = int(np.argmax(e > 1e-5))
+        first = "no contact-list difference before the end"
+        for j, (rb, rt) in enumerate(zip(recb, rect)):
+            if rb[1] != rt[1]:
+                sb, st = set(rb[1]), set(rt[1])
+                only = list(sb ^ st) or [p for p in rb[1] if rb[1].count(p) != rt[1].count(p)]
+                g1, g2 = only[0]
+                lst, dep = (rb[1], rb[2]) if rb[1].count(only[0]) > rt[1].count(only[0]) else (rt[1], rt[2])
+                depth = min([d for p, d in zip(lst, dep) if p == only[0]] or [0.0])
+                first = "contact lists first differ in env step %d substep %d: %s <-> %s, depth %.2e m (%d vs %d contacts)" % (
+                    rb[0] + 1, j % 50 + 1, _geom_label(names, M, g1), _geom_label(names, M, g2), -depth, len(rb[1]), len(rt[1]))
+                break
+        lead = int(np.abs(qb[onset] - qt[onset]).argmax())
+        msg = "  control env %5d: end error %.1e, onset env step %d (coordinate %d: %s); %s" % (
+            k, e[-1], onset + 1, lead, "arm" if lead < 6 else ("fingers" if lead < 9 else ("object" if lead < 16 else "pedestal")), first)
+    return k, float(e[-1]), msg
+
+
+def control(nenv, nproc):
+    """The closed-loop counterpart of bench.py's ctrl-level control: how often does the fp64 oracle env part from ITSELF by more than 1e-4 over the
+    run when nothing but the evaluation point of its forward passes is rounded to fp32?  That share is the floor of any fp32 engine on this workload."""
+    import multiprocessing as mp
+    with mp.get_context("fork").Pool(nproc) as pool:
+        res = pool.map(control_one, range(nenv), chunksize=4)
+    ends = np.array([r[1] for r in res])
+    print("control: fp64 oracle env vs the same oracle with fp32-rounded evaluation points, %d envs x %d env steps: <= 1e-4 at the end: %.2f %% (median %.1e, p90 %.1e, max %.1e); %d envs beyond 1e-4:" % (
+        nenv, _W["nstep"], 100 * np.mean(ends <= 1e-4), np.median(ends), np.percentile(ends, 90), ends.max(), int((ends > 1e-4).sum())))
+    for r in res:
+        if r[2]:
+            print(r[2])
+
+
 def main():
     import multiprocessing as mp
     from mujoco_jaco_amd.modelc import blob
@@ -204,6 +249,8 @@ def main():
     sens = sum(1 for x in res if x[1] == 0 and x[2] > 1e-5)
     for x in res:
         print(x[4])
+    if len(sys.argv) > 5:
+        control(int(sys.argv[5]), nproc)
     print("summary: %d envs analysed; %d explained (the fp64 oracle itself ends beyond 1e-4 under an fp32-rounding-size perturbation), %d sensitive (twins beyond 1e-5), %d unexplained; "
           "%d with a contact switching on / off at a different substep" % (len(res), expl, sens, len(res) - expl - sens, sum(1 for x in res if x[3])))
 
