@@ -182,7 +182,10 @@ def config_legs(args):
             LEG_FLAGS["config%s" % c] = leg_flags(line)
             out["config%s" % c] = {"env_steps_per_s": line["value"], "ms_per_step": line["ms_per_step"], "kernel_ms": line["roofline"]["kernel_ms"],
                                    "frame_skip": line["config"]["frame_skip"], "envs": line["config"]["envs_per_gpu"], "substeps_per_s": line["config"]["substeps_per_s"],
-                                   "launches_per_step": line["config"].get("launches_per_step"), "done_fraction": line["config"]["done_fraction"]}
+                                   "launches_per_step": line["config"].get("launches_per_step"), "done_fraction": line["config"]["done_fraction"],
+                                   # (no-reset legs: a finished env stays frozen and its env steps cost next to nothing -- the share of env steps that were real work)
+                                   "live_env_steps_per_s": line["value"] * (1.0 - line["config"]["done_fraction"]),
+                                   "outside_kernel_ms": line["ms_per_step"] - line["roofline"]["kernel_ms"]}
         except Exception as e:
             out["config%s" % c] = None
             print("bench.py: config %s leg failed: %r" % (c, e), file=sys.stderr)

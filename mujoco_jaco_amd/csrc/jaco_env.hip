@@ -45,7 +45,7 @@ static_assert(JFLAG_CON_OVERFLOW == JACO_FLAG_CON_OVERFLOW && JFLAG_EFC_OVERFLOW
 #ifndef JACO_HEAVY_GRID
 #define JACO_HEAVY_GRID 1024u   // 4 heavy-tier workgroups per CU
 #endif
-enum { JQ_COUNT = 0, JQ_TAKEN = 3, JQ_LIMIT = 6, JQ_LIGHT = 9, JQ_RESERVE = 10, JQ_ROUTED = 13, JQ_HINTED = 14, JQ_PREV_COUNT = 17, JQ_PREV_HINTED = 20, JQ_LASTMODE = 23, JQ_ROUND1 = 24, JQ_WORDS = 26 };   // (JQ_ROUND1 + t, t = 0, 1: the queue's length before the second drain round, -1 = no second round)
+enum { JQ_COUNT = 0, JQ_TAKEN = 3, JQ_LIMIT = 6, JQ_LIGHT = 9, JQ_RESERVE = 10, JQ_ROUTED = 13, JQ_HINTED = 14, JQ_PREV_COUNT = 17, JQ_PREV_HINTED = 20, JQ_LASTMODE = 23, JQ_ROUND1 = 24, JQ_TICKET = 26, JQ_WORDS = 27 };   // (JQ_ROUND1 + t, t = 0, 1: the queue's length before the second drain round, -1 = no second round)
 
 struct JacoHandle {
   JacoModelDev model_host;
@@ -379,6 +379,18 @@ __global__ __launch_bounds__(1024) void jaco_order_scatter_kernel(const unsigned
   if (threadIdx.x < 32) gb[threadIdx.x] = lh[threadIdx.x] ? base[threadIdx.x] + atomicAdd(&oc[32 + threadIdx.x], lh[threadIdx.x]) : 0u;   // reserve the block's range
   __syncthreads();
   if (valid) order[gb[b] + off] = i;
+  // the last block to finish turns this launch's cost sum into the bucket reference of the NEXT launch (was a one-thread launch of its own):
+  // every block has read oc[66] by now (hist and scatter must bucket with the same reference)
+  __shared__ int last_block;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) last_block = atomicAdd(&oc[68], 1u) == gridDim.x - 1u;
+  __syncthreads();
+  if (last_block && threadIdx.x == 0) {
+    const unsigned long long total = atomicAdd(reinterpret_cast<unsigned long long*>(oc + 64), 0ull);
+    oc[66] = (unsigned)(total / (unsigned long long)(n > 0 ? n : 1));
+    oc[68] = 0u;
+  }
 }
 // ... and sizes this launch's workers from what the ordering pass has just counted: per tier, the envs that start there
 // (a medium worker serves ~8 of them in a third of a step, a heavy one ~4, a huge one ~2) plus a reserve for overflows that
@@ -393,40 +405,40 @@ __global__ void jaco_drain_round2_kernel(int* ctl, int medium_grid, int heavy_gr
   ctl[JQ_ROUND1 + 0] = ctl[JQ_TAKEN + 0];   // = the medium queue's length when its first drain ended
   ctl[JQ_ROUND1 + 1] = ctl[JQ_COUNT + 1];   // (the heavy queue only grows again in the second medium drain)
 }
-__global__ void jaco_route_kernel(int* hint, int* mark, int launch_id, int* lists, int* ctl, int* remaining, unsigned* cost, int n, int nsub) {
+// ... and the last block to finish sizes this launch's workers from what has just been queued (was a one-thread launch of its own): per tier, the
+// envs that start there (a medium worker serves ~8 of them in a third of a step, a heavy one ~4, a huge one ~2) plus the reserve for overflows
+// that only show up during the step (jaco_prepare_kernel: a tenth of the last step's late arrivals)
+__global__ void jaco_route_kernel(int* hint, int* mark, int launch_id, int* lists, int* ctl, int* remaining, unsigned* cost, int n, int nsub, int wm, int wh, int wg) {
   const int e = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-  if (e >= n) return;
-  const int t = hint[e];
-  if (t <= 0) return;
-  hint[e] = 0;
-  mark[e] = launch_id;
-  remaining[e] = nsub;
-  cost[e] = 0u;   // (the tiers add what they spend)
-  lists[(size_t)(t - 1) * 2 * n + atomicAdd(&ctl[JQ_COUNT + t - 1], 1)] = e;
-}
-// ... and this launch's workers are sized from what has just been queued: per tier, the envs that start there (a medium worker
-// serves ~8 of them in a third of a step, a heavy one ~4, a huge one ~2) plus the reserve for overflows that only show up
-// during the step (jaco_prepare_kernel: a tenth of the last step's late arrivals)
-__global__ void jaco_route_finish_kernel(int n, int* ctl, int wm, int wh, int wg) {
+  const int t = e < n ? hint[e] : 0;
+  if (t > 0) {
+    hint[e] = 0;
+    mark[e] = launch_id;
+    remaining[e] = nsub;
+    cost[e] = 0u;   // (the tiers add what they spend)
+    lists[(size_t)(t - 1) * 2 * n + atomicAdd(&ctl[JQ_COUNT + t - 1], 1)] = e;
+  }
+  __shared__ int last_block;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) last_block = atomicAdd(&ctl[JQ_TICKET], 1) == (int)gridDim.x - 1;
+  __syncthreads();
+  if (!last_block || threadIdx.x != 0) return;
   const int cap[3] = {wm, wh, wg}, per[3] = {8, 4, 2};
   int routed = 0;
-  for (int t = 0; t < 3; t++) {
-    const int hinted = ctl[JQ_COUNT + t];
-    ctl[JQ_HINTED + t] = hinted;
+  for (int q = 0; q < 3; q++) {
+    const int hinted = atomicAdd(&ctl[JQ_COUNT + q], 0);   // (device-scope read: the other blocks' appends)
+    ctl[JQ_HINTED + q] = hinted;
     routed += hinted;
-    const int reserve = ctl[JQ_RESERVE + t] < cap[t] ? ctl[JQ_RESERVE + t] : cap[t];
-    const int want = reserve + (hinted + per[t] - 1) / per[t];
-    ctl[JQ_LIMIT + t] = want < cap[t] ? want : cap[t];
-    ctl[JQ_RESERVE + t] = reserve;
+    const int reserve = ctl[JQ_RESERVE + q] < cap[q] ? ctl[JQ_RESERVE + q] : cap[q];
+    const int want = reserve + (hinted + per[q] - 1) / per[q];
+    ctl[JQ_LIMIT + q] = want < cap[q] ? want : cap[q];
+    ctl[JQ_RESERVE + q] = reserve;
   }
   ctl[JQ_ROUTED] = routed;
   ctl[JQ_LIGHT] = n - routed;   // the light workgroups of queued envs leave without being counted
+  ctl[JQ_TICKET] = 0;
 }
-__global__ void jaco_order_finish_kernel(unsigned* oc, int n) {
-  const unsigned long long total = *reinterpret_cast<unsigned long long*>(oc + 64);
-  oc[66] = (unsigned)(total / (unsigned long long)(n > 0 ? n : 1));
-}
-
 // queue reset before every launch: entries = -1, counters zeroed, light workgroups to go = nenv; how many of the launched
 // workers of each tier stay resident follows the previous launch's demand for that tier (an idle worker still holds LDS the
 // light grid could use): a medium worker serves an env in ~1/20 of a step, a heavy / huge one in ~1/8 - 1/4
@@ -524,8 +536,8 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
   JLAUNCH(h, jaco_prepare_kernel, dim3((unsigned)((6 * h->num_envs + 255) / 256)), dim3(256), 0, st, h->qctl, h->qlist, h->num_envs, h->workers, h->workers_heavy, h->workers_huge, h->order_ctl, io.mode, (int)light_grid);
   HIPCHK(h, hipGetLastError());
   if (A.hint && io.mode <= 1) {   // queue the envs whose last step ended in a bigger tier, size the tiers' workers
-    JLAUNCH(h, jaco_route_kernel, dim3((unsigned)((h->num_envs + 255) / 256)), dim3(256), 0, st, h->hint, h->routed_mark, A.launch_id, h->qlist, h->qctl, h->remaining, h->cost, h->num_envs, nsub);
-    JLAUNCH(h, jaco_route_finish_kernel, dim3(1), dim3(1), 0, st, h->num_envs, h->qctl, h->workers, h->workers_heavy, h->workers_huge);
+    JLAUNCH(h, jaco_route_kernel, dim3((unsigned)((h->num_envs + 255) / 256)), dim3(256), 0, st, h->hint, h->routed_mark, A.launch_id, h->qlist, h->qctl, h->remaining, h->cost, h->num_envs, nsub,
+            h->workers, h->workers_heavy, h->workers_huge);
     A.routed_mark = h->routed_mark;
   }
   // The resident workers go first: their workgroups need 20 - 68 KB of LDS on one CU, and once the light grid (13 KB per workgroup,
@@ -547,7 +559,6 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
     const unsigned ob = (unsigned)((h->num_envs + 1023) / 1024);
     JLAUNCH(h, jaco_order_hist_kernel, dim3(ob), dim3(1024), 0, st, h->cost, h->order_ctl, h->num_envs, A.routed_mark, A.launch_id);
     JLAUNCH(h, jaco_order_scatter_kernel, dim3(ob), dim3(1024), 0, st, h->cost, h->order_ctl, h->order, h->num_envs, A.routed_mark, A.launch_id);
-    JLAUNCH(h, jaco_order_finish_kernel, dim3(1), dim3(1), 0, st, h->order_ctl, h->num_envs);
     HIPCHK(h, hipGetLastError());
     A.order = h->order;
   }
@@ -564,7 +575,7 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
   if (io.mode == 2) { mg = mg < 64 ? mg : 64; hg = hg < 64 ? hg : 64; gg = gg < 256 ? gg : 256; }   // (reset-time forward passes: overflows of the light tier go straight to the last one)
   if (io.mode == 4 || io.mode == 5) { if (ev) HIPCHK(h, hipEventRecord(ev->second, st)); return JACO_OK; }   // take_action / terminal_inspection run no substep: nothing can overflow
   if (io.mode != 2) JLAUNCHK(h, JK_MEDIUM_DRAIN, mg, st, A);   // (mode 2 queues for the last tier only)
-  if (h->handdown && io.mode == 1) {
+  if (h->handdown && io.mode == 1 && nsub >= JACO_HANDDOWN_MIN) {   // (a hand-down needs JACO_HANDDOWN_MIN substeps left to pay: shorter steps never hand down, and skip the round)
     // the heavy tier holds 4 envs per CU: an env that needed it for a few substeps is passed back down to a second medium drain
     // (8 per CU) rather than kept there for the rest of its step; what overflows again is served by a second, final heavy drain
     A.handdown = 1;

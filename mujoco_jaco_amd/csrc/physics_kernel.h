@@ -23,16 +23,22 @@
 //   heavy: <= 256 rows / 64 contacts -> 4 rows per lane, ~43 KB LDS, for envs that overflow medium;
 //   huge: <= 512 rows / 128 contacts -> 8 rows per lane, ~80 KB LDS, for envs that overflow heavy (beyond that rows are dropped and flagged).
 // A light wave that meets an overflow hands its env (state untouched for that substep) to the heavy launch.
-// Constraint rows in body space (round 5; -DJACO_WRENCH=0 builds the dense rows of rounds 1-4 for comparison).  A contact row is
+// Constraint rows in body space (round 5; an A/B build option: -DJACO_WRENCH=1, default OFF -- measured slower, see below).  A contact row is
 // J_r = w_r^T (J_B - J_A): a 6-vector wrench w_r = (pos x dir + rotational part, dir) applied to the motion subspaces S_k of the dofs that move
 // body B but not body A (and with the opposite sign vice versa).  The row is stored as that wrench (8 floats with the solver's two per-row
 // staging slots) plus the two body ids -- 48 bytes with its parameters instead of 100 -- and every product with J is formed from it:
-//   J v      = w . (V_B - V_A),  V_b = sum over the chain of b of S_k v_k   (one 6-vector per body, then 12 LDS reads per row)
+//   J v      = w . D_c,  D_c = signed sum of S_k v_k over the dofs that move exactly one of the contact's two bodies (lane = (contact, component))
 //   J^T D J  = the matrix-core pass generates its J entries on the fly: lane (column k) holds S_k and forms sgn_k(r) w_r . S_k per row
-//   J^T f    = S_k . (sum of the contacts' wrenches acting below dof k)
-// so the light tier holds 128 rows in the LDS that used to hold 64.  Joint-limit rows (J = +-e_d) are "unit rows": flag + dof + sign.
+//   J^T f    = S_k . (sum of the wrenches of the contacts dof k moves)
+// so the light tier holds 128 rows in the LDS that holds 64 dense ones (13 584 B, 168 VGPRs, 3 waves per SIMD either way; medium / heavy /
+// huge: 14.7 / 22.1 / 39.5 KB instead of 20.2 / 43 / 80 KB).  Joint-limit rows (J = +-e_d) are "unit rows": flag + dof + sign.
+// Parity: every emulator suite green (tests/, built with -DJACO_WRENCH=1).  MEASURED on MI355X (profiles/r05_ab_wrench_rows.txt): headline
+// 1.84 -> 1.70 M env-steps/s, action scale 0.05 0.50 -> 0.21 M, policy-driven 1.33 -> 1.22 M -- the envs do stay in the light tier (bigger-tier
+// share 0.60 -> 0.09) but every product with J now costs VALU work and dependent LDS round trips that a dense row in registers did not
+// (rows_dot: 21 v_readlane + 21 fma -> two LDS hand-offs and a bit-scan loop; the matrix-core pass: 1 LDS read per entry -> 14 VALU): the
+// dense rows stay the product path.
 #ifndef JACO_WRENCH
-#define JACO_WRENCH 1
+#define JACO_WRENCH 0
 #endif
 template <int MAXEFC_, int MAXCON_, int MAXCAND_, bool CONTACT_ = true>
 struct JacoCaps {
@@ -276,7 +282,7 @@ struct JacoLDS {
     int b_jtype[JNB], b_qadr[JNB], b_dadr[JNB], b_parent[JNB];
     int inner_body[JMAXINNER];
     unsigned b_descmask[JNB];
-    unsigned b_chain[JNB];                      // bit d set: dof d moves body b
+    unsigned b_chain[C::WRENCH ? JNB : 1];      // body-space rows only: bit d set: dof d moves body b
     int b_anc[JNB][3];                          // ancestors 1, 2 and 4 levels up (-1: none), for the pointer-jumping tree stages
     int d_body[JNV], d_parent[JNV];
     int q_dof[JNQ + 1];                         // dof that advances position coordinate q linearly (hinge angle, free-body translation), -1: quaternion component
@@ -295,7 +301,7 @@ JDEV void stage_model(const JacoModelDev* m, L& s, int lane) {
     int p1 = m->b_parent[b], p2 = p1 >= 0 ? m->b_parent[p1] : -1, p3 = p2 >= 0 ? m->b_parent[p2] : -1, p4 = p3 >= 0 ? m->b_parent[p3] : -1;
     s.mc.b_parent[b] = p1;
     s.mc.b_descmask[b] = m->b_descmask[b];
-    s.mc.b_chain[b] = m->b_chainmask[b];
+    if (L::Caps::WRENCH) s.mc.b_chain[b] = m->b_chainmask[b];
     if (b < JMAXINNER) s.mc.inner_body[b] = m->inner_body[b];
     s.mc.b_anc[b][0] = p1; s.mc.b_anc[b][1] = p2; s.mc.b_anc[b][2] = p4;
     const int qa = m->b_qadr[b], da = m->b_dadr[b];
@@ -1168,16 +1174,27 @@ JDEV NewtonOut stage_newton(const JacoModelDev* m, L& s, const float (&mrow)[JNV
       const float cj = col < JNV - JB0 ? 1.f : 0.f, cx = col == JNV - JB0 ? -1.f : 0.f;
       const float* jcol = s.J + JB0 + (col < JNV - JB0 ? col : 0);
       const int last = ne - 1;
-      for (int r0 = 0; r0 < ne; r0 += 16) {
-        float jv[4], wv[4];
+      // software-pipelined: the operands of the NEXT four issues are fetched from LDS before this round's four matrix-core issues (which only
+      // need registers), so the LDS latency runs under the matrix pipe instead of in front of it (the final, surplus fetch re-reads the last row
+      // with weight 0).  Same products in the same order: bit-identical results.
+      float jv[4], wv[4], jn[4], wn[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const int r = r0 + 4 * u + uq, rc = r < last ? r : last;
-          jv[u] = cj * jcol[rc * JLD] + cx * xs[rc];
-          wv[u] = r < ne ? s.e_f[rc] : 0.f;
+      for (int u = 0; u < 4; u++) {
+        const int r = 4 * u + uq, rc = r < last ? r : last;
+        jv[u] = cj * jcol[rc * JLD] + cx * xs[rc];
+        wv[u] = r < ne ? s.e_f[rc] : 0.f;
+      }
+      for (int r0 = 0; r0 < ne; r0 += 16) {
+        float xn[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {   // raw fetches only: nothing here waits for them
+          const int r = r0 + 16 + 4 * u + uq, rc = r < last ? r : last;
+          jn[u] = jcol[rc * JLD]; xn[u] = xs[rc]; wn[u] = s.e_f[rc];
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) wave_mfma_16x16x4(jv[u], wv[u] * jv[u], C);
+#pragma unroll
+        for (int u = 0; u < 4; u++) { jv[u] = cj * jn[u] + cx * xn[u]; wv[u] = (r0 + 16 + 4 * u + uq) < ne ? wn[u] : 0.f; }
       }
       JSTAMP(12);
       // symmetric tile: H[jd][c] = C[c][jd] sits in lane jd + 16 * (c >> 2), register c & 3 (jd = this lane's dof - JB0)
@@ -1197,16 +1214,24 @@ JDEV NewtonOut stage_newton(const JacoModelDev* m, L& s, const float (&mrow)[JNV
     const float cj = col < JNV ? 1.f : 0.f, cx = col == JNV ? -1.f : 0.f;
     const float* jcol = s.J + (col < JNV ? col : 0);
     const int last = ne - 1;
+    float jv[4], wv[4], jn[4], wn[4];   // (software-pipelined like the 16 x 16 form above)
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int r = 2 * u + uh, rc = r < last ? r : last;
+      jv[u] = cj * jcol[rc * JLD] + cx * xs[rc];
+      wv[u] = r < ne ? s.e_f[rc] : 0.f;
+    }
     for (int r0 = 0; r0 < ne; r0 += 8) {
-      float jv[4], wv[4];
+      float xn[4];
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        const int r = r0 + 2 * u + uh, rc = r < last ? r : last;
-        jv[u] = cj * jcol[rc * JLD] + cx * xs[rc];
-        wv[u] = r < ne ? s.e_f[rc] : 0.f;
+        const int r = r0 + 8 + 2 * u + uh, rc = r < last ? r : last;
+        jn[u] = jcol[rc * JLD]; xn[u] = xs[rc]; wn[u] = s.e_f[rc];
       }
 #pragma unroll
       for (int u = 0; u < 4; u++) wave_mfma_32x32x2(jv[u], wv[u] * jv[u], C);
+#pragma unroll
+      for (int u = 0; u < 4; u++) { jv[u] = cj * jn[u] + cx * xn[u]; wv[u] = (r0 + 8 + 2 * u + uh) < ne ? wn[u] : 0.f; }
     }
     JSTAMP(12);
     // C is symmetric: row j of the tile, column `lane`, is where lane `lane` finds H[lane][j]
@@ -1837,7 +1862,11 @@ JDEV int run_env(const JacoStepArgs& A_, JacoLDS<C>& s, int env, int nsub, int l
   if (FULL && (A.env_mode == 3 || A.env_mode == 2 || A.env_mode == 6) && A.mask && !A.mask[env]) return 0;   // masked reset: the other envs are not touched
   if (lane < nq) { s.qpos[lane] = A.qpos[(size_t)env * nq + lane]; s.qpos_lo[lane] = A.qpos_lo ? A.qpos_lo[(size_t)env * nq + lane] : 0.f; }
   if (lane < nv) { s.qvel[lane] = A.qvel[(size_t)env * nv + lane]; s.qacc_ws[lane] = A.qacc_ws[(size_t)env * nv + lane]; s.qvel_lo[lane] = A.qvel_lo ? A.qvel_lo[(size_t)env * nv + lane] : 0.f; }
-  if (lane < nu) s.ctrl[lane] = A.ctrl[(size_t)env * nu + lane];
+  // ctrl-level launches read the caller's controls.  Env-level launches compute theirs (controller + gripper ramp, or the interrupted substep's
+  // from the task row); a forward pass alone (mode 2: sim.forward() after sim.reset(), which zeroes data.ctrl) runs on ZERO controls -- A.ctrl is
+  // only a readable placeholder there (the qvel buffer: reading it made a reset's first touch reading depend on other envs' velocities;
+  // found by the auto-reset bit-identity test in round 5, 1 env of 8 192 x 6 steps)
+  if (lane < nu) s.ctrl[lane] = A.env_mode == 0 ? A.ctrl[(size_t)env * nu + lane] : 0.f;
   stage_model(m, s, lane);
   if (lane == 0) { s.ncon = 0; s.nefc = 0; s.ncand = 0; s.nlimit = 0; s.nsphere = 0; s.nside = 0; s.nside_cand = 0; }   // (LDS is not zeroed between workgroups)
   unsigned flags = LIGHT ? 0u : JFLAG_HEAVY_TIER;

@@ -6,9 +6,17 @@
  * (SURVEY.md section 8 row a6, Appendix D.1).  The arithmetic itself lives in the closed
  * MuJoCo 2.0 binary reached through an un-pinned mujoco-py fork (README.md:15-24 of the
  * reference), which is absent from /root/reference and from this image, and the reference
- * has no tests: ** parity unpinned ** for this tier.  The algorithms below restate the
- * published MuJoCo computation pipeline [EXT]; each function cites the reference call
- * site whose result it stands for.
+ * has no tests.  PINNED (round 5) against the only MuJoCo-produced numbers the reference holds:
+ * the object-height transients of its recorded trajectories (models_baseline/trajectories/*.npz,
+ * obs[:, 10]) -- ten float32 values of the object falling onto the floor, thirteen of the holder
+ * pushing it out of its spawn overlap, both rest heights -- reproduced BIT FOR BIT
+ * (tests/test_mujoco_statics.py, tests/golden/mujoco_rest_heights.json): plane-box and box-box
+ * contact generation, solref / solimp mixing, impedance, regulariser, pyramidal cone, Newton
+ * optimum, semi-implicit Euler.  The articulated-arm dynamics, the hull contacts (MPR) and the
+ * controller are NOT pinned against MuJoCo ("parity unpinned" for those): they restate the
+ * published computation pipeline [EXT] and are held by first principles and by the success
+ * rates of the reference's shipped policies.  Each function cites the reference call site
+ * whose result it stands for.
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
  * library.  The product path (mujoco_jaco_amd/) never does.

@@ -571,3 +571,21 @@ def test_reset_draws_the_reaching_goal_from_an_init_buffer(model_arrays):
         assert not any(np.array_equal(e.task[0, 32:38], np.hstack([buf[i, 1:4], buf[i, 4:7]])) for i in range(n))   # back to sampled goals
     finally:
         e.set_init_buffer(None)
+
+
+def test_forward_pass_runs_on_zero_controls_whatever_the_neighbours_do(model_arrays):
+    """sim.forward() after sim.reset() sees data.ctrl = 0.  The env-level launches hand the kernel a placeholder ctrl pointer (the qvel buffer);
+    a forward pass alone (mode 2: jaco_forward, the explicit reset chain) used to READ it -- env e took qvel words [9 e, 9 e + 9) as its nine
+    controls, so a reset's first touch reading depended on other envs' velocities (found on MI355X by the auto-reset bit-identity test: 1 env of
+    8 192 x 6 steps, a reset with the hand inside the pedestal).  Two envs in such a pose: env 1's readings must not move when env 0 spins."""
+    q = workload.reset_states(model_arrays["qpos0"], 64, seed=7, f32_draws=True)[62]   # hand 10 cm inside the pedestal: pads and EE sensor loaded
+    out = []
+    for spin in (0.0, 25.0):
+        e = EmuJacoEnv(nenv=2)
+        e.qpos[:] = q
+        e.task[:, 4:7] = q[9:12]; e.task[:, 7:9] = q[16:18]; e.task[:, 9] = 0.3468
+        e.qvel[0, 9:18] = spin          # what env 1 would read as ctrl[0..8]
+        e.forward(np.full((2, 12), 0.5, np.float32))
+        out.append((e.sensordata[1].copy(), e.obs[1].copy()))
+    assert out[0][0].max() > 0.01                                   # the scenario really loads a sensor
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])

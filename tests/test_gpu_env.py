@@ -933,8 +933,9 @@ def test_grasp_regime_parity_under_the_shipped_policy(names):
     print("grasp regime, %d envs with finger-object contact (%d stepped by a bigger tier), %d env steps compared, %d touch-class flips: obs err median %.2e p90 %.2e max %.2e; reward err max %.2e" % (
         len(sel), bigger, ncmp, flips, np.median(oerr), np.percentile(oerr, 90), oerr.max(), rerr.max()))
     assert flips <= 2 and ncmp >= 40
-    # 3x measured on MI355X (obs median 8.6e-8, p90 2.5e-7, max 2.0e-6; reward 5.2e-6; 24 envs, 69 env steps)
-    assert np.median(oerr) < 2.6e-7 and np.percentile(oerr, 90) < 7.5e-7 and oerr.max() < 6e-6 and rerr.max() < 1.6e-5
+    # 3x measured on MI355X (round 5, half-depth box-box contacts: obs median 8.9e-8, p90 2.9e-7, max 1.0e-5; reward 7.2e-6; 24 envs, 67 env steps;
+    # round 4: 8.6e-8 / 2.5e-7 / 2.0e-6 / 5.2e-6 -- the maximum belongs to one env step)
+    assert np.median(oerr) < 2.7e-7 and np.percentile(oerr, 90) < 8.8e-7 and oerr.max() < 3.1e-5 and rerr.max() < 2.2e-5
     env.close()
 
 

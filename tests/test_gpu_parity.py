@@ -134,11 +134,14 @@ def _drift_vs_control(model_arrays, B, nsub, seed, compensated=1, control=3):
 
 
 def test_free_running_drift_100_substeps(model_arrays):
-    """Measured (MI355X, round 3, compensated state): median 1.0e-7, p99 3.7e-6, max 1.2e-5 over all 256 envs."""
+    """Measured (MI355X, round 5: box-box face contacts at MuJoCo's half depth, so the object spends these 100 substeps rising out of its 1 cm
+    spawn overlap, tests/test_mujoco_statics.py): median 1.0e-7, p90 2.1e-7, 255 of 256 envs <= 1e-4, max 1.2e-4 (one env; round 3, with the object
+    out in 20 substeps: max 1.2e-5).  Bounds: 3x."""
     err, ctl, fl = _drift_vs_control(model_arrays, 256, 100, 41)
+    print("drift after 100 substeps: p99 %.2e, envs beyond 1e-4: %d" % (np.percentile(err, 99), int((err > 1e-4).sum())))
     assert (fl & 15).max() == 0
-    assert err.max() <= 4e-5, err.max()                                       # MAX over the whole batch (3x the measured value)
-    assert np.median(err) <= 3e-7 and np.percentile(err, 99) <= 1.2e-5
+    assert err.max() <= 3.5e-4, err.max()                                     # MAX over the whole batch
+    assert np.median(err) <= 3e-7 and np.percentile(err, 90) <= 6.4e-7 and (err > 1e-4).sum() <= 2
 
 
 def test_free_running_drift_1000_substeps(model_arrays):
@@ -148,8 +151,9 @@ def test_free_running_drift_1000_substeps(model_arrays):
     fp64 control 38 %.  The envs that part are the ones in which unactuated impacts amplify last-bit differences (the fp64 oracle
     started 1 ulp(fp32) away parts from itself in 15.6 % of them)."""
     err, ctl, fl = _drift_vs_control(model_arrays, 256, 1000, 41)
-    assert np.mean(err <= 1e-4) >= 0.75, np.mean(err <= 1e-4)
-    assert np.mean(err <= 1e-4) >= np.mean(ctl <= 1e-4) - 0.08                 # no further from the oracle than the compensated-state ceiling
+    # round 5 (half-depth box-box contacts): 81.6 % against the control's 87.1 % (5.5 points: 14 envs of 256); round 4: 81.2 % / 87.6 %
+    assert np.mean(err <= 1e-4) >= 0.78, np.mean(err <= 1e-4)
+    assert np.mean(err <= 1e-4) >= np.mean(ctl <= 1e-4) - 0.07                 # no further from the oracle than the compensated-state ceiling
     assert np.median(err) <= 3e-5 and np.percentile(err, 25) <= 8e-6
     # ... and the compensated state is what buys it: the same kernel carrying a plain fp32 state loses most envs, like its control
     err0, ctl0, _ = _drift_vs_control(model_arrays, 256, 1000, 41, compensated=0, control=1)
@@ -332,7 +336,9 @@ def test_sensor_model_with_cylinder_geoms_on_the_d12_build():
         nsub, np.median(eq), np.percentile(eq, 90), eq.max(), ev.max(), st[:, 1].min(), st[:, 1].max(), st[:, 0].max(), int((gst[:, 1] == st[:, 1]).sum()), B))
     assert (env.flags().cpu().numpy() & 15).max() == 0 and (st[:, 0] >= 1).mean() > 0.9   # the box is on the disc in (nearly) every env
     # (the emulated kernel on the first 48 of these envs: median 1.2e-7, p90 3.2e-7, max 1.5e-5 -- one env whose fingers hit the holder hard)
-    assert np.median(eq) < 4e-7 and np.percentile(eq, 90) < 2e-6 and eq.max() < 1e-3
+    # MI355X: median 1.2e-7, p90 2.8e-7, max 8.1e-5 (one env whose fingers hit the holder hard), qvel max 1.2e-2, same row count in 243 of 256: 3x
+    assert np.median(eq) < 4e-7 and np.percentile(eq, 90) < 8.5e-7 and eq.max() < 2.5e-4
+    assert ev.max() < 3.6e-2 and (gst[:, 1] == st[:, 1]).sum() >= 0.9 * B
     # (B) arm-on-cylinder poses, one substep
     P = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sensor_post_poses.npz"))["qpos"]
     n = len(P)
@@ -455,4 +461,51 @@ def test_kernel_follows_the_mujoco_recorded_object_transients(model_arrays):
     print("rest heights: floor %d / 256 envs equal MuJoCo's float32, holder %d / 256" % ((uf[-1] == 0).sum(), (uh[-1] == 0).sum()))
     assert np.delete(uf, 4, axis=0).max() <= 2.0 and uf[4].max() <= 12.0
     assert uh.max() <= 2.0
+    env.close()
+
+
+def test_deep_overlap_resets_agree_with_the_oracle_substep_by_substep(model_arrays):
+    """The four envs of the smoke batch whose reset puts the hand centimetres inside the pedestal (up to 10 cm; ~1 % of picking resets, 100-400
+    rows): the batch MAX of a free run is loose for them by construction -- MPR's answer jumps where a contact sits on an edge between nearly
+    coplanar hull facets, and the fp64 oracle flips such contacts itself under 3e-7 perturbations (profiles/r04_smoke_knife_edge.txt).  What CAN
+    be asserted sharply: the kernel free-runs in 1-substep launches, before every substep the oracle is handed the kernel's own state, both take
+    the substep -- contact count, row count and the state after the step must agree at every one of the 20 substeps (measured on MI355X: 79 of
+    the 80 single steps within 2.3e-7, same counts everywhere), except for facet flips of that kind: same counts but a state difference above
+    2e-6 (measured: one, env 62 substep 7, 3.4e-6); counted, at most 3."""
+    from mujoco_jaco_amd import workload
+    from oracle_binding import Oracle
+    B, nsub = 64, 20
+    q = workload.reset_states(model_arrays["qpos0"], B, seed=7, f32_draws=True)
+    c = workload.random_ctrl(B, seed=8, scale=0.2).astype(np.float32).astype(np.float64)
+    deep = [8, 36, 54, 62]
+    env = _env(B)
+    dev = env.device
+    env.set_state(_t(q, dev), None, None)
+    ct = _t(c, dev)
+    oracles = {k: Oracle() for k in deep}
+    worst, flips, cmp = 0.0, 0, 0
+    for s in range(nsub):
+        st = [x.cpu().numpy().astype(np.float64) for x in env.get_state()]
+        for k in deep:
+            o = oracles[k]
+            # (first substep: the exact start state -- the pedestal's bottom face sits exactly ON the floor plane there, and the float32 rounding
+            # of its height 0.09 would lift it 3.6e-9 m off the plane for the fp64 oracle: 4 contacts fewer than the kernel sees, for one substep)
+            o.set("qpos", q[k] if s == 0 else st[0][k]); o.set("qvel", st[1][k]); o.set("qacc_warmstart", st[2][k])
+            o.step(c[k])
+        env.send_forces(ct, nsub=1)
+        after = [x.cpu().numpy().astype(np.float64) for x in env.get_state()]
+        stats = env.stats().cpu().numpy()
+        for k in deep:
+            o = oracles[k]
+            same_counts = (stats[k, 0], stats[k, 1]) == (o.ncon, o.nefc)
+            e = np.abs(after[0][k] - o.get("qpos")).max()
+            cmp += 1
+            if not same_counts or e > 2e-6:
+                flips += 1
+                print("substep %d env %d: contacts / rows kernel %d / %d oracle %d / %d, single-step qpos diff %.2e" % (s + 1, k, stats[k, 0], stats[k, 1], o.ncon, o.nefc, e))
+            else:
+                worst = max(worst, e)
+    print("deep-overlap envs %s: %d single substeps from the kernel's own states: worst agreeing step %.2e, %d steps with a contact-set or facet difference" % (deep, cmp, worst, flips))
+    assert (env.flags().cpu().numpy()[deep] & 15).max() == 0
+    assert flips <= 3 and worst <= 7e-7
     env.close()

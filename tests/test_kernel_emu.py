@@ -304,7 +304,7 @@ def test_separating_direction_cache_does_not_change_results(model_arrays, names)
             assert np.array_equal(x, y)
     (calls_on, q_on), (calls_off, q_off) = queries
     print("hull pairs: %d narrowphase calls; support queries %d with the cache, %d without" % (calls_on, q_on, q_off))
-    assert calls_on == calls_off and q_on < q_off   # (this scenario is dominated by hits; the saving under the shipped policy is ~a quarter of all queries: tools/mpr_query_stats_emu.py)
+    assert calls_on == calls_off and q_on < q_off   # (this scenario is dominated by hits; the saving under the shipped policy is ~a quarter of all queries: tools/mpr_query_stats.py kernel)
 
 
 def test_dual_arm_model_on_the_d30_build_matches_oracle():
