@@ -1174,27 +1174,17 @@ JDEV NewtonOut stage_newton(const JacoModelDev* m, L& s, const float (&mrow)[JNV
       const float cj = col < JNV - JB0 ? 1.f : 0.f, cx = col == JNV - JB0 ? -1.f : 0.f;
       const float* jcol = s.J + JB0 + (col < JNV - JB0 ? col : 0);
       const int last = ne - 1;
-      // software-pipelined: the operands of the NEXT four issues are fetched from LDS before this round's four matrix-core issues (which only
-      // need registers), so the LDS latency runs under the matrix pipe instead of in front of it (the final, surplus fetch re-reads the last row
-      // with weight 0).  Same products in the same order: bit-identical results.
-      float jv[4], wv[4], jn[4], wn[4];
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int r = 4 * u + uq, rc = r < last ? r : last;
-        jv[u] = cj * jcol[rc * JLD] + cx * xs[rc];
-        wv[u] = r < ne ? s.e_f[rc] : 0.f;
-      }
+      // (fetching the next round's operands ahead of this round's matrix-core issues was tried in round 5: neutral, profiles/r05_ab_variants.txt)
       for (int r0 = 0; r0 < ne; r0 += 16) {
-        float xn[4];
+        float jv[4], wv[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {   // raw fetches only: nothing here waits for them
-          const int r = r0 + 16 + 4 * u + uq, rc = r < last ? r : last;
-          jn[u] = jcol[rc * JLD]; xn[u] = xs[rc]; wn[u] = s.e_f[rc];
+        for (int u = 0; u < 4; u++) {
+          const int r = r0 + 4 * u + uq, rc = r < last ? r : last;
+          jv[u] = cj * jcol[rc * JLD] + cx * xs[rc];
+          wv[u] = r < ne ? s.e_f[rc] : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) wave_mfma_16x16x4(jv[u], wv[u] * jv[u], C);
-#pragma unroll
-        for (int u = 0; u < 4; u++) { jv[u] = cj * jn[u] + cx * xn[u]; wv[u] = (r0 + 16 + 4 * u + uq) < ne ? wn[u] : 0.f; }
       }
       JSTAMP(12);
       // symmetric tile: H[jd][c] = C[c][jd] sits in lane jd + 16 * (c >> 2), register c & 3 (jd = this lane's dof - JB0)
@@ -1214,24 +1204,16 @@ JDEV NewtonOut stage_newton(const JacoModelDev* m, L& s, const float (&mrow)[JNV
     const float cj = col < JNV ? 1.f : 0.f, cx = col == JNV ? -1.f : 0.f;
     const float* jcol = s.J + (col < JNV ? col : 0);
     const int last = ne - 1;
-    float jv[4], wv[4], jn[4], wn[4];   // (software-pipelined like the 16 x 16 form above)
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int r = 2 * u + uh, rc = r < last ? r : last;
-      jv[u] = cj * jcol[rc * JLD] + cx * xs[rc];
-      wv[u] = r < ne ? s.e_f[rc] : 0.f;
-    }
     for (int r0 = 0; r0 < ne; r0 += 8) {
-      float xn[4];
+      float jv[4], wv[4];
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        const int r = r0 + 8 + 2 * u + uh, rc = r < last ? r : last;
-        jn[u] = jcol[rc * JLD]; xn[u] = xs[rc]; wn[u] = s.e_f[rc];
+        const int r = r0 + 2 * u + uh, rc = r < last ? r : last;
+        jv[u] = cj * jcol[rc * JLD] + cx * xs[rc];
+        wv[u] = r < ne ? s.e_f[rc] : 0.f;
       }
 #pragma unroll
       for (int u = 0; u < 4; u++) wave_mfma_32x32x2(jv[u], wv[u] * jv[u], C);
-#pragma unroll
-      for (int u = 0; u < 4; u++) { jv[u] = cj * jn[u] + cx * xn[u]; wv[u] = (r0 + 8 + 2 * u + uh) < ne ? wn[u] : 0.f; }
     }
     JSTAMP(12);
     // C is symmetric: row j of the tile, column `lane`, is where lane `lane` finds H[lane][j]

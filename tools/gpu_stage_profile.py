@@ -3,6 +3,12 @@ import ctypes, os, sys, time
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 os.environ.setdefault("JACO_ENV_LIB", "libjaco_env_prof.so")
+# the diagnostic twin is only built on request (python __graft_entry__.py variant prof): a stale one from an earlier round, with another argument-block
+# or handle layout, would pass the loader's symbol check and produce garbage profiles or faults -- refuse anything older than the product library
+_pk = os.path.join(ROOT, "mujoco_jaco_amd")
+_prof, _main = os.path.join(_pk, os.environ["JACO_ENV_LIB"]), os.path.join(_pk, "libjaco_env.so")
+if not os.path.exists(_prof) or os.path.getmtime(_prof) < os.path.getmtime(_main):
+    sys.exit("gpu_stage_profile.py: %s is missing or older than libjaco_env.so: build it first (python __graft_entry__.py variant prof)" % _prof)
 import numpy as np, torch
 from mujoco_jaco_amd.physics import BatchedMujoco
 from mujoco_jaco_amd.modelc import blob

@@ -3,7 +3,7 @@
 # The PMC file gets the layout bench.py replays (commit = HEAD: commit the sources the libraries were built from first).
 set -e
 cd "$(dirname "$0")/.."
-P=${1:-r04}
+P=${1:-r05}
 grep -v amdgpu.ids gpurun_out/stage_profile.txt > profiles/${P}_stage_profile.txt
 grep -v amdgpu.ids gpurun_out/stage_profile_policy.txt > profiles/${P}_stage_profile_policy.txt
 grep -v amdgpu.ids gpurun_out/stage_profile_arm.txt > profiles/${P}_stage_profile_arm.txt
