@@ -36,7 +36,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2   # wave-instructions/s: 1 024 SIMD-32 units, one wave64 VALU instruction per 2 cycles, 2.4 GHz
-PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc.json")
 
 
 def parse_args(argv=None):
