@@ -230,6 +230,10 @@ JDEV int m_index(int d, int j) {   // (d, j in the same block)
 //   * geom poses + broadphase survivors (tree walk .. collision)   with   the constraint rows (row builders .. Euler), behind the
 //     first JSCRATCH floats of that area, which the early stages use as scratch.
 // Light tier: 13.3 KB -> 12 envs per CU (3 waves per SIMD); it was 20.5 KB -> 8.
+// (body-space rows only: per-body dof chain masks; an empty base otherwise -- four more bytes take the medium tier from 20 480 B = 8 workgroups
+//  per CU to 20 496 B = 7)
+template <bool W> struct JacoChainTab { unsigned b_chain[JNB]; };   // bit d set: dof d moves body b
+template <> struct JacoChainTab<false> {};
 template <class C>
 struct JacoLDS {
   typedef C Caps;
@@ -277,12 +281,11 @@ struct JacoLDS {
   float task[JTASK_FLOATS];                    // (= JTASK_N of env_logic.h)
   float osc_qd[4];                              // target orientation quaternion of the current env step (constant over its substeps)
   // per-launch copy of the small, hot model tables (per-lane gathers from LDS instead of dependent global loads)
-  struct {
+  struct McTab : JacoChainTab<C::WRENCH> {
     float b_pos[JNB][3], b_mat[JNB][9], b_axis[JNB][3], b_com[JNB][3], b_qpos0[JNB];
     int b_jtype[JNB], b_qadr[JNB], b_dadr[JNB], b_parent[JNB];
     int inner_body[JMAXINNER];
     unsigned b_descmask[JNB];
-    unsigned b_chain[C::WRENCH ? JNB : 1];      // body-space rows only: bit d set: dof d moves body b
     int b_anc[JNB][3];                          // ancestors 1, 2 and 4 levels up (-1: none), for the pointer-jumping tree stages
     int d_body[JNV], d_parent[JNV];
     int q_dof[JNQ + 1];                         // dof that advances position coordinate q linearly (hinge angle, free-body translation), -1: quaternion component
@@ -301,7 +304,7 @@ JDEV void stage_model(const JacoModelDev* m, L& s, int lane) {
     int p1 = m->b_parent[b], p2 = p1 >= 0 ? m->b_parent[p1] : -1, p3 = p2 >= 0 ? m->b_parent[p2] : -1, p4 = p3 >= 0 ? m->b_parent[p3] : -1;
     s.mc.b_parent[b] = p1;
     s.mc.b_descmask[b] = m->b_descmask[b];
-    if (L::Caps::WRENCH) s.mc.b_chain[b] = m->b_chainmask[b];
+    if constexpr (L::Caps::WRENCH) s.mc.b_chain[b] = m->b_chainmask[b];
     if (b < JMAXINNER) s.mc.inner_body[b] = m->inner_body[b];
     s.mc.b_anc[b][0] = p1; s.mc.b_anc[b][1] = p2; s.mc.b_anc[b][2] = p4;
     const int qa = m->b_qadr[b], da = m->b_dadr[b];
