@@ -82,7 +82,8 @@ struct JacoHandle {
   int schedule = 1;           // option "schedule": 0 = launch envs in index order
   int auto_reset = 0;         // option "auto_reset"
   int min_nsub_sched = 2;     // option "min_nsub_sched": shortest step (substeps) that gets the resident tier workers
-  int min_nsub_order = 2;     // option "min_nsub_order": shortest step that gets the cost-ordered launch (three small launches in front of the light grid)
+  int min_nsub_order = 8;     // option "min_nsub_order": shortest step that gets the cost-ordered launch (two small launches in front of the light grid); at frame_skip 4 the
+                              // ordering does not pay: 19.4-19.7 M env-steps/s with it, 20.1 M without (round 5, tools/gpu_cfg4_options.sh)
   const float* noise = nullptr;
   const float* subgoal = nullptr;   // obs_mode 1: the policy's sub-goal offsets for the "subgoal_reach" marker
   int obs_mode = 0;
@@ -168,10 +169,7 @@ extern "C" int jaco_create(const JacoConfig* cfg, JacoHandle** out) {
   CREATECHK(hipMalloc(&h->qlist, 6 * B * sizeof(int)));   // (per tier 2 B slots: an env can come by twice, see the second drain round)
   CREATECHK(hipMalloc(&h->qctl, JQ_WORDS * sizeof(int)));
   CREATECHK(hipMemset(h->qctl, 0, JQ_WORDS * sizeof(int)));
-  if (m.npair > 0) {
-    CREATECHK(hipMalloc(&h->sepdir, B * JMAXPAIR * 4 * sizeof(float)));
-    CREATECHK(hipMemset(h->sepdir, 0, B * JMAXPAIR * 4 * sizeof(float)));
-  }
+  // (the separating-direction cache, 16 B x JMAXPAIR per env = 0.8 GB at 65 536 envs, is allocated by the first launch that uses it: launch_step)
   CREATECHK(hipMalloc(&h->hint, B * sizeof(int)));
   CREATECHK(hipMemset(h->hint, 0, B * sizeof(int)));
   CREATECHK(hipMalloc(&h->routed_mark, B * sizeof(int)));
@@ -484,6 +482,11 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
   A.model = h->model_dev; A.hull = h->hull_dev; A.qpos = h->qpos; A.qvel = h->qvel; A.qacc_ws = h->qacc_ws; A.qpos_lo = h->qpos_lo; A.qvel_lo = h->qvel_lo;
   A.ctrl = ctrl ? ctrl : h->qvel;   // env modes compute ctrl in-kernel; the pointer only has to be readable
   A.sensordata = h->sensordata; A.flags = h->flags; A.stats = h->stats; A.nenv = h->num_envs; A.nsub = nsub;
+  if (h->sep_cache && !h->disable_contact && h->model_host.npair > 0 && !h->sepdir) {   // first use: a handle that never runs contacts with the cache on never pays for it
+    const size_t bytes = (size_t)h->num_envs * JMAXPAIR * 4 * sizeof(float);
+    HIPCHK(h, hipMalloc(&h->sepdir, bytes));
+    HIPCHK(h, hipMemsetAsync(h->sepdir, 0, bytes, st));   // (entries are re-validated by a support query before use: zeros are "no direction known")
+  }
   A.disable_contact = h->disable_contact; A.no_pairlist = !h->pair_list; A.sepdir = h->sep_cache ? h->sepdir : nullptr; A.no_tier_return = !h->tier_return; A.dbg = dbg; A.dbg_env = dbg_env; A.prof = h->prof;
   A.remaining = h->remaining; A.light_left = h->qctl + JQ_LIGHT; A.hint = h->use_hints ? h->hint : nullptr; A.hint_mode = h->use_hints;
   for (int t = 0; t < 3; t++) { A.q[t].list = h->qlist + (size_t)t * 2 * h->num_envs; A.q[t].count = h->qctl + JQ_COUNT + t; A.q[t].taken = h->qctl + JQ_TAKEN + t; A.q[t].limit = h->qctl + JQ_LIMIT + t; A.q[t].reserve = h->qctl + JQ_RESERVE + t; }
