@@ -356,16 +356,17 @@ def test_dual_arm_model_on_the_d30_build_matches_oracle():
 def test_pair_list_on_the_d30_build_keeps_floor_contacts():
     """d30 layout (3 584-pair table: pair-list entries pack 12 + 7 + 7 bits, the plane flag sits at bit 26 where the default layout has it at
     bit 22).  A list pass over a chunk with floor pairs must test them in plane form: both objects lie on the floor, the arms hang over
-    them; 40 free-running substeps with the pair list on and off must agree BIT FOR BIT and keep the objects' floor contacts.  (A chunk's
-    plane flag was once read from the default layout's bit 22 = bit 3 of g2 here; this scene alone does not expose that -- chunk 0 also holds
-    entries with that bit set -- the fix is the shared expression JPL_KBITS + 2 JPL_GBITS; the test is the d30 build's on / off regression.)"""
+    them; 40 free-running substeps with the pair list on / off and the separating-direction cache on / off must agree BIT FOR BIT and keep the
+    objects' floor contacts.  (A chunk's plane flag was once read from the default layout's bit 22 = bit 3 of g2 here; this scene alone does not
+    expose that -- chunk 0 also holds entries with that bit set -- the fix is the shared expression JPL_KBITS + 2 JPL_GBITS; the test is the d30
+    build's on / off regression for both execution options.)"""
     import ctypes
     runs = []
-    for on in (1, 0):
+    for pl_on, sc_on in ((1, 1), (0, 1), (1, 0)):
         e = EmuEnv("jaco2_dual_torque")
-        e.L.emu_set_pair_list.argtypes = [ctypes.c_int]
+        e.L.emu_set_pair_list.argtypes = [ctypes.c_int]; e.L.emu_set_sep_cache.argtypes = [ctypes.c_int]
         e.L.emu_get_counter.argtypes = [ctypes.c_int, ctypes.c_int]; e.L.emu_get_counter.restype = ctypes.c_long
-        e.L.emu_set_pair_list(on)
+        e.L.emu_set_pair_list(pl_on); e.L.emu_set_sep_cache(sc_on)
         e.L.emu_get_counter(0, 1); e.L.emu_get_counter(1, 1)
         try:
             q = e.M["qpos0"].copy()
@@ -379,11 +380,12 @@ def test_pair_list_on_the_d30_build_keeps_floor_contacts():
                 trace.append((e.qpos.copy(), e.qvel.copy(), e.stats.copy(), e.flags.copy(), e.sensordata.copy()))
             runs.append((trace, e.L.emu_get_counter(0, 1), e.L.emu_get_counter(1, 1)))
         finally:
-            e.L.emu_set_pair_list(1)
-    (ta, full_on, list_on), (tb, _, list_off) = runs
-    for x, y in zip(ta, tb):
-        for u, v in zip(x, y):
-            assert np.array_equal(u, v)
+            e.L.emu_set_pair_list(1); e.L.emu_set_sep_cache(1)
+    (ta, full_on, list_on), (tb, _, list_off), (tc, _, _) = runs
+    for other in (tb, tc):
+        for x, y in zip(ta, other):
+            for u, v in zip(x, y):
+                assert np.array_equal(u, v)
     assert list_off == 0 and list_on > 30, (full_on, list_on)        # the list carried nearly every substep
     assert ta[-1][2][0, 3] >= 8                                      # both objects still rest on the floor (4 contacts each) at the end
     assert abs(ta[-1][0][0, 20] - 0.03) < 1e-4 and abs(ta[-1][0][0, 27] - 0.03) < 1e-4
