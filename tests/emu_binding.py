@@ -23,7 +23,7 @@ def lib(layout=""):
     """layout "": the default build (11 bodies / 21 dofs in blocks 9 + 6 + 6); "_d12": the build for jaco2_torque.xml (12 hinge dofs, one tree);
     "_d30": the build for jaco2_dual_torque.xml (two arms + two objects, 30 dofs; ctrl level)."""
     if layout not in _libs:
-        subprocess.check_call(["make", "-s", "-C", EMU_DIR])
+        subprocess.check_call(["make", "-s", "-C", EMU_DIR] + (["libjaco_emu_wrench.so"] if layout == "_wrench" else []))
         L = ctypes.CDLL(os.path.join(EMU_DIR, "libjaco_emu%s.so" % layout))
         fp, ip, up = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint)
         L.emu_physics_step.argtypes = [ctypes.c_char_p, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int, fp, fp, fp, fp, fp, up, ip, fp, ctypes.c_int, ip]
@@ -39,12 +39,12 @@ def lib(layout=""):
 class EmuEnv:
     """Batched env state (fp32, [nenv][n]) stepped by the emulated kernel."""
 
-    def __init__(self, model="jaco2_curtain_torque", nenv=1):
+    def __init__(self, model="jaco2_curtain_torque", nenv=1, layout=None):
         self.blob = open(os.path.join(ASSETS, model + ".jacomdl"), "rb").read()
         from mujoco_jaco_amd.modelc import blob as blobmod
         M = blobmod.loads(self.blob)
         from mujoco_jaco_amd import _lib as product_lib
-        self.L = lib(product_lib.variant_for(self.blob))   # (the same layout choice as the product's loader)
+        self.L = lib(layout if layout is not None else product_lib.variant_for(self.blob))   # (the same layout choice as the product's loader)
         self.M = M
         self.nq, self.nv, self.nu, self.ns = int(M["nq"][0]), int(M["nv"][0]), int(M["nu"][0]), int(M["nsensor"][0])
         self.nenv = nenv

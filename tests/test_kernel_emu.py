@@ -389,3 +389,37 @@ def test_pair_list_on_the_d30_build_keeps_floor_contacts():
     assert list_off == 0 and list_on > 30, (full_on, list_on)        # the list carried nearly every substep
     assert ta[-1][2][0, 3] >= 8                                      # both objects still rest on the floor (4 contacts each) at the end
     assert abs(ta[-1][0][0, 20] - 0.03) < 1e-4 and abs(ta[-1][0][0, 27] - 0.03) < 1e-4
+
+
+def test_wrench_rows_build_option_matches_oracle(model_arrays, names):
+    """The body-space ("wrench") constraint rows (physics_kernel.h, -DJACO_WRENCH=1: a row as its 6-vector wrench + two body ids, every product
+    with J formed from it) are an A/B build option, measured slower on MI355X and not shipped (profiles/r05_ab_wrench_rows.txt).  This keeps the
+    option honest: the same kernel sources built with it, single steps re-synchronised with the oracle -- reset distribution (plane-box, box-box,
+    limit rows) and the in-hand grasp (condim-6 hull contacts, ~230 rows through the bigger tiers): same contact / row counts, same bounds as the
+    dense rows."""
+    from mujoco_jaco_amd.modelc import rot
+    o = Oracle(); e = EmuEnv(layout="_wrench")
+    q = workload.reset_states(model_arrays["qpos0"], 3, seed=11)
+    c = workload.random_ctrl(3, seed=12, scale=0.2)
+    worst = 0.0
+    for k in range(3):
+        o.reset(); o.set("qpos", q[k])
+        for i in range(12):
+            eq, ev = _sync_step(o, e, c[k])
+            assert (e.stats[0, 0], e.stats[0, 1]) == (o.ncon, o.nefc), (k, i)
+            worst = max(worst, eq)
+    assert worst < 2e-6 and e.flags[0] == 0
+    qg = model_arrays["qpos0"].copy()
+    qg[:6] = [1.3, 3.85, 1.05, 2.05, 1.5, -1.15]; qg[6:9] = 0.6; qg[16:18] = [.4, .3]
+    o.reset(); o.set("qpos", qg); o.forward()
+    b = names["body"].index("EE_obj")
+    xp = o.get("xpos").reshape(-1, 3)[b]; xq = o.get("xquat").reshape(-1, 4)[b]
+    qg[9:12] = xp + rot.quat_to_mat(xq) @ np.array([-0.04, 0, 0]); qg[12:16] = xq
+    o.set("qpos", qg); o.set("qvel", np.zeros(21)); o.set("qacc_warmstart", np.zeros(21))
+    most = 0
+    for i in range(6):
+        eq, ev = _sync_step(o, e, np.concatenate([np.zeros(6), [1.0] * 3]))
+        assert (e.stats[0, 0], e.stats[0, 1]) == (o.ncon, o.nefc), i
+        most = max(most, o.nefc)
+        assert eq < 5e-6
+    assert most > 128 and (e.flags[0] & 15) == 0

@@ -8,7 +8,6 @@ rounding (U(-1, 1) x 2e-7 on the arm / finger angles, `draws` times):
   * the first substep at which a twin's contact LIST (geom pairs, in order) differs from the unperturbed run's, which contact appears /
     disappears (geom names, its depth at that moment) -- a grazing contact switching on or off one substep earlier or later,
   * or, without any difference in the contact lists, the growth of the perturbation per env step (smooth amplification through stiff contacts),
-  * whether the controller's pseudo-inverse branch (|det(J M^-1 J^T)| < 1e-3, abr_control's SVD path) is taken by one twin and not the other.
 
 An env whose oracle twins all stay within 1e-5 while the HIP env parts by > 1e-4 would be a discrepancy of the kernel itself: listed as UNEXPLAINED.
 
@@ -41,7 +40,7 @@ def _geom_label(names, M, g):
 
 
 class Twin:
-    """OracleEnv with a per-substep record of the contact list and the controller branch."""
+    """OracleEnv with a per-substep record of the contact list."""
 
     def __init__(self, names, q0k, round_state=0):
         from oracle_env import OracleEnv
@@ -67,7 +66,7 @@ class Twin:
         oe.grip, oe.steps, oe.episodes = s["grip"], s["steps"], s["episodes"]
 
     def run(self, act, noise, first, last, record=False):
-        """env steps first .. last - 1; returns qpos after each, and (record) per substep the contact pair list + depth list + OSC branch."""
+        """env steps first .. last - 1; returns qpos after each, and (record) per substep the contact pair list + depth list."""
         import glue
         oe, o = self.oe, self.oe.o
         qs, rec = [], []
