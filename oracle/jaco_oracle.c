@@ -1,5 +1,6 @@
 /* TEST INFRASTRUCTURE - NOT PRODUCT CODE.  See jaco_oracle.h for scope, citations and the
- * "parity unpinned" statement.  Plain C99, fp64, scalar; generic over the raw (unfused)
+ * parity statement (pinned to MuJoCo's recorded object transients for the contact physics of the free bodies; arm dynamics, hull contacts and
+ * the controller unpinned).  Plain C99, fp64, scalar; generic over the raw (unfused)
  * model arrays so that it shares no structure with the HIP path it checks.
  *
  * Pipeline restated (SURVEY.md App. D.1 numbering, all [EXT] = published MuJoCo algorithm):

@@ -1,7 +1,7 @@
 """CPU tier: the fp64 oracle against analytic known answers and an independent numpy formulation.
 
-The reference has no tests and its physics lives in an absent closed-source binary (SURVEY.md 8c:
-"parity unpinned"), so the oracle is pinned by first principles instead: closed-form solutions,
+The reference has no tests and its physics lives in an absent closed-source binary.  Its contact physics of the free bodies is
+pinned to MuJoCo's own recorded numbers (tests/test_mujoco_statics.py); everything else by first principles, here: closed-form solutions,
 conservation laws, two independent algorithms reaching the same optimum, and the dumbest possible
 numpy restatement of the kinematics / mass matrix (mujoco_jaco_amd/modelc/kin.py).
 """
