@@ -7,7 +7,7 @@
  * MuJoCo 2.0 binary reached through an un-pinned mujoco-py fork (README.md:15-24 of the
  * reference), which is absent from /root/reference and from this image, and the reference
  * has no tests.  PINNED (round 5) against the only MuJoCo-produced numbers the reference holds:
- * the object-height transients of its recorded trajectories (models_baseline/trajectories/*.npz,
+ * the object-height transients of its recorded trajectories (the .npz files under models_baseline/trajectories,
  * obs[:, 10]) -- ten float32 values of the object falling onto the floor, thirteen of the holder
  * pushing it out of its spawn overlap, both rest heights -- reproduced BIT FOR BIT
  * (tests/test_mujoco_statics.py, tests/golden/mujoco_rest_heights.json): plane-box and box-box
