@@ -58,7 +58,9 @@ struct JacoHandle {
   int* stats = nullptr;
   int* remaining = nullptr;
   // tier queues (medium, heavy, huge): lists [3][num_envs] and the control words JQ_* below
-  int *qlist = nullptr, *qctl = nullptr;
+  int *qlist = nullptr, *qctl = nullptr;   // both double-buffered: launch N uses lists [qsel][6 B] and control words [qsel][JQ_WORDS]
+  int qsel = 0;                               // buffer of the next launch
+  bool q_ready = false;                       // ... already prepared by the previous launch's routing kernel
   int* hint = nullptr;                        // [num_envs] tier the env's last step needed
   bool reset_listed = false;                  // jaco_reset in progress: h->order holds the list of the masked envs
   int* routed_mark = nullptr;                 // [num_envs] id of the launch that queued the env for a bigger tier before it started
@@ -166,9 +168,9 @@ extern "C" int jaco_create(const JacoConfig* cfg, JacoHandle** out) {
   CREATECHK(hipMalloc(&h->stats, B * 4 * sizeof(int)));
   CREATECHK(hipMalloc(&h->dbg, JDBG_SIZE * sizeof(float)));
   CREATECHK(hipMalloc(&h->remaining, B * sizeof(int)));
-  CREATECHK(hipMalloc(&h->qlist, 6 * B * sizeof(int)));   // (per tier 2 B slots: an env can come by twice, see the second drain round)
-  CREATECHK(hipMalloc(&h->qctl, JQ_WORDS * sizeof(int)));
-  CREATECHK(hipMemset(h->qctl, 0, JQ_WORDS * sizeof(int)));
+  CREATECHK(hipMalloc(&h->qlist, 2 * 6 * B * sizeof(int)));   // (per tier 2 B slots: an env can come by twice, see the second drain round)
+  CREATECHK(hipMalloc(&h->qctl, 2 * JQ_WORDS * sizeof(int)));
+  CREATECHK(hipMemset(h->qctl, 0, 2 * JQ_WORDS * sizeof(int)));
   // (the separating-direction cache, 16 B x JMAXPAIR per env = 0.8 GB at 65 536 envs, is allocated by the first launch that uses it: launch_step)
   CREATECHK(hipMalloc(&h->hint, B * sizeof(int)));
   CREATECHK(hipMemset(h->hint, 0, B * sizeof(int)));
@@ -403,11 +405,52 @@ __global__ void jaco_drain_round2_kernel(int* ctl, int medium_grid, int heavy_gr
   ctl[JQ_ROUND1 + 0] = ctl[JQ_TAKEN + 0];   // = the medium queue's length when its first drain ended
   ctl[JQ_ROUND1 + 1] = ctl[JQ_COUNT + 1];   // (the heavy queue only grows again in the second medium drain)
 }
-// ... and the last block to finish sizes this launch's workers from what has just been queued (was a one-thread launch of its own): per tier, the
-// envs that start there (a medium worker serves ~8 of them in a third of a step, a heavy one ~4, a huge one ~2) plus the reserve for overflows
-// that only show up during the step (jaco_prepare_kernel: a tenth of the last step's late arrivals)
-__global__ void jaco_route_kernel(int* hint, int* mark, int launch_id, int* lists, int* ctl, int* remaining, unsigned* cost, int n, int nsub, int wm, int wh, int wg) {
+// Queue state is double-buffered: launch N works on buffer N & 1 (control words + lists).  What used to be a launch of its own in front of
+// every step -- lists back to -1, counters zeroed, the workers sized from the previous launch's demand -- is now done for the NEXT launch's
+// buffer by this launch's routing kernel (nobody touches that buffer during this launch set: the launch that used it is complete in
+// stream order), so an env step in a row of env steps starts with ONE small kernel instead of two.  Launches that do not route (reset-time
+// forward passes, ctrl level without hints) and the first launch after one of those run jaco_prepare_kernel on their own buffer.
+//
+// Sizing the workers (one thread): how many of the launched workers of each tier start, and how many stay resident when the queue runs
+// dry, follows the previous launch's demand for that tier (an idle worker still holds LDS the light grid could use): a medium worker
+// serves an env in ~1/20 of a step, a heavy / huge one in ~1/8 - 1/4.  `prev` = control words of the launch before (final), `ctl` = this launch's.
+static __device__ void jaco_queue_limits(const int* prev, int* ctl, int mode, int wm, int wh, int wg, int light_wgs) {
+  // (the demand that counts is that of the last real step, not of a reset-time forward pass in between)
+  for (int t = 0; t < 3; t++) {
+    if (prev[JQ_LASTMODE] <= 1) {
+      // (what came by a second time -- handed down by the heavy drain, overflowed again after that -- is not new demand)
+      ctl[JQ_PREV_COUNT + t] = (t < 2 && prev[JQ_ROUND1 + t] >= 0) ? prev[JQ_ROUND1 + t] : prev[JQ_COUNT + t];
+      ctl[JQ_PREV_HINTED + t] = prev[JQ_HINTED + t];
+    } else { ctl[JQ_PREV_COUNT + t] = prev[JQ_PREV_COUNT + t]; ctl[JQ_PREV_HINTED + t] = prev[JQ_PREV_HINTED + t]; }
+  }
+  ctl[JQ_LASTMODE] = mode; ctl[JQ_ROUND1] = -1; ctl[JQ_ROUND1 + 1] = -1;
+  const int* pc = ctl + JQ_PREV_COUNT;
+  const int want[3] = {16 + pc[0] / 10, 8 + pc[1] / 4, 2 + pc[2] / 2}, cap[3] = {wm, wh, wg};
+  for (int t = 0; t < 3; t++) {
+    const int w = want[t] < cap[t] ? want[t] : cap[t];
+    // reserve: overflows that only show up during a step = last step's demand minus what it had queued at once
+    int late = pc[t] - ctl[JQ_PREV_HINTED + t];
+    late = late < 0 ? 0 : late;
+    const int base = t == 0 ? 8 : (t == 1 ? 4 : 1);   // (a resident heavy / huge worker holds the LDS of 3 / 5 light envs)
+    ctl[JQ_LIMIT + t] = w; ctl[JQ_RESERVE + t] = base + late / 10;
+  }
+  ctl[JQ_LIGHT] = light_wgs;
+}
+// a buffer ready for use: nothing queued, nothing claimed (JQ_PREV_*, JQ_LASTMODE, JQ_LIMIT, JQ_RESERVE, JQ_LIGHT are written by jaco_queue_limits)
+static __device__ void jaco_queue_clear(int* ctl) {
+  for (int t = 0; t < 3; t++) { ctl[JQ_COUNT + t] = 0; ctl[JQ_TAKEN + t] = 0; ctl[JQ_HINTED + t] = 0; }
+  ctl[JQ_ROUTED] = 0; ctl[JQ_TICKET] = 0; ctl[JQ_ROUND1] = -1; ctl[JQ_ROUND1 + 1] = -1;
+}
+// Envs whose previous step ended in a bigger tier go there at once: queued here, before the launch, so that the tier's workers find them
+// when they start; the hint is consumed (it is re-earned during the step by whichever tier is really needed).  The last block to finish
+// sizes this launch's workers: per tier the previous launch's demand (jaco_queue_limits), then the envs that start there (a medium
+// worker serves ~8 of them in a third of a step, a heavy one ~4, a huge one ~2) plus the reserve for overflows that only show up during
+// the step -- and clears the other buffer's control words for the next launch.  Every thread resets its share of the other buffer's lists.
+__global__ void jaco_route_kernel(int* hint, int* mark, int launch_id, int* lists, int* ctl, int* remaining, unsigned* cost, int n, int nsub, int wm, int wh, int wg,
+                                  int* next_lists, int* other_ctl, unsigned* oc, int mode) {
   const int e = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (e < n) for (int j = 0; j < 6; j++) next_lists[(size_t)j * n + e] = -1;
+  if (e < 66) oc[e] = 0u;
   const int t = e < n ? hint[e] : 0;
   if (t > 0) {
     hint[e] = 0;
@@ -422,6 +465,7 @@ __global__ void jaco_route_kernel(int* hint, int* mark, int launch_id, int* list
   if (threadIdx.x == 0) last_block = atomicAdd(&ctl[JQ_TICKET], 1) == (int)gridDim.x - 1;
   __syncthreads();
   if (!last_block || threadIdx.x != 0) return;
+  jaco_queue_limits(other_ctl, ctl, mode, wm, wh, wg, n);
   const int cap[3] = {wm, wh, wg}, per[3] = {8, 4, 2};
   int routed = 0;
   for (int q = 0; q < 3; q++) {
@@ -436,36 +480,17 @@ __global__ void jaco_route_kernel(int* hint, int* mark, int launch_id, int* list
   ctl[JQ_ROUTED] = routed;
   ctl[JQ_LIGHT] = n - routed;   // the light workgroups of queued envs leave without being counted
   ctl[JQ_TICKET] = 0;
+  jaco_queue_clear(other_ctl);   // (its demand figures have been carried over: the next launch's buffer)
 }
-// queue reset before every launch: entries = -1, counters zeroed, light workgroups to go = nenv; how many of the launched
-// workers of each tier stay resident follows the previous launch's demand for that tier (an idle worker still holds LDS the
-// light grid could use): a medium worker serves an env in ~1/20 of a step, a heavy / huge one in ~1/8 - 1/4
-__global__ void jaco_prepare_kernel(int* ctl, int* lists, int n, int wm, int wh, int wg, unsigned* oc, int mode, int light_wgs) {
+// queue preparation as a launch of its own (launches that do not route, and the first launch after one of those): this launch's lists = -1,
+// its counters zeroed, its workers sized from the launch before
+__global__ void jaco_prepare_kernel(int* ctl, const int* prev_ctl, int* lists, int n, int wm, int wh, int wg, unsigned* oc, int mode, int light_wgs) {
   int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   if (i < 6 * n) lists[i] = -1;
   if (i < 66) oc[i] = 0u;
   if (i == 0) {
-    // without the ordering pass (small batches, reset-time launches) nothing is known about this launch's demand: workers as
-    // the previous launch would have wanted them, all of them staying to the end
-    // (the demand that counts is that of the last real step, not of a reset-time forward pass in between)
-    if (ctl[JQ_LASTMODE] <= 1) for (int t = 0; t < 3; t++) {
-      // (what came by a second time -- handed down by the heavy drain, overflowed again after that -- is not new demand)
-      ctl[JQ_PREV_COUNT + t] = (t < 2 && ctl[JQ_ROUND1 + t] >= 0) ? ctl[JQ_ROUND1 + t] : ctl[JQ_COUNT + t];
-      ctl[JQ_PREV_HINTED + t] = ctl[JQ_HINTED + t];
-    }
-    ctl[JQ_LASTMODE] = mode; ctl[JQ_ROUND1] = -1; ctl[JQ_ROUND1 + 1] = -1;
-    const int* pc = ctl + JQ_PREV_COUNT;
-    int want[3] = {16 + pc[0] / 10, 8 + pc[1] / 4, 2 + pc[2] / 2}, cap[3] = {wm, wh, wg};
-    for (int t = 0; t < 3; t++) {
-      const int w = want[t] < cap[t] ? want[t] : cap[t];
-      // reserve: overflows that only show up during a step = last step's demand minus what it had queued at once
-      int late = pc[t] - ctl[JQ_PREV_HINTED + t];
-      late = late < 0 ? 0 : late;
-      const int base = t == 0 ? 8 : (t == 1 ? 4 : 1);   // (a resident heavy / huge worker holds the LDS of 3 / 5 light envs)
-      ctl[JQ_LIMIT + t] = w; ctl[JQ_RESERVE + t] = base + late / 10; ctl[JQ_COUNT + t] = 0; ctl[JQ_TAKEN + t] = 0; ctl[JQ_HINTED + t] = 0;
-    }
-    ctl[JQ_ROUTED] = 0;
-    ctl[JQ_LIGHT] = light_wgs;
+    jaco_queue_clear(ctl);
+    jaco_queue_limits(prev_ctl, ctl, mode, wm, wh, wg, light_wgs);
   }
 }
 
@@ -488,8 +513,13 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
     HIPCHK(h, hipMemsetAsync(h->sepdir, 0, bytes, st));   // (entries are re-validated by a support query before use: zeros are "no direction known")
   }
   A.disable_contact = h->disable_contact; A.no_pairlist = !h->pair_list; A.sepdir = h->sep_cache ? h->sepdir : nullptr; A.no_tier_return = !h->tier_return; A.dbg = dbg; A.dbg_env = dbg_env; A.prof = h->prof;
-  A.remaining = h->remaining; A.light_left = h->qctl + JQ_LIGHT; A.hint = h->use_hints ? h->hint : nullptr; A.hint_mode = h->use_hints;
-  for (int t = 0; t < 3; t++) { A.q[t].list = h->qlist + (size_t)t * 2 * h->num_envs; A.q[t].count = h->qctl + JQ_COUNT + t; A.q[t].taken = h->qctl + JQ_TAKEN + t; A.q[t].limit = h->qctl + JQ_LIMIT + t; A.q[t].reserve = h->qctl + JQ_RESERVE + t; }
+  // this launch's queue buffer (lists + control words) and the other one: the previous launch's, and the next launch's
+  int* const qctl = h->qctl + h->qsel * JQ_WORDS;
+  int* const qctl_other = h->qctl + (h->qsel ^ 1) * JQ_WORDS;
+  int* const qlist = h->qlist + (size_t)h->qsel * 6 * h->num_envs;
+  int* const qlist_other = h->qlist + (size_t)(h->qsel ^ 1) * 6 * h->num_envs;
+  A.remaining = h->remaining; A.light_left = qctl + JQ_LIGHT; A.hint = h->use_hints ? h->hint : nullptr; A.hint_mode = h->use_hints;
+  for (int t = 0; t < 3; t++) { A.q[t].list = qlist + (size_t)t * 2 * h->num_envs; A.q[t].count = qctl + JQ_COUNT + t; A.q[t].taken = qctl + JQ_TAKEN + t; A.q[t].limit = qctl + JQ_LIMIT + t; A.q[t].reserve = qctl + JQ_RESERVE + t; }
   A.routed_mark = nullptr; A.launch_id = ++h->launch_id;
   A.env_mode = io.mode; A.task_id = h->task; A.nact = (h->task == JACO_TASK_REACHING || h->task == JACO_TASK_PUSHING) ? 6 : 7; A.seed = h->seed;
   A.task = h->task_rows; A.cache = h->cache; A.action = io.action; A.noise = h->noise; A.obs_mode = h->obs_mode; A.subgoal = h->subgoal; A.obs = io.obs; A.reward = io.reward; A.done = io.done; A.terminal = h->terminal; A.terminal_obs = h->terminal_obs; A.goal_buf = h->goal_buf; A.goal_n = h->goal_n; A.goal_stride = h->goal_stride; A.mask = io.mask; A.marker = h->marker;
@@ -536,13 +566,19 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
   // frees and would otherwise starve behind the light grid, leaving serial tails of several ms per env step).  The drains that
   // follow in stream order serve whatever the workers did not (all of it when concurrency is off: full grids, which is also
   // what carries the load when most envs overflow).
-  JLAUNCH(h, jaco_prepare_kernel, dim3((unsigned)((6 * h->num_envs + 255) / 256)), dim3(256), 0, st, h->qctl, h->qlist, h->num_envs, h->workers, h->workers_heavy, h->workers_huge, h->order_ctl, io.mode, (int)light_grid);
-  HIPCHK(h, hipGetLastError());
-  if (A.hint && io.mode <= 1) {   // queue the envs whose last step ended in a bigger tier, size the tiers' workers
-    JLAUNCH(h, jaco_route_kernel, dim3((unsigned)((h->num_envs + 255) / 256)), dim3(256), 0, st, h->hint, h->routed_mark, A.launch_id, h->qlist, h->qctl, h->remaining, h->cost, h->num_envs, nsub,
-            h->workers, h->workers_heavy, h->workers_huge);
+  // (the contact-free path above, take_action and terminal_inspection use no queue: they leave the buffers as they are)
+  const bool routes = A.hint && io.mode <= 1 && !(io.listed && io.mask);
+  if (!h->q_ready || !routes) {   // this launch's buffer has not been prepared by the launch before
+    JLAUNCH(h, jaco_prepare_kernel, dim3((unsigned)((6 * h->num_envs + 255) / 256)), dim3(256), 0, st, qctl, qctl_other, qlist, h->num_envs, h->workers, h->workers_heavy, h->workers_huge, h->order_ctl, io.mode, (int)light_grid);
+    HIPCHK(h, hipGetLastError());
+  }
+  if (routes) {   // queue the envs whose last step ended in a bigger tier, size the tiers' workers, prepare the next launch's buffer
+    JLAUNCH(h, jaco_route_kernel, dim3((unsigned)((h->num_envs + 255) / 256)), dim3(256), 0, st, h->hint, h->routed_mark, A.launch_id, qlist, qctl, h->remaining, h->cost, h->num_envs, nsub,
+            h->workers, h->workers_heavy, h->workers_huge, qlist_other, qctl_other, h->order_ctl, io.mode);
     A.routed_mark = h->routed_mark;
   }
+  h->q_ready = routes;
+  h->qsel ^= 1;
   // The resident workers go first: their workgroups need 20 - 68 KB of LDS on one CU, and once the light grid (13 KB per workgroup,
   // 65 536 of them) has filled the chip such a hole only opens when the grid runs out -- a huge-tier env queued at t = 0 would then
   // start its 10 ms of work when everything else is done.  Launched before the ordering pass, they have three small kernels of
@@ -584,7 +620,7 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
     A.handdown = 1;
     JLAUNCHK(h, JK_HEAVY_DRAIN, hg, st, A);
     A.handdown = 0;
-    JLAUNCH(h, jaco_drain_round2_kernel, dim3(1), dim3(1), 0, st, h->qctl, (int)mg, (int)hg);
+    JLAUNCH(h, jaco_drain_round2_kernel, dim3(1), dim3(1), 0, st, qctl, (int)mg, (int)hg);
     JLAUNCHK(h, JK_MEDIUM_DRAIN, mg, st, A);
   }
   if (io.mode != 2) JLAUNCHK(h, JK_HEAVY_DRAIN, hg, st, A);
@@ -752,7 +788,7 @@ extern "C" int jaco_debug_queue_words(JacoHandle* h, int32_t* out_host, int n) {
   if (!h || !out_host || n < JQ_WORDS) return JACO_EINVAL;
   ENTER(h);
   HIPCHK(h, hipDeviceSynchronize());
-  HIPCHK(h, hipMemcpy(out_host, h->qctl, JQ_WORDS * sizeof(int), hipMemcpyDeviceToHost));
+  HIPCHK(h, hipMemcpy(out_host, h->qctl + (h->qsel ^ 1) * JQ_WORDS, JQ_WORDS * sizeof(int), hipMemcpyDeviceToHost));   // (qsel: the NEXT launch's buffer)
   return JQ_WORDS;
 }
 extern "C" int jaco_physics_step_debug(JacoHandle* h, const float* ctrl_dev, int nsub, int env, float* dump_host, int dump_floats) {
