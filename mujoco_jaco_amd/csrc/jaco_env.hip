@@ -449,7 +449,6 @@ static __device__ void jaco_queue_clear(int* ctl) {
 __global__ void jaco_route_kernel(int* hint, int* mark, int launch_id, int* lists, int* ctl, int* remaining, unsigned* cost, int n, int nsub, int wm, int wh, int wg,
                                   int* next_lists, int* other_ctl, unsigned* oc, int mode) {
   const int e = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-  if (e < n) for (int j = 0; j < 6; j++) next_lists[(size_t)j * n + e] = -1;
   if (e < 66) oc[e] = 0u;
   const int t = e < n ? hint[e] : 0;
   if (t > 0) {
@@ -463,24 +462,38 @@ __global__ void jaco_route_kernel(int* hint, int* mark, int launch_id, int* list
   __threadfence();
   __syncthreads();
   if (threadIdx.x == 0) last_block = atomicAdd(&ctl[JQ_TICKET], 1) == (int)gridDim.x - 1;
+  // the other buffer's lists back to "nothing published" (behind the ticket: these stores need no fence, the end of the kernel makes them visible)
+  if (e < n) for (int j = 0; j < 6; j++) next_lists[(size_t)j * n + e] = -1;
   __syncthreads();
-  if (!last_block || threadIdx.x != 0) return;
-  jaco_queue_limits(other_ctl, ctl, mode, wm, wh, wg, n);
-  const int cap[3] = {wm, wh, wg}, per[3] = {8, 4, 2};
-  int routed = 0;
-  for (int q = 0; q < 3; q++) {
-    const int hinted = atomicAdd(&ctl[JQ_COUNT + q], 0);   // (device-scope read: the other blocks' appends)
-    ctl[JQ_HINTED + q] = hinted;
-    routed += hinted;
-    const int reserve = ctl[JQ_RESERVE + q] < cap[q] ? ctl[JQ_RESERVE + q] : cap[q];
-    const int want = reserve + (hinted + per[q] - 1) / per[q];
-    ctl[JQ_LIMIT + q] = want < cap[q] ? want : cap[q];
-    ctl[JQ_RESERVE + q] = reserve;
+  if (!last_block) return;
+  // (one thread doing this on global memory is ~50 dependent round trips = 15 us in front of every step: the two buffers' control words come in
+  //  and go out in parallel, the arithmetic in between runs on their copies in LDS)
+  __shared__ int sp[JQ_WORDS], sc[JQ_WORDS];
+  if (threadIdx.x < JQ_WORDS) {
+    sp[threadIdx.x] = other_ctl[threadIdx.x];
+    sc[threadIdx.x] = atomicAdd(&ctl[threadIdx.x], 0);   // (device-scope read: the other blocks' appends)
   }
-  ctl[JQ_ROUTED] = routed;
-  ctl[JQ_LIGHT] = n - routed;   // the light workgroups of queued envs leave without being counted
-  ctl[JQ_TICKET] = 0;
-  jaco_queue_clear(other_ctl);   // (its demand figures have been carried over: the next launch's buffer)
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    jaco_queue_limits(sp, sc, mode, wm, wh, wg, n);
+    const int cap[3] = {wm, wh, wg}, per[3] = {8, 4, 2};
+    int routed = 0;
+    for (int q = 0; q < 3; q++) {
+      const int hinted = sc[JQ_COUNT + q];
+      sc[JQ_HINTED + q] = hinted;
+      routed += hinted;
+      const int reserve = sc[JQ_RESERVE + q] < cap[q] ? sc[JQ_RESERVE + q] : cap[q];
+      const int want = reserve + (hinted + per[q] - 1) / per[q];
+      sc[JQ_LIMIT + q] = want < cap[q] ? want : cap[q];
+      sc[JQ_RESERVE + q] = reserve;
+    }
+    sc[JQ_ROUTED] = routed;
+    sc[JQ_LIGHT] = n - routed;   // the light workgroups of queued envs leave without being counted
+    sc[JQ_TICKET] = 0;
+    jaco_queue_clear(sp);   // (its demand figures have been carried over: the next launch's buffer)
+  }
+  __syncthreads();
+  if (threadIdx.x < JQ_WORDS) { ctl[threadIdx.x] = sc[threadIdx.x]; other_ctl[threadIdx.x] = sp[threadIdx.x]; }
 }
 // queue preparation as a launch of its own (launches that do not route, and the first launch after one of those): this launch's lists = -1,
 // its counters zeroed, its workers sized from the launch before
@@ -607,7 +620,7 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
   else JLAUNCHK(h, JK_STEP, light_grid, st, A);
   if (kev) HIPCHK(h, hipEventRecord(kev->second, st));
   HIPCHK(h, hipGetLastError());
-  if (conc) for (int t = 0; t < 3; t++) HIPCHK(h, hipStreamWaitEvent(st, h->ev_join[t], 0));
+  if (conc) for (int t = 0; t < 3; t++) HIPCHK(h, hipStreamWaitEvent(st, h->ev_join[t], 0));   // (joining each tier's workers only in front of the drain that needs them was tried: no gain, every cross-stream wait costs its ~15 us wherever it sits)
   const unsigned ne = (unsigned)h->num_envs;
   // drain grids = the tiers' full occupancy on 256 CUs (8 / 4 / 2 workgroups per CU by LDS and registers); slots are claimed one at a time
   unsigned mg = ne < 2048 ? ne : 2048, hg = ne < JACO_HEAVY_GRID ? ne : JACO_HEAVY_GRID, gg = ne < 512 ? ne : 512;

@@ -1084,6 +1084,18 @@ JDEV float jt_vec(const float* J, const float (&f)[NR], int ne, int lane, int nv
   return lane < nv ? acc : 0.f;
 }
 
+// The stopping test one iteration ahead.  When the step just taken switched no row on or off, the cost along it was ONE quadratic, of which
+// the search direction was the exact Newton step: the gradient left over is (1 - al) times the old one and the iteration that would follow would
+// improve the cost by exactly (1 - al)^2 times what this one did.  MuJoCo's own criterion (improvement * scale < tolerance, [EXT] engine_solver.c)
+// applied to that prediction ends the solve here -- without the matrix-core pass, Hessian fetch and gradient that the next round would spend on
+// finding out the same thing (half of all Hessian builds: most solves are one real Newton step).
+#ifndef JACO_NEWTON_LOOKAHEAD
+#define JACO_NEWTON_LOOKAHEAD 1   // (0: A/B builds, tools/build_variant.sh)
+#endif
+JDEV bool newton_next_round_is_idle(bool any_row_switched, float al, float improvement, float scale, float tol) {
+  const float r = 1.f - al;
+  return JACO_NEWTON_LOOKAHEAD && !any_row_switched && r * r * improvement * scale < tol;
+}
 template <class L>
 JDEV NewtonOut stage_newton(const JacoModelDev* m, L& s, const float (&mrow)[JNV], float smooth, float hd, int lane, JProfCtx& pc) {
   (void)pc;
@@ -1277,17 +1289,20 @@ JDEV NewtonOut stage_newton(const JacoModelDev* m, L& s, const float (&mrow)[JNV
     // move; the cost decrease is evaluated along the line in cancellation-free form so that MuJoCo's absolute
     // tolerance stays meaningful in fp32 (the 1280 kg pedestal's cost terms are ~1e3, the object's ~1e-3)
     float dc = 0.f;
+    bool switched = false;
 #pragma unroll
     for (int q = 0; q < NR; q++) {
       float dx = al * jp[q], xn = x[q] + dx;
       bool was = x[q] < 0.f, is = xn < 0.f;
+      switched = switched || was != is;
       dc += (was && is) ? 0.5f * D[q] * dx * (2.f * x[q] + dx) : (is ? 0.5f * D[q] * xn * xn : (was ? -0.5f * D[q] * x[q] * x[q] : 0.f));
       x[q] = xn;
     }
+    const bool any_switched = wave_ballot(switched) != 0ull;
     float improvement = -(al * pMa + 0.5f * al * al * pMp + wave_sum(dc));
     JSTAMP(14);
     a += al * p; Ma += al * Mp;
-    if (improvement * scale < tol) { it++; break; }
+    if (improvement * scale < tol || newton_next_round_is_idle(any_switched, al, improvement, scale, tol)) { it++; break; }
   }
 #pragma unroll
   for (int q = 0; q < NR; q++) f[q] = x[q] < 0.f ? -D[q] * x[q] : 0.f;
@@ -1519,17 +1534,20 @@ JDEV NewtonOut stage_newton_w(const JacoModelDev* m, L& s, const float (&mrow)[J
       nls++;
     }
     float dc = 0.f;
+    bool switched = false;
 #pragma unroll
     for (int q = 0; q < NR; q++) {
       float dx = al * jp[q], xn = x[q] + dx;
       bool was = x[q] < 0.f, is = xn < 0.f;
+      switched = switched || was != is;
       dc += (was && is) ? 0.5f * D[q] * dx * (2.f * x[q] + dx) : (is ? 0.5f * D[q] * xn * xn : (was ? -0.5f * D[q] * x[q] * x[q] : 0.f));
       x[q] = xn;
     }
+    const bool any_switched = wave_ballot(switched) != 0ull;
     float improvement = -(al * pMa + 0.5f * al * al * pMp + wave_sum(dc));
     JSTAMP(14);
     a += al * p; Ma += al * Mp;
-    if (improvement * scale < tol) { it++; break; }
+    if (improvement * scale < tol || newton_next_round_is_idle(any_switched, al, improvement, scale, tol)) { it++; break; }
   }
 #pragma unroll
   for (int q = 0; q < NR; q++) f[q] = x[q] < 0.f ? -D[q] * x[q] : 0.f;
@@ -1642,11 +1660,12 @@ JDEV NewtonOut stage_newton_limits(const JacoModelDev* m, L& s, const float (&mr
     }
     const float dx = al * jp, xn = x + dx;
     const bool was = has && x < 0.f, is = has && xn < 0.f;
+    const bool any_switched = wave_ballot(was != is) != 0ull;
     const float dc = (was && is) ? 0.5f * D * dx * (2.f * x + dx) : (is ? 0.5f * D * xn * xn : (was ? -0.5f * D * x * x : 0.f));
     x = xn;
     const float improvement = -(al * pMa + 0.5f * al * al * pMp + wave_sum(dc));
     a += al * p; Ma += al * Mp;
-    if (improvement * scale < tol) { it++; break; }
+    if (improvement * scale < tol || newton_next_round_is_idle(any_switched, al, improvement, scale, tol)) { it++; break; }
   }
   const float f = (has && x < 0.f) ? -D * x : 0.f;
   out.qacc = a;
@@ -1794,11 +1813,12 @@ JDEV void newton_side(const JacoModelDev* m, L& s, const float (&mrow)[JNV], flo
     }
     const float dx = al * jp, xn = x + dx;
     const bool was = x < 0.f, is = xn < 0.f;
+    const bool any_switched = wave_ballot(was != is) != 0ull;
     const float dc = (was && is) ? 0.5f * D * dx * (2.f * x + dx) : (is ? 0.5f * D * xn * xn : (was ? -0.5f * D * x * x : 0.f));
     x = xn;
     const float improvement = -(al * pMa + 0.5f * al * al * pMp + wave_sum(dc));
     a += al * p; Ma += al * Mp;
-    if (improvement * scale < tol) { it++; break; }
+    if (improvement * scale < tol || newton_next_round_is_idle(any_switched, al, improvement, scale, tol)) { it++; break; }
   }
   // row forces (touch stage) and J^T f of the block
   const float f = x < 0.f ? -D * x : 0.f;

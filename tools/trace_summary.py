@@ -1,5 +1,5 @@
-"""Per-step kernel timeline from a rocprofv3 --kernel-trace CSV: for the last N env steps (a step starts at jaco_prepare_kernel of a
-step launch set, i.e. one that is followed by jaco_physics_kernel), mean start offset and duration of every kernel in launch order,
+"""Per-step kernel timeline from a rocprofv3 --kernel-trace CSV: for the last N env steps (a step starts at the first queue kernel --
+jaco_route_kernel, or a jaco_prepare_kernel in front of it -- of a launch set that holds jaco_physics_kernel), mean start offset and duration of every kernel in launch order,
 GPU-busy time and the step period.  Usage: trace_summary.py <dir with *kernel_trace.csv> [nsteps]"""
 import csv, glob, sys, collections
 d = sys.argv[1]; nlast = int(sys.argv[2]) if len(sys.argv) > 2 else 20
@@ -13,7 +13,9 @@ light = [i for i, r in enumerate(rows) if r[2].startswith("jaco_physics_kernel")
 starts = []
 for i in light:
     j = i
-    while j > 0 and "jaco_prepare_kernel" not in rows[j][2]:
+    while j > 0 and "jaco_prepare_kernel" not in rows[j][2] and "jaco_route_kernel" not in rows[j][2]:
+        j -= 1
+    if j > 0 and "jaco_route_kernel" in rows[j][2] and "jaco_prepare_kernel" in rows[j - 1][2]:
         j -= 1
     starts.append(j)
 starts = starts[-(nlast + 1):]
