@@ -1157,11 +1157,17 @@ JDEV NewtonOut stage_newton(const JacoModelDev* m, L& s, const float (&mrow)[JNV
 #pragma unroll
   for (int q = 0; q < NR; q++) x[q] = valid[q] ? x[q] - ar[q] : 0.f;
   JSTAMP(11);
+#ifdef JACO_EMULATED
+  if (lane == 0) emu_counter[8]++;   // (CPU tests: constrained solves, and -- below -- the Hessian builds they took)
+#endif
   int it = 0, nls = 0;
   for (; it < m->iterations; it++) {
     // (lane-id predicates are recomputed inside the iteration: hoisted out of it they live as ~60 SGPR masks, spilled to VGPR lanes
     //  on entry and fetched back with two v_readlane per use -- a v_cmp at the use is one instruction)
     lane = wave_opaque_i(lane);
+#ifdef JACO_EMULATED
+    if (lane == 0) emu_counter[9]++;
+#endif
     bool coupled = false;
 #pragma unroll
     for (int q = 0; q < NR; q++) {

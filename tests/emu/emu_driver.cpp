@@ -25,8 +25,8 @@ static int g_use_hints = 0;
 static int g_obs_mode = 0;
 extern "C" void emu_set_obs_mode(int v) { g_obs_mode = v; }
 extern "C" void emu_set_hints(int on) { g_use_hints = on; }
-long emu_counter[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-extern "C" long emu_get_counter(int i, int reset) { long v = emu_counter[i & 7]; if (reset) emu_counter[i & 7] = 0; return v; }
+long emu_counter[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // (8: constrained Newton solves, 9: their Hessian builds = matrix-core passes)
+extern "C" long emu_get_counter(int i, int reset) { long v = emu_counter[i & 15]; if (reset) emu_counter[i & 15] = 0; return v; }
 static int g_no_pairlist = 0;
 static std::vector<float> g_terminal;
 extern "C" const float* emu_last_terminal() { return g_terminal.data(); }   // [nenv][2] (success, wb) latched by terminal steps

@@ -11,7 +11,7 @@
 union EmuWord { float f; int i; unsigned long long u; };
 extern EmuWord emu_x[2][64];
 extern unsigned emu_cnt[64];
-extern long emu_counter[8];   // event counters the kernel source bumps under JACO_EMULATED (0 / 1: all-pairs / list passes of the broadphase, 2: entries tested by list passes,
+extern long emu_counter[16];   // event counters the kernel source bumps under JACO_EMULATED (0 / 1: all-pairs / list passes of the broadphase, 2: entries tested by list passes,
                               // 3: MPR calls, 4: MPR hits, 5 / 6: support queries of hit / miss calls)
 
 JDEV int lane_id() { return emu_cur_lane; }
