@@ -61,6 +61,7 @@ struct JacoHandle {
   int *qlist = nullptr, *qctl = nullptr;   // both double-buffered: launch N uses lists [qsel][6 B] and control words [qsel][JQ_WORDS]
   int qsel = 0;                               // buffer of the next launch
   bool q_ready = false;                       // ... already prepared by the previous launch's routing kernel
+  int merge_prepare = 1;                      // option "merge_prepare": 0 = every launch prepares its own buffer with jaco_prepare_kernel (the launch set of rounds 1-4; comparison / regression tests)
   int* hint = nullptr;                        // [num_envs] tier the env's last step needed
   bool reset_listed = false;                  // jaco_reset in progress: h->order holds the list of the masked envs
   int* routed_mark = nullptr;                 // [num_envs] id of the launch that queued the env for a bigger tier before it started
@@ -590,7 +591,7 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
             h->workers, h->workers_heavy, h->workers_huge, qlist_other, qctl_other, h->order_ctl, io.mode);
     A.routed_mark = h->routed_mark;
   }
-  h->q_ready = routes;
+  h->q_ready = routes && h->merge_prepare;   // (the routing kernel has prepared the other buffer either way; with the option off the next launch prepares it again)
   h->qsel ^= 1;
   // The resident workers go first: their workgroups need 20 - 68 KB of LDS on one CU, and once the light grid (13 KB per workgroup,
   // 65 536 of them) has filled the chip such a hole only opens when the grid runs out -- a huge-tier env queued at t = 0 would then
@@ -853,6 +854,7 @@ extern "C" int jaco_set_option(JacoHandle* h, const char* name, double v) {
   if (!strcmp(name, "tier_return")) { h->tier_return = v != 0; return JACO_OK; }
   if (!strcmp(name, "heavy_workers")) { h->workers = v < 1 ? 1 : (int)v; return JACO_OK; }
   if (!strcmp(name, "handdown")) { h->handdown = v != 0; return JACO_OK; }
+  if (!strcmp(name, "merge_prepare")) { h->merge_prepare = v != 0; if (!h->merge_prepare) h->q_ready = false; return JACO_OK; }
   if (!strcmp(name, "auto_reset")) { h->auto_reset = v != 0; return JACO_OK; }
   if (!strcmp(name, "min_nsub_sched")) { h->min_nsub_sched = v < 1 ? 1 : (int)v; return JACO_OK; }
   if (!strcmp(name, "min_nsub_order")) { h->min_nsub_order = v < 1 ? 1 : (int)v; return JACO_OK; }

@@ -278,6 +278,46 @@ def test_launch_order_does_not_change_results():
             assert heavy > B // 200          # the hand-off path really was exercised
 
 
+def test_double_buffered_queue_state_does_not_change_results():
+    """The routing kernel of launch N prepares the queue buffer of launch N + 1 (lists back to "nothing published", counters zeroed, workers
+    sized from launch N's demand); option merge_prepare = 0 brings back the launch set in which every launch prepares its own buffer with
+    jaco_prepare_kernel.  Both must give the same states and outputs bit for bit over a sequence that mixes what flips the buffers in
+    different ways: env steps in a row (fast path), masked resets and forward passes in between (launches that do not route), ctrl-level
+    launches, at action scale 0.05 (most envs go through the tier queues every step).  Launches per step: one fewer on the fast path."""
+    from mujoco_jaco_amd.env import JacoBatchedEnv
+    B = 8192
+    outs, launches = [], []
+    for merge in (1, 0):
+        env = JacoBatchedEnv(num_envs=B, task="picking", seed=41)
+        env.sim.set_option("merge_prepare", merge)
+        env.reset()
+        gen = torch.Generator(device=env.device); gen.manual_seed(9)
+        rec = []
+        for s in range(7):
+            a = (torch.rand(B, 7, device=env.device, generator=gen) * 2 - 1) * (0.05 if s < 5 else 1.0)
+            if s == 2:
+                env.sim.launch_count()
+            obs, rew, done, _ = env.step(a)
+            if s == 2:
+                launches.append(env.sim.launch_count())
+            if s == 3:      # a masked reset (reset kernel + listed forward pass: neither routes) between two steps
+                mask = torch.zeros(B, dtype=torch.bool, device=env.device); mask[::7] = True
+                obs = obs.clone(); obs[mask] = env.reset(mask)[mask]
+            if s == 4:      # a ctrl-level launch of the sim tier on the same handle (routes too: hints are on)
+                env.sim.send_forces(torch.zeros(B, 9, device=env.device), nsub=3)
+            rec.append((obs.clone(), rew.clone(), done.clone()))
+        q, v, _ = env.sim.get_state()
+        rec.append((q.clone(), v.clone(), env.sim.flags().clone()))
+        heavy = int(((env.sim.flags() & 32) != 0).sum())
+        outs.append(rec)
+        env.close()
+    assert heavy > B // 4                                     # the queues really carried load
+    assert launches[0] == launches[1] - 1, launches           # the fast path saves the prepare launch
+    for x, y in zip(*outs):
+        for u, w in zip(x, y):
+            assert torch.equal(u, w)
+
+
 def test_execution_options():
     """Hand-down (heavy drain -> second medium drain) only changes which workgroup runs the same code: bit-identical states and
     outputs.  The start-of-step routing ("hints") changes which capacity tier's code steps a substep; the tiers group their
