@@ -791,6 +791,7 @@ JDEV void stage_collision(const JacoStepArgs& A, const JacoModelDev* m, L& s, in
     v4 sepA; sepA.x = sepA.y = sepA.z = sepA.w = 0.f;
     float* const seprow = A.sepdir ? A.sepdir + (size_t)env * (4 * JMAXPAIR) : nullptr;
     if (seprow && lane < nhere && ((codeA >> 16) & 15) != JG_PLANE && ((codeA >> 16) & 255) != (JG_BOX | (JG_BOX << 4))) sepA = ld4(seprow + 4 * pkA);
+    JSTAMP_NARROW(11);
     for (int c = 0; c < nhere;) {
       lane = wave_opaque_i(lane);   // (lane-id predicates of the narrowphase routines stay inside the loop: physics_kernel.h stage_newton)
       // contact buffer full and a bigger tier to hand the env to: the rest of the narrowphase would be thrown away with the substep
@@ -799,6 +800,7 @@ JDEV void stage_collision(const JacoStepArgs& A, const JacoModelDev* m, L& s, in
         const int run = ffs64(~(boxes >> c) | 16ull);
         collide_box_box4(m, s, c, run, pkA, codeA, m1A, m2A, obA, dimA, saA, sbA, lane, ncon, flags);
         c += run;
+        JSTAMP_NARROW(12);
         continue;
       }
       const int pk = wave_bcast_i(pkA, c), code = wave_bcast_i(codeA, c);
@@ -810,6 +812,7 @@ JDEV void stage_collision(const JacoStepArgs& A, const JacoModelDev* m, L& s, in
         if (t2 == JG_BOX) collide_plane_box(mk3(wave_bcast(sbA.x, c), wave_bcast(sbA.y, c), wave_bcast(sbA.z, c)), s, g1, g2, pk, lane, ncon, flags);
         else if (t2 == JG_SPHERE) collide_plane_sphere(m, s, g1, g2, pk, lane, ncon, flags);
         else if (t2 == JG_MESH) collide_plane_convex(A, m, s, g1, g2, t2, pk, lane, ncon, flags);
+        JSTAMP_NARROW(13);
       } else {
         float depth;
         v3 dir, pos;
@@ -843,6 +846,7 @@ JDEV void stage_collision(const JacoStepArgs& A, const JacoModelDev* m, L& s, in
         if (lane == 0) printf("mpr g1 %d g2 %d hit %d depth %g\n", g1, g2, (int)hit, hit ? depth : 0.f);
 #endif
         push_contacts(s, hit && lane == 0, -depth, pos, dir, pk, ncon, flags, 1);
+        JSTAMP_NARROW(hit ? 14 : 1);
       }
       if (ncon > before) {   // dof chain masks / body ids of the two geoms, for the row builder and the touch stage
         int cc = before + lane;

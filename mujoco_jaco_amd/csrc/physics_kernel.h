@@ -105,6 +105,16 @@ JDEV void jprof_stamp(JProfCtx& pc, int i, int lane) {
 #else
 #define JSTAMP(i)
 #endif
+// -DJACO_NARROW_PROFILE (with JACO_PROFILE_STAGES; tools/gpu_stage_profile.py --narrow): the narrowphase split by what it ran -- slot 11 candidate
+// records (L2 round trip), 12 box-box, 13 plane-*, 14 MPR hits, 1 MPR misses incl. the cached-direction test; the Newton solver's four intervals,
+// the usual owners of 11 .. 14, all go to slot 6 in such a build
+#ifdef JACO_NARROW_PROFILE
+#define JSTAMP_NEWTON(i) JSTAMP(6)
+#define JSTAMP_NARROW(i) JSTAMP(i)
+#else
+#define JSTAMP_NEWTON(i) JSTAMP(i)
+#define JSTAMP_NARROW(i)
+#endif
 
 struct JacoStepArgs {
   const JacoModelDev* model;
@@ -1156,7 +1166,7 @@ JDEV NewtonOut stage_newton(const JacoModelDev* m, L& s, const float (&mrow)[JNV
   rows_dot<NR>(s.J, jrow, a, lane, ne, nv, x);
 #pragma unroll
   for (int q = 0; q < NR; q++) x[q] = valid[q] ? x[q] - ar[q] : 0.f;
-  JSTAMP(11);
+  JSTAMP_NEWTON(11);
 #ifdef JACO_EMULATED
   if (lane == 0) emu_counter[8]++;   // (CPU tests: constrained solves, and -- below -- the Hessian builds they took)
 #endif
@@ -1207,7 +1217,7 @@ JDEV NewtonOut stage_newton(const JacoModelDev* m, L& s, const float (&mrow)[JNV
 #pragma unroll
         for (int u = 0; u < 4; u++) wave_mfma_16x16x4(jv[u], wv[u] * jv[u], C);
       }
-      JSTAMP(12);
+      JSTAMP_NEWTON(12);
       // symmetric tile: H[jd][c] = C[c][jd] sits in lane jd + 16 * (c >> 2), register c & 3 (jd = this lane's dof - JB0)
       const int jd = (lane >= JB0 && lane < JNV) ? lane - JB0 : 0;
 #pragma unroll
@@ -1236,7 +1246,7 @@ JDEV NewtonOut stage_newton(const JacoModelDev* m, L& s, const float (&mrow)[JNV
 #pragma unroll
       for (int u = 0; u < 4; u++) wave_mfma_32x32x2(jv[u], wv[u] * jv[u], C);
     }
-    JSTAMP(12);
+    JSTAMP_NEWTON(12);
     // C is symmetric: row j of the tile, column `lane`, is where lane `lane` finds H[lane][j]
 #pragma unroll
     for (int j2 = 0; j2 < JNV; j2++) {
@@ -1254,7 +1264,7 @@ JDEV NewtonOut stage_newton(const JacoModelDev* m, L& s, const float (&mrow)[JNV
     // the pedestal) when the arm block carries no row, else all 21
     float p = !full ? ldl_solve_blocks(h, -grad, lane, rowblocks) : ((rowblocks & 1) == 0 ? ldl_block<JB0, JNV>(h, -grad, lane) : ldl_solve<true>(h, -grad, lane));
     p = lane < nv ? p : 0.f;
-    JSTAMP(13);
+    JSTAMP_NEWTON(13);
     // exact line search on phi(al) = cost(a + al p)
     float Mp = mat_vec(mrow, p);
     float pMp, pMa;
@@ -1306,7 +1316,7 @@ JDEV NewtonOut stage_newton(const JacoModelDev* m, L& s, const float (&mrow)[JNV
     }
     const bool any_switched = wave_ballot(switched) != 0ull;
     float improvement = -(al * pMa + 0.5f * al * al * pMp + wave_sum(dc));
-    JSTAMP(14);
+    JSTAMP_NEWTON(14);
     a += al * p; Ma += al * Mp;
     if (improvement * scale < tol || newton_next_round_is_idle(any_switched, al, improvement, scale, tol)) { it++; break; }
   }
@@ -1430,7 +1440,7 @@ JDEV NewtonOut stage_newton_w(const JacoModelDev* m, L& s, const float (&mrow)[J
   rows_dot_w<NR>(s, w, con, a, lane, nv, ncon, x);
 #pragma unroll
   for (int q = 0; q < NR; q++) x[q] = valid[q] ? x[q] - ar[q] : 0.f;
-  JSTAMP(11);
+  JSTAMP_NEWTON(11);
   // the dof columns of the matrix-core pass: lane -> column lane & 31 of the 32 x 32 tile, or dof JB0 + (lane & 15) of the 16 x 16 one
   const bool small_tile = (rowblocks & 1) == 0;
   const int col = small_tile ? (lane & 15) : (lane & 31);
@@ -1469,7 +1479,7 @@ JDEV NewtonOut stage_newton_w(const JacoModelDev* m, L& s, const float (&mrow)[J
 #pragma unroll
         for (int u = 0; u < 4; u++) wave_mfma_16x16x4(jv[u], wv[u] * jv[u], C);
       }
-      JSTAMP(12);
+      JSTAMP_NEWTON(12);
       const int jd = (lane >= JB0 && lane < JNV) ? lane - JB0 : 0;
 #pragma unroll
       for (int j2 = 0; j2 < JNV; j2++) {
@@ -1495,7 +1505,7 @@ JDEV NewtonOut stage_newton_w(const JacoModelDev* m, L& s, const float (&mrow)[J
 #pragma unroll
         for (int u = 0; u < 4; u++) wave_mfma_32x32x2(jv[u], wv[u] * jv[u], C);
       }
-      JSTAMP(12);
+      JSTAMP_NEWTON(12);
 #pragma unroll
       for (int j2 = 0; j2 < JNV; j2++) {
         const int reg = (j2 & 3) + 4 * (j2 >> 3);
@@ -1509,7 +1519,7 @@ JDEV NewtonOut stage_newton_w(const JacoModelDev* m, L& s, const float (&mrow)[J
     if (gn * scale < tol) break;
     float p = !full ? ldl_solve_blocks(h, -grad, lane, rowblocks) : ((rowblocks & 1) == 0 ? ldl_block<JB0, JNV>(h, -grad, lane) : ldl_solve<true>(h, -grad, lane));
     p = lane < nv ? p : 0.f;
-    JSTAMP(13);
+    JSTAMP_NEWTON(13);
     float Mp = mat_vec(mrow, p);
     float pMp, pMa;
     wave_sum2(p * Mp, p * Ma, &pMp, &pMa);
@@ -1551,7 +1561,7 @@ JDEV NewtonOut stage_newton_w(const JacoModelDev* m, L& s, const float (&mrow)[J
     }
     const bool any_switched = wave_ballot(switched) != 0ull;
     float improvement = -(al * pMa + 0.5f * al * al * pMp + wave_sum(dc));
-    JSTAMP(14);
+    JSTAMP_NEWTON(14);
     a += al * p; Ma += al * Mp;
     if (improvement * scale < tol || newton_next_round_is_idle(any_switched, al, improvement, scale, tol)) { it++; break; }
   }

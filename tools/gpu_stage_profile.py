@@ -66,6 +66,9 @@ else:
 env._chk(env.L.jaco_stage_profile(env.h, prof.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), 1))
 names = ["walk", "geoms+inertia", "accum+mass+act", "limit rows", "collision: narrowphase", "contact rows", "newton: rest (start, qacc_smooth, final)", "touch",
          "euler+integrate", "collision: spheres", "collision: OBB cull", "newton: prologue (M rows, qacc_smooth, start point)", "newton: MFMA H build", "newton: H fetch+LDL", "newton: line search", "OSC (env level only)"]
+if "--narrow" in sys.argv:   # a -DJACO_NARROW_PROFILE build of the diagnostic twin (JACO_ENV_LIB names it): the narrowphase by what it ran
+    names[11], names[12], names[13], names[14], names[1] = "narrow: candidate records", "narrow: box-box", "narrow: plane-*", "narrow: MPR hits", "narrow: MPR misses + cached-direction tests"
+    names[6] = "newton: everything"; names[4] = "narrow: rest (bookkeeping, tail)"
 per = prof[:, :16].astype(np.float64) / nsub
 print("B", B, "nsub", nsub, "substeps/s %.3g" % (B * nsub / dt), "flags", int(env.flags().max()))
 st = env.stats().cpu().numpy()
