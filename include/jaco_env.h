@@ -181,13 +181,15 @@ int jaco_set_frame_skip(JacoHandle* h, int frame_skip);
  * jaco_reset(done mask); honoured for the tasks whose reset is draws + forward pass (picking, reaching, pickAndplace).
  * Setting a model option (everything in this first group except "disable_contact") SYNCHRONISES the device before the model
  * constants are re-uploaded: it is the one entry point besides the *_debug / *_time_ms hooks that does.
- * Execution options ("schedule", "concurrent_heavy", "heavy_workers", "handdown": bit-identical results; "hints" / "tier_return" pick which
+ * Execution options ("schedule", "concurrent_heavy", "heavy_workers", "handdown", "merge_prepare": bit-identical results; "hints" / "tier_return" pick which
  * capacity tier's code steps a substep, and the tiers group their row sums differently: results agree to fp32 rounding): "schedule" (1: launch expensive envs first), "concurrent_heavy" (1: medium / heavy / huge
  * tier workgroups resident next to the light grid), "heavy_workers" (maximum of the medium tier's; the resident number follows the
  * previous step's hand-overs), "tier_return" (1: a bigger tier gives an env back once its overflow is over), "hints" (where an env
  * starts its next step: 0 always the light tier, 1 the biggest tier its last step needed, 2 (default) the tier its last substep
  * needed), "handdown" (1, default: the first heavy drain passes calmed-down envs to a second medium drain instead of keeping them
- * for the rest of the step). */
+ * for the rest of the step), "merge_prepare" (1, default: a step's routing kernel also prepares the tier queues of the NEXT launch --
+ * the queue state is double-buffered -- so that steps in a row start with one small kernel; 0: every launch prepares its own queues
+ * with a kernel of its own; bit-identical results). */
 int jaco_set_option(JacoHandle* h, const char* name, double value);
 
 /* Test hook: like jaco_physics_step but also copies the stage dump of environment `env` taken in
