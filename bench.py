@@ -133,6 +133,7 @@ def small_action_runs(args):
                "--batch", str(args.batch), "--model", args.model, "--task", args.task, "--no-cpu-baseline", "--extra-scales", "", "--policy-leg", "", "--config-legs", ""]
         if args.frame_skip is not None:
             cmd += ["--frame-skip", str(args.frame_skip)]
+        cmd += [x for kv in args.set_option for x in ("--set-option", kv)]   # (library options follow into the side legs: A/B runs)
         try:
             p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
             line = json.loads(p.stdout.strip().splitlines()[-1])
@@ -153,6 +154,7 @@ def policy_run(args):
            "--preroll", "180", "--batch", str(args.batch), "--model", args.model, "--no-cpu-baseline", "--extra-scales", "", "--policy-leg", "", "--config-legs", ""]
     if args.frame_skip is not None:
         cmd += ["--frame-skip", str(args.frame_skip)]
+    cmd += [x for kv in args.set_option for x in ("--set-option", kv)]   # (library options follow into the side legs: A/B runs)
     try:
         p = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
         line = json.loads(p.stdout.strip().splitlines()[-1])
@@ -177,7 +179,7 @@ def config_legs(args):
         if c not in legs:
             continue
         try:
-            p = subprocess.run([sys.executable, os.path.abspath(__file__)] + legs[c] + common, capture_output=True, text=True, timeout=600)
+            p = subprocess.run([sys.executable, os.path.abspath(__file__)] + legs[c] + common + [x for kv in args.set_option for x in ("--set-option", kv)], capture_output=True, text=True, timeout=600)
             line = json.loads(p.stdout.strip().splitlines()[-1])
             LEG_FLAGS["config%s" % c] = leg_flags(line)
             out["config%s" % c] = {"env_steps_per_s": line["value"], "ms_per_step": line["ms_per_step"], "kernel_ms": line["roofline"]["kernel_ms"],

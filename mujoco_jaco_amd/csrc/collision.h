@@ -604,6 +604,154 @@ JDEV bool mpr_penetration(const JacoStepArgs& A, const JacoModelDev* m, const Mp
 }
 #endif
 
+// ---------------------------------------------------------------- MPR, two pairs side by side -- built, measured, NOT shipped (-DJACO_MPR_PAIRS=1)
+// Measured on MI355X (round 5, profiles/r05_ab_variants.txt item 8): bit-identical results, and no gain -- policy-driven 1.378 / 1.382 M without, 1.379 / 1.370 M with
+// the option on the same build -- while the mere presence of the code (scratch 288 -> 348 B per lane in the light kernel: the narrowphase is the register
+// hot spot) costs the headline 2.4 % (1.90 -> 1.855 M).  Kept as a build option with its emulator test (tests/test_kernel_emu.py, on-demand build).
+#ifndef JACO_MPR_PAIRS
+#define JACO_MPR_PAIRS 0
+#endif
+#if JACO_MPR_PAIRS
+// Everything MPR computes between two support queries is the same handful of 3-vector operations in every lane; the 64 lanes only matter inside a
+// query, where they hold the 64 candidate vertices of a hull's support-table cell.  Under the shipped policy a grasping env runs ~6 hull pairs
+// through MPR per substep, ~10 queries and portal steps each -- half of its substep.  Here TWO candidates go through the routine at once, one per
+// half wave: lanes 0..31 carry pair A's geoms, portal and direction, lanes 32..63 pair B's (no register more than before: the "uniform" values simply
+// differ between the halves); a lane holds TWO table slots (l and l + 32 of its pair's cell), the maximum is taken inside the half (DPP row
+// maximum + one exchange with the neighbouring row).  The control flow is mpr_penetration's state machine with the phase as a per-lane value:
+// every pass of the loop makes one query for both halves, then each half takes its own step.  Per pair the arithmetic, its order and the
+// tie-breaking (lowest vertex index) are those of the one-pair routine: results are bit-identical (tests: test_mpr_pairs_*).
+// Eligible: candidates whose hull meshes all have a support table (every finger / hand / link hull; the 1 511-vertex base mesh is scanned).
+// support point of one geom (per-half values G, l) in its local frame; hulls: table cell of the half's direction, two slots per lane
+JDEV v3 support_half(const JacoStepArgs& A, const MprGeom& G, v3 l, int lane, bool anyhull) {
+  v3 sp = support_prim(G, l);
+  if (anyhull) {   // (wave-uniform: some half's geom is a hull; the other half loads a cell of the table's first row for nothing)
+    const bool hull = G.cellR > 0;
+    const int gl = lane & 31, gb = lane & 32;
+    const float* row = A.hull + 4 * ((size_t)(hull ? G.celladr : 0) + (size_t)(hull ? cube_cell(l, G.cellR) : 0) * 64);
+    const v4 ea = ld4(row + 4 * gl), eb = ld4(row + 4 * (gl + 32));
+    const int ida = __builtin_bit_cast(int, ea.w), idb = __builtin_bit_cast(int, eb.w);
+    const float ta = (hull && ida >= 0) ? ea.x * l.x + ea.y * l.y + ea.z * l.z : -3.0e38f;
+    const float tb = (hull && idb >= 0) ? eb.x * l.x + eb.y * l.y + eb.z * l.z : -3.0e38f;
+    const bool useb = tb > ta;   // (slots are in vertex-index order: on a tie the lower slot stays)
+    const float best = useb ? tb : ta;
+    const bool have = hull && (useb ? idb : ida) >= 0;
+    const v3 c = useb ? mk3(eb.x, eb.y, eb.z) : mk3(ea.x, ea.y, ea.z);
+    const float bv = half_max(best);
+    const bool cand = have && best == bv;
+    // lowest slot among the maxima: the lower 32 slots (held as `a`) before the upper 32
+    const unsigned ma = (unsigned)(wave_ballot(cand && !useb) >> gb), mb = (unsigned)(wave_ballot(cand && useb) >> gb);
+    const unsigned mm = ma ? ma : mb;
+    const int wl = gb + (mm ? ffs64((unsigned long long)mm) : 0);   // (no lane matches for a non-finite direction: the half's first lane)
+    const v3 w = mk3(wave_shfl(c.x, wl), wave_shfl(c.y, wl), wave_shfl(c.z, wl));
+    if (hull) sp = w;
+  }
+  return sp;
+}
+JDEV Sup mpr_support_half(const JacoStepArgs& A, const MprGeom& G1, const MprGeom& G2, v3 dir, int lane, bool anyhull1, bool anyhull2) {
+  const v3 l1 = mulT(G1.P.R, dir), l2 = mulT(G2.P.R, -dir);
+  const v3 sp1 = support_half(A, G1, l1, lane, anyhull1), sp2 = support_half(A, G2, l2, lane, anyhull2);
+  Sup r;
+  r.v1 = G1.P.p + mul(G1.P.R, sp1);
+  r.v = r.v1 - (G2.P.p + mul(G2.P.R, sp2));
+  return r;
+}
+// Per half: the cached-direction test (sepd.w != 0: one query along the cached direction; apart -> nothing to do) and, if that does not settle it,
+// mpr_penetration's state machine.  `active`: the half has a pair at all.  Outputs are per-half values: hit / depth / dir / pos as mpr_penetration's,
+// ran = MPR itself was run (the caller then stores sep / sepvalid in the pair's cache entry, as the one-pair path does).
+JDEV void mpr_pair2(const JacoStepArgs& A, const JacoModelDev* m, const MprGeom& G1, const MprGeom& G2, v4 sepd, bool active, int lane,
+                    bool* hit_out, float* depth, v3* dirout, v3* pos, v3* sep, bool* sepvalid, bool* ran_out) {
+  const bool anyhull1 = wave_ballot(G1.cellR > 0) != 0ull, anyhull2 = wave_ballot(G2.cellR > 0) != 0ull;
+  const float tol = m->mpr_tolerance;
+  const int maxit = m->mpr_iterations;
+  Sup p0, p1, p2, p3;
+  p0.v1 = G1.P.p; p0.v = p0.v1 - G2.P.p;
+  if (norm(p0.v) < 1e-9f) p0.v.x = 1e-5f;
+  p1 = p0; p2 = p0; p3 = p0;
+  enum { DONE = 9 };
+  int phase = !active ? DONE : (sepd.w != 0.f ? -1 : 0), it = 0;
+  v3 dr = phase == -1 ? mk3(sepd.x, sepd.y, sepd.z) : normalized(-p0.v);
+  bool hit = false, ran = active && phase == 0, sv = false;
+  v3 sp = mk3(0.f, 0.f, 0.f);
+  *depth = 0.f; *dirout = mk3(0.f, 0.f, 1.f); *pos = mk3(0.f, 0.f, 0.f);
+#ifdef JACO_EMULATED
+  int nq = 0;   // (CPU diagnostics: support queries of this half's pair, tools/mpr_query_stats.py)
+#endif
+  while (wave_ballot(phase != DONE) != 0ull) {
+    if (phase == 2 && it > 100) phase = DONE;
+#ifdef JACO_EMULATED
+    if (phase != DONE) nq++;
+#endif
+    const Sup q = mpr_support_half(A, G1, G2, dr, lane, anyhull1, anyhull2);   // (every lane, every pass: the one place with cross-lane traffic)
+    const float qd = dot(q.v, dr);
+    if (phase == -1) {
+      const bool apart = qd < -1e-5f && fabsf(dot(dr, dr) - 1.f) < 1e-3f;
+      if (apart) phase = DONE;
+      else { phase = 0; ran = true; dr = normalized(-p0.v); }
+    } else if (phase == 0) {
+      p1 = q;
+      if (qd <= 0.f) { sp = dr; sv = true; phase = DONE; }
+      else {
+        dr = cross(p0.v, p1.v);
+        if (norm(dr) < 1e-9f) {
+          *depth = norm(p1.v); *dirout = normalized(p1.v); *pos = p1.v1 - p1.v * 0.5f;
+          hit = true; phase = DONE;
+        } else { dr = normalized(dr); phase = 1; }
+      }
+    } else if (phase == 1) {
+      p2 = q;
+      if (qd <= 0.f) { sp = dr; sv = true; phase = DONE; }
+      else {
+        dr = normalized(cross(p1.v - p0.v, p2.v - p0.v));
+        if (dot(dr, p0.v) > 0.f) { Sup t = p1; p1 = p2; p2 = t; dr = -dr; }
+        phase = 2; it = 0;
+      }
+    } else if (phase == 2) {
+      p3 = q;
+      if (qd <= 0.f) { sp = dr; sv = true; phase = DONE; }
+      else {
+        bool cont = false;
+        if (dot(cross(p1.v, p3.v), p0.v) < -1e-11f) { p2 = p3; cont = true; }
+        if (!cont && dot(cross(p3.v, p2.v), p0.v) < -1e-11f) { p1 = p3; cont = true; }
+        if (cont) { dr = normalized(cross(p1.v - p0.v, p2.v - p0.v)); it++; }
+        else {
+          dr = portal_dir(p1, p2, p3);
+          phase = dot(dr, p1.v) >= 0.f ? 4 : 3; it = 0;
+        }
+      }
+    } else if (phase == 3) {
+      if (qd < 0.f) { sp = dr; sv = true; phase = DONE; }
+      else if (reach_tol(p1, p2, p3, q, dr, tol) || it > maxit) phase = DONE;
+      else {
+        expand_portal(p0, p1, p2, p3, q);
+        dr = portal_dir(p1, p2, p3);
+        it++;
+        if (dot(dr, p1.v) >= 0.f) { phase = 4; it = 0; }
+      }
+    } else if (phase == 4) {
+      if (reach_tol(p1, p2, p3, q, dr, tol) || it > maxit) {
+        if (m->mpr_output == 1) { *dirout = dr; *depth = qd; }
+        else {
+          v3 cp;
+          *depth = point_tri_closest(p1.v, p2.v, p3.v, &cp);
+          *dirout = *depth < 1e-10f ? dr : normalized(cp);
+        }
+        *pos = mpr_find_pos(p0, p1, p2, p3);
+        hit = true; phase = DONE;
+      } else {
+        expand_portal(p0, p1, p2, p3, q);
+        dr = portal_dir(p1, p2, p3);
+        it++;
+      }
+    }
+  }
+  *hit_out = hit; *sep = sp; *sepvalid = sv; *ran_out = ran;
+#ifdef JACO_EMULATED
+  if ((lane & 31) == 0 && active) { emu_counter[7] += nq; emu_counter[hit ? 5 : 6] += nq; }
+#endif
+}
+
+#endif   // JACO_MPR_PAIRS
+
 // ---------------------------------------------------------------- stage C
 // Pair list of the bounding-sphere phase (temporal coherence across the substeps of a launch).  Geoms move well under a
 // millimetre per 1 ms substep, yet the phase used to test all ~720 whitelisted pairs every substep.  A full pass now also lists,
@@ -783,6 +931,8 @@ JDEV void stage_collision(const JacoStepArgs& A, const JacoModelDev* m, L& s, in
     const unsigned m1A = m->pair[pkA].m1, m2A = m->pair[pkA].m2;
     const int obA = m->pair[pkA].ob, dimA = m->pair[pkA].condim;
     const unsigned long long boxes = wave_ballot(lane < nhere && ((codeA >> 16) & 255) == (JG_BOX | (JG_BOX << 4)));
+    // candidates that go through MPR (neither plane-* nor box-box): two in a row can share a wave (mpr_pair2)
+    const unsigned long long hullc = wave_ballot(lane < nhere && ((codeA >> 16) & 15) != JG_PLANE && ((codeA >> 16) & 255) != (JG_BOX | (JG_BOX << 4)));
     // Separating directions (hull pairs).  A pair that MPR found apart ended on a direction d with  max over (G1 - G2) of x . d <= 0; as
     // long as one support query along the cached d still gives < -10 um the geoms are provably apart and MPR -- which would say the same
     // after ~5 queries -- is not run.  Per (env, pair) one float4 in global memory (w = 1: valid), fetched here with the pair records; any
@@ -792,6 +942,54 @@ JDEV void stage_collision(const JacoStepArgs& A, const JacoModelDev* m, L& s, in
     float* const seprow = A.sepdir ? A.sepdir + (size_t)env * (4 * JMAXPAIR) : nullptr;
     if (seprow && lane < nhere && ((codeA >> 16) & 15) != JG_PLANE && ((codeA >> 16) & 255) != (JG_BOX | (JG_BOX << 4))) sepA = ld4(seprow + 4 * pkA);
     JSTAMP_NARROW(11);
+#if JACO_MPR_PAIRS
+    // Hull candidates, two at a time (option "mpr_pairs"; mpr_pair2): the finger hulls' pairs with the object sit between box-box pairs of the finger
+    // pads in candidate order, so they are run up front, one per half wave, and their results parked -- 8 floats per candidate in the early stages'
+    // scratch area, dead since the pair list was dealt out -- for the in-order loop below, which appends the contacts exactly where the one-pair path
+    // would have.  An odd one out (and every candidate when fewer than two are eligible) takes the one-pair path there.
+    float* const stash = s.early_scratch;   // [64][8]: hit, depth, pos, dir
+    static_assert(JSCRATCH >= 512, "MPR result stash");
+    unsigned long long parked = 0ull;
+    if (A.mpr_pairs && popc64(hullc) >= 2) {
+      // (eligible: every hull mesh of the pair has its support table -- all but the 1 511-vertex base mesh, which is scanned)
+      const int gA1 = codeA & 255, gA2 = (codeA >> 8) & 255;
+      const bool okA = lane < nhere && !((((codeA >> 16) & 15) == JG_MESH && m->g_cellR[gA1] == 0) || (((codeA >> 20) & 15) == JG_MESH && m->g_cellR[gA2] == 0));
+      unsigned long long todo = hullc & wave_ballot(okA);
+      while (popc64(todo) >= 2) {
+        lane = wave_opaque_i(lane);
+        const int c1 = ffs64(todo); todo &= todo - 1ull;
+        const int c2 = ffs64(todo); todo &= todo - 1ull;
+        const int cc = lane < 32 ? c1 : c2;
+        const int pk2 = wave_shfl_i(pkA, cc), code2 = wave_shfl_i(codeA, cc);
+        const MprGeom H1 = mpr_geom(m, s, code2 & 255, (code2 >> 16) & 15), H2 = mpr_geom(m, s, (code2 >> 8) & 255, (code2 >> 20) & 15);
+        v4 sd; sd.x = wave_shfl(sepA.x, cc); sd.y = wave_shfl(sepA.y, cc); sd.z = wave_shfl(sepA.z, cc); sd.w = wave_shfl(sepA.w, cc);
+        bool hit2, sv2, ran2;
+        float depth2;
+        v3 dir2, pos2, sep2;
+        mpr_pair2(A, m, H1, H2, sd, true, lane, &hit2, &depth2, &dir2, &pos2, &sep2, &sv2, &ran2);
+        if ((lane & 31) == 0) {
+          if (seprow && ran2 && (sv2 || sd.w != 0.f)) {
+            v4 o; o.x = sep2.x; o.y = sep2.y; o.z = sep2.z; o.w = sv2 ? 1.f : 0.f;
+            *reinterpret_cast<v4*>(seprow + 4 * pk2) = o;
+          }
+          float* st = stash + 8 * cc;
+          st[0] = hit2 ? 1.f : 0.f; st[1] = depth2; st[2] = pos2.x; st[3] = pos2.y; st[4] = pos2.z; st[5] = dir2.x; st[6] = dir2.y; st[7] = dir2.z;
+#ifdef JACO_EMULATED
+          emu_counter[3]++; emu_counter[4] += hit2;
+#endif
+        }
+#ifdef JACO_EMULATED
+        if (lane == 0) emu_counter[10]++;
+#endif
+        parked |= (1ull << c1) | (1ull << c2);
+      }
+      wave_sync();   // the parked results are visible
+      JSTAMP_NARROW(14);
+    }
+#else
+    const unsigned long long parked = 0ull;
+    (void)hullc;
+#endif
     for (int c = 0; c < nhere;) {
       lane = wave_opaque_i(lane);   // (lane-id predicates of the narrowphase routines stay inside the loop: physics_kernel.h stage_newton)
       // contact buffer full and a bigger tier to hand the env to: the rest of the narrowphase would be thrown away with the substep
@@ -827,6 +1025,13 @@ JDEV void stage_collision(const JacoStepArgs& A, const JacoModelDev* m, L& s, in
         const float sw = wave_bcast(sepA.w, c);
         bool hit = false, apart = false, sepvalid = false;
         v3 sep = mk3(0.f, 0.f, 0.f);
+#if JACO_MPR_PAIRS
+        if ((parked >> c) & 1ull) {   // run up front by the two-pair routine: the result is parked
+          const float* st = stash + 8 * c;
+          hit = st[0] != 0.f; depth = st[1]; pos = mk3(st[2], st[3], st[4]); dir = mk3(st[5], st[6], st[7]);
+          apart = true;
+        } else
+#endif
         if (sw != 0.f) {   // (wave-uniform)
           const v3 d = mk3(wave_bcast(sepA.x, c), wave_bcast(sepA.y, c), wave_bcast(sepA.z, c));
           const Sup q = mpr_support(A, G1, G2, d, lane JROWPASS);
@@ -840,7 +1045,7 @@ JDEV void stage_collision(const JacoStepArgs& A, const JacoModelDev* m, L& s, in
           }
         }
 #ifdef JACO_EMULATED
-        if (lane == 0) { emu_counter[3]++; emu_counter[4] += hit; emu_counter[hit ? 5 : 6] += emu_counter[7] - q0_; }   // (CPU diagnostics: tools/mpr_query_stats.py)
+        if (lane == 0 && !((parked >> c) & 1ull)) { emu_counter[3]++; emu_counter[4] += hit; emu_counter[hit ? 5 : 6] += emu_counter[7] - q0_; }   // (CPU diagnostics: tools/mpr_query_stats.py)
 #endif
 #ifdef JACO_TRACE_MPR
         if (lane == 0) printf("mpr g1 %d g2 %d hit %d depth %g\n", g1, g2, (int)hit, hit ? depth : 0.f);

@@ -79,6 +79,14 @@ JDEV float wave_max(float v) {
   return fmaxf(fmaxf(wave_bcast(v, 0), wave_bcast(v, 16)), fmaxf(wave_bcast(v, 32), wave_bcast(v, 48)));
 }
 JDEV float wave_min(float v) { return -wave_max(-v); }
+// maximum over the lane's own 32-lane half, in every lane (row butterflies, then one exchange with the neighbouring row)
+JDEV float half_max(float v) {
+  v = fmaxf(v, dpp_f<0xB1>(v));
+  v = fmaxf(v, dpp_f<0x4E>(v));
+  v = fmaxf(v, dpp_f<0x141>(v));
+  v = fmaxf(v, dpp_f<0x140>(v));
+  return fmaxf(v, wave_shfl(v, lane_id() ^ 16));
+}
 
 // argmax with lowest-index tie-break; returns the winning index in all lanes, *best gets the value.
 #define JACO_ARGMAX_STEP(CTRL)                              \

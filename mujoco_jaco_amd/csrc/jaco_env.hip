@@ -71,6 +71,7 @@ struct JacoHandle {
   int pair_list = 1;   // option "pair_list"
   float* sepdir = nullptr;   // [num_envs][JMAXPAIR][4] separating-direction cache of the hull narrowphase (collision.h)
   int sep_cache = 1;         // option "sep_cache"
+  int mpr_pairs = JACO_MPR_PAIRS;   // option "mpr_pairs" (libraries built with -DJACO_MPR_PAIRS=1 only): hull candidates go through MPR two at a time, one per half wave (collision.h mpr_pair2); bit-identical results
   int arm_kernel = 1;        // option "arm_kernel": contact-free steps use the contact-free instantiation (0: the general kernel with its runtime flag, comparison)
   int concurrent = 1, workers = 1024, workers_heavy = 256, workers_huge = 32, tier_return = 1, use_hints = 2, handdown = 1;   // options "concurrent_heavy", "heavy_workers", "hints"
   float *task_rows = nullptr, *cache = nullptr;
@@ -526,7 +527,7 @@ static int launch_step(JacoHandle* h, const float* ctrl, int nsub, hipStream_t s
     HIPCHK(h, hipMalloc(&h->sepdir, bytes));
     HIPCHK(h, hipMemsetAsync(h->sepdir, 0, bytes, st));   // (entries are re-validated by a support query before use: zeros are "no direction known")
   }
-  A.disable_contact = h->disable_contact; A.no_pairlist = !h->pair_list; A.sepdir = h->sep_cache ? h->sepdir : nullptr; A.no_tier_return = !h->tier_return; A.dbg = dbg; A.dbg_env = dbg_env; A.prof = h->prof;
+  A.disable_contact = h->disable_contact; A.no_pairlist = !h->pair_list; A.mpr_pairs = h->mpr_pairs; A.sepdir = h->sep_cache ? h->sepdir : nullptr; A.no_tier_return = !h->tier_return; A.dbg = dbg; A.dbg_env = dbg_env; A.prof = h->prof;
   // this launch's queue buffer (lists + control words) and the other one: the previous launch's, and the next launch's
   int* const qctl = h->qctl + h->qsel * JQ_WORDS;
   int* const qctl_other = h->qctl + (h->qsel ^ 1) * JQ_WORDS;
@@ -848,6 +849,10 @@ extern "C" int jaco_set_option(JacoHandle* h, const char* name, double v) {
   if (!strcmp(name, "disable_contact")) { h->disable_contact = v != 0; return JACO_OK; }
   if (!strcmp(name, "pair_list")) { h->pair_list = v != 0; return JACO_OK; }
   if (!strcmp(name, "sep_cache")) { h->sep_cache = v != 0; return JACO_OK; }
+  if (!strcmp(name, "mpr_pairs")) {   // (an A/B build option of the kernel: collision.h JACO_MPR_PAIRS)
+    if (!JACO_MPR_PAIRS && v != 0) { h->err = "jaco_set_option: mpr_pairs needs a library built with -DJACO_MPR_PAIRS=1"; return JACO_EINVAL; }
+    h->mpr_pairs = v != 0; return JACO_OK;
+  }
   if (!strcmp(name, "arm_kernel")) { h->arm_kernel = v != 0; return JACO_OK; }
   if (!strcmp(name, "schedule")) { h->schedule = v != 0; return JACO_OK; }
   if (!strcmp(name, "concurrent_heavy")) { h->concurrent = v != 0; return JACO_OK; }

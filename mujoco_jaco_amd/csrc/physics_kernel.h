@@ -145,6 +145,7 @@ struct JacoStepArgs {
   int* hint;           // [nenv] highest tier (0..3) the env's last step really needed, or nullptr: where its next step starts
   int nenv, nsub, disable_contact;
   int no_pairlist;     // 1: the bounding-sphere phase tests every pair in every substep (option "pair_list" = 0: comparison runs)
+  int mpr_pairs;       // 1: two hull candidates in a row go through MPR side by side, one per half wave (option "mpr_pairs"; collision.h mpr_pair2)
   float* sepdir;       // [nenv][JMAXPAIR][4] cached separating direction of every hull pair (collision.h), or nullptr (option "sep_cache" = 0)
   int handdown;        // 1: a heavy-tier workgroup (4 per CU) passes an env that has calmed down on to the medium queue instead of running the
                        //    medium / light code itself for the rest of the step (first heavy drain only: a second medium drain follows it)

@@ -33,6 +33,8 @@ extern "C" const float* emu_last_terminal() { return g_terminal.data(); }   // [
 static int g_sep_cache = 1;
 static std::vector<float> g_sepdir;
 extern "C" void emu_set_sep_cache(int on) { g_sep_cache = on; g_sepdir.clear(); }   // 0: every hull pair goes through MPR (option "sep_cache" = 0); either call empties the cache
+static int g_mpr_pairs = 1;
+extern "C" void emu_set_mpr_pairs(int on) { g_mpr_pairs = on; }   // option "mpr_pairs" of the library (counter 10: passes of the two-pair routine)
 extern "C" void emu_set_pair_list(int on) { g_no_pairlist = !on; }   // 0: every pair tested in every substep (option "pair_list" = 0 of the library)
 static int g_handdown = 0, g_handed_down = 0;
 extern "C" void emu_set_handdown(int on) { g_handdown = on; }
@@ -40,6 +42,7 @@ extern "C" int emu_handed_down() { return g_handed_down; }   // envs passed from
 static int emu_launch(JacoStepArgs A, int* heavy_envs) {
   A.no_tier_return = g_no_tier_return_fwd();
   A.no_pairlist = g_no_pairlist;
+  A.mpr_pairs = g_mpr_pairs;
   if (g_sepdir.size() != (size_t)A.nenv * JMAXPAIR * 4) g_sepdir.assign((size_t)A.nenv * JMAXPAIR * 4, 0.f);
   A.sepdir = g_sep_cache ? g_sepdir.data() : nullptr;
   if (g_terminal.size() != (size_t)A.nenv * 2) g_terminal.assign((size_t)A.nenv * 2, 0.f);

@@ -79,6 +79,14 @@ JDEV float wave_max(float v) {
   return m;
 }
 JDEV float wave_min(float v) { return -wave_max(-v); }
+JDEV float half_max(float v) {
+  int p = emu_post_f(v);
+  emu_collective();
+  const int h0 = emu_cur_lane & 32;
+  float m = emu_x[p][h0].f;
+  for (int l = h0 + 1; l < h0 + 32; l++) m = fmaxf(m, emu_x[p][l].f);
+  return m;
+}
 JDEV int wave_argmax(float v, int idx, float* best) {
   int p = emu_post_f(v);
   emu_collective();

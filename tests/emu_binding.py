@@ -21,10 +21,10 @@ _libs = {}
 
 def lib(layout=""):
     """layout "": the default build (11 bodies / 21 dofs in blocks 9 + 6 + 6); "_d12": the build for jaco2_torque.xml (12 hinge dofs, one tree);
-    "_d30": the build for jaco2_dual_torque.xml (two arms + two objects, 30 dofs; ctrl level); "_wrench" / "_nolook": A/B builds of the default layout
-    (body-space constraint rows; the Newton solver without its look-ahead stop)."""
+    "_d30": the build for jaco2_dual_torque.xml (two arms + two objects, 30 dofs; ctrl level); "_wrench" / "_nolook" / "_mprpairs": A/B builds of the default layout
+    (body-space constraint rows; the Newton solver without its look-ahead stop; MPR two pairs per wave)."""
     if layout not in _libs:
-        subprocess.check_call(["make", "-s", "-C", EMU_DIR] + (["libjaco_emu%s.so" % layout] if layout in ("_wrench", "_nolook") else []))   # (A/B builds: on demand)
+        subprocess.check_call(["make", "-s", "-C", EMU_DIR] + (["libjaco_emu%s.so" % layout] if layout in ("_wrench", "_nolook", "_mprpairs") else []))   # (A/B builds: on demand)
         L = ctypes.CDLL(os.path.join(EMU_DIR, "libjaco_emu%s.so" % layout))
         fp, ip, up = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint)
         L.emu_physics_step.argtypes = [ctypes.c_char_p, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int, fp, fp, fp, fp, fp, up, ip, fp, ctypes.c_int, ip]

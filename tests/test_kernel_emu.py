@@ -452,3 +452,44 @@ def test_newton_look_ahead_stop_saves_hessian_builds_and_keeps_the_solution(mode
     assert n1 == n0 == 150
     assert b1 <= b0 - 0.9 * n0, (b1, b0)     # one Hessian build fewer per solve (measured on this transient workload -- the object is being pushed out of its spawn overlap: 320 against 470)
     assert med1 <= 2 * med0 + 1e-7 and max1 <= 2 * max0 + 1e-6, (med1, med0, max1, max0)
+
+
+def test_mpr_pairs_do_not_change_results(model_arrays, names):
+    """Build option -DJACO_MPR_PAIRS=1 (measured on MI355X: no gain, not shipped; kept honest here): hull candidates go through MPR two at a time,
+    one per half wave (collision.h mpr_pair2; option "mpr_pairs"), their results parked for the in-order contact loop.  Per pair the
+    arithmetic, its order and the tie-breaking are those of the one-pair routine, so a free run of the in-hand grasp scenario (fingers closing onto
+    the object: ~10 hull pairs per substep, hits, near misses, cached separating directions coming and going) must give the same state, contact /
+    row counts and sensor values BIT FOR BIT with the option on and off -- and the two-pair routine must really have run."""
+    import ctypes
+    from mujoco_jaco_amd.modelc import rot
+    o = Oracle()
+    q = model_arrays["qpos0"].copy()
+    q[:6] = [1.3, 3.85, 1.05, 2.05, 1.5, -1.15]; q[6:9] = 0.6; q[16:18] = [.4, .3]
+    o.set("qpos", q); o.forward()
+    b = names["body"].index("EE_obj")
+    xp = o.get("xpos").reshape(-1, 3)[b]; xq = o.get("xquat").reshape(-1, 4)[b]
+    q[9:12] = xp + rot.quat_to_mat(xq) @ np.array([-0.04, 0, 0]); q[12:16] = xq
+    for cache in (1, 0):
+        runs, passes, calls = [], [], []
+        for on in (1, 0):
+            e = EmuEnv(layout="_mprpairs")   # (the build option's own emulator library, made on demand)
+            e.L.emu_set_mpr_pairs.argtypes = [ctypes.c_int]; e.L.emu_set_sep_cache.argtypes = [ctypes.c_int]
+            e.L.emu_get_counter.argtypes = [ctypes.c_int, ctypes.c_int]; e.L.emu_get_counter.restype = ctypes.c_long
+            e.L.emu_set_mpr_pairs(on); e.L.emu_set_sep_cache(cache)
+            try:
+                e.qpos[0] = q
+                for i in (3, 4, 10): e.L.emu_get_counter(i, 1)
+                trace = []
+                for i in range(40):
+                    g = min(1.0, 0.6 + 0.006 * i)
+                    e.step(np.array([0.5, -0.3, 0.2, 0.1, 0, 0, g, g, g]), nsub=1)
+                    trace.append((e.qpos.copy(), e.qvel.copy(), e.stats[:, :2].copy(), e.sensordata.copy(), e.flags.copy()))
+                runs.append(trace)
+                passes.append(e.L.emu_get_counter(10, 1)); calls.append((e.L.emu_get_counter(3, 1), e.L.emu_get_counter(4, 1)))
+            finally:
+                e.L.emu_set_mpr_pairs(1); e.L.emu_set_sep_cache(1)
+        for i, (ta, tb) in enumerate(zip(*runs)):
+            for x, y in zip(ta, tb):
+                assert np.array_equal(x, y), (cache, i)
+        print("separating-direction cache %d: %d passes of the two-pair routine over 40 substeps; MPR runs / hits %s with it, %s without" % (cache, passes[0], calls[0], calls[1]))
+        assert passes[0] > 80 and passes[1] == 0 and calls[0] == calls[1]
